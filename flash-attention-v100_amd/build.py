@@ -1,0 +1,72 @@
+"""Ahead-of-time build of libfa_mi355.so (hand-written HIP for gfx950).
+
+`hipcc` cross-compiles without a GPU, so the library is built in-tree in the build
+container and travels to the GPU box with the repository snapshot.  No torch headers are
+involved: the library is a plain C-ABI shared object (include/fa_mi355.h)."""
+import hashlib
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+OUT_DIR = os.path.join(HERE, "flash_attn_mi355")
+LIB = os.path.join(OUT_DIR, "libfa_mi355.so")
+SOURCES = ["fa_api.hip", "fa_fwd.hip", "fa_bwd.hip", "fa_kvcache.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"),
+         "-I" + CSRC, "-Wno-unused-value"]
+
+
+def _hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    return "hipcc"
+
+
+def _digest(paths):
+    h = hashlib.sha256()
+    for p in sorted(paths):
+        h.update(p.encode())
+        h.update(open(p, "rb").read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def build(force=False, verbose=False):
+    """Compile every HIP source for gfx950 and link libfa_mi355.so. Returns the path."""
+    bdir = os.path.join(CSRC, "build")
+    os.makedirs(bdir, exist_ok=True)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
+    deps.append(os.path.join(ROOT, "include", "fa_mi355.h"))
+    stamp = os.path.join(bdir, "stamp.txt")
+    dig = _digest(deps)
+    if (not force and os.path.exists(LIB) and os.path.exists(stamp)
+            and open(stamp).read().strip() == dig):
+        return LIB
+    hipcc = _hipcc()
+    procs = []
+    objs = []
+    for src in SOURCES:
+        obj = os.path.join(bdir, src.replace(".hip", ".o"))
+        objs.append(obj)
+        cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for src, pr in procs:
+        out, _ = pr.communicate()
+        if pr.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {src}:\n{out.decode(errors='replace')}")
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    if out.returncode != 0:
+        raise RuntimeError("link failed:\n" + out.stdout.decode(errors="replace"))
+    with open(stamp, "w") as f:
+        f.write(dig)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,230 @@
+// fa_api.hip - extern "C" entry points of libfa_mi355.so (see include/fa_mi355.h).
+//
+// Host-side validation and flag normalisation mirror the reference's wrappers:
+//   dense    kernel/fused_mha_forward.cu:317-371,409-413
+//   varlen   kernel/fused_mha_forward_varlen.cu:371-482
+//   kvcache  kernel/fused_mha_forward_kvcache.cu:416-472,488,582-598
+//   backward kernel/fused_mha_backward.cu:577-692, kernel/fused_mha_backward_varlen.cu:636-765
+// Errors never cross the boundary as exceptions: negative status + fa_last_error().
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include "fa_common.h"
+
+namespace fa {
+int launch_fwd(const KArgs& a, hipStream_t stream);
+int launch_bwd(const KArgs& a, hipStream_t stream);
+size_t bwd_workspace_bytes(const fa_params& p);
+int launch_kvcache_append(const KArgs& a, hipStream_t stream);
+int launch_decode(const KArgs& a, hipStream_t stream);
+size_t decode_workspace_bytes(const fa_params& p);
+bool decode_applicable(const fa_params& p);
+}  // namespace fa
+
+static thread_local std::string g_last_error;
+
+static int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define FA_CHECK(cond, ...)                                              \
+    do {                                                                 \
+        if (!(cond)) return fail(FA_ERR_INVALID_ARGUMENT, __VA_ARGS__);  \
+    } while (0)
+
+static int check_hip(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(FA_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e));
+    return FA_OK;
+}
+
+static bool supported_head_dim(int d) { return d == 64 || d == 128; }
+
+// Checks shared by every op (reference: fused_mha_forward.cu:324-340).
+static int check_common(const fa_params& p, bool need_out) {
+    const bool no_keys = (p.seqlen_k == 0 && !p.cu_seqlens_k);
+    FA_CHECK(p.q && (no_keys || (p.k && p.v)), "q, k, v must not be NULL");
+    FA_CHECK(!need_out || (p.o && p.lse), "o and lse must not be NULL");
+    FA_CHECK(p.dtype == FA_FP16 || p.dtype == FA_BF16, "q must be fp16 or bf16");
+    FA_CHECK(p.batch > 0, "batch size must be positive");
+    FA_CHECK(p.head_dim <= 256, "head dimension must be <= 256");
+    FA_CHECK(p.head_dim % 8 == 0, "head dimension must be multiple of 8");
+    FA_CHECK(p.nheads_k > 0 && p.nheads_q % p.nheads_k == 0, "H_Q must be divisible by H_K for GQA/MQA");
+    FA_CHECK(p.p_dropout >= 0.f && p.p_dropout < 1.f, "p_dropout must be in [0, 1)");
+    if (p.softcap > 0.f) FA_CHECK(p.p_dropout == 0.f, "Softcapping does not support dropout for now");
+    FA_CHECK((p.q_row_stride % 8) == 0 && (p.q_head_stride % 8) == 0 && (p.k_row_stride % 8) == 0 &&
+             (p.k_head_stride % 8) == 0 && (p.v_row_stride % 8) == 0 && (p.v_head_stride % 8) == 0,
+             "q/k/v strides must be multiples of 8 elements (16-byte rows)");
+    FA_CHECK((reinterpret_cast<uintptr_t>(p.q) & 15) == 0 && (reinterpret_cast<uintptr_t>(p.k) & 15) == 0 &&
+             (reinterpret_cast<uintptr_t>(p.v) & 15) == 0, "q/k/v must be 16-byte aligned");
+    if (!supported_head_dim(p.head_dim))
+        return fail(FA_ERR_UNSUPPORTED, "head dimension %d has no gfx950 kernel in this build (64, 128)", p.head_dim);
+    return FA_OK;
+}
+
+// Flag normalisation (reference: fused_mha_forward.cu:343-352).
+static void normalize(fa_params& p, bool kvcache) {
+    if (p.seqlen_q == 1 && !p.alibi_slopes) p.is_causal = 0;
+    if (kvcache && p.is_causal) p.window_right = 0;
+    if (p.window_left >= p.seqlen_k) p.window_left = -1;
+    if (p.window_right >= p.seqlen_k) p.window_right = -1;
+}
+
+static fa::KArgs make_args(const fa_params& p, int block_m) {
+    fa::KArgs a;
+    memset(&a, 0, sizeof(a));
+    a.p = p;
+    a.n_qblocks = (p.seqlen_q + block_m - 1) / block_m;
+    a.has_bias = (p.alibi_slopes != nullptr) || (p.softcap > 0.f);
+    a.scale_log2e = p.softmax_scale * fa::kLog2e;
+    return a;
+}
+
+extern "C" {
+
+int fa_abi_version(void) { return FA_ABI_VERSION; }
+size_t fa_params_size(void) { return sizeof(fa_params); }
+const char* fa_last_error(void) { return g_last_error.c_str(); }
+const char* fa_build_info(void) {
+    return "libfa_mi355: gfx950 (CDNA4) hand-written HIP; mfma_f32_32x32x16_{bf16,f16}; head_dim {64,128}; "
+           "ops fwd/bwd/varlen_fwd/varlen_bwd/fwd_kvcache";
+}
+
+size_t fa_fwd_workspace_bytes(const fa_params*) { return 0; }
+size_t fa_bwd_workspace_bytes(const fa_params* p) { return p ? fa::bwd_workspace_bytes(*p) : 0; }
+size_t fa_fwd_kvcache_workspace_bytes(const fa_params* p) { return p ? fa::decode_workspace_bytes(*p) : 0; }
+
+int fa_fwd(const fa_params* pp, void* stream) {
+    if (!pp) return fail(FA_ERR_INVALID_ARGUMENT, "params is NULL");
+    fa_params p = *pp;
+    p.cu_seqlens_q = p.cu_seqlens_k = p.seqused_k = nullptr;
+    p.block_table = nullptr;
+    int rc = check_common(p, true);
+    if (rc) return rc;
+    FA_CHECK(p.kv_dtype == p.dtype, "k/v must have the same dtype as q");
+    FA_CHECK(p.seqlen_q >= 0 && p.seqlen_k >= 0, "sequence lengths must be non-negative");
+    if (p.p_dropout > 0.f) return fail(FA_ERR_UNSUPPORTED, "dropout is not implemented in this build yet");
+    if (p.seqlen_q == 0) return FA_OK;
+    normalize(p, false);
+    fa::KArgs a = make_args(p, 128);
+    rc = fa::launch_fwd(a, static_cast<hipStream_t>(stream));
+    if (rc) return fail(FA_ERR_UNSUPPORTED, "no forward kernel for this configuration");
+    return check_hip("fa_fwd launch");
+}
+
+int fa_varlen_fwd(const fa_params* pp, void* stream) {
+    if (!pp) return fail(FA_ERR_INVALID_ARGUMENT, "params is NULL");
+    fa_params p = *pp;
+    int rc = check_common(p, true);
+    if (rc) return rc;
+    FA_CHECK(p.kv_dtype == p.dtype, "k/v must have the same dtype as q");
+    FA_CHECK(p.cu_seqlens_q && p.cu_seqlens_k, "cu_seqlens_q and cu_seqlens_k are required");
+    if (p.block_table) {
+        FA_CHECK(p.page_block_size > 0, "page_block_size must be positive");
+        FA_CHECK(p.page_block_size % 64 == 0, "Paged KV cache block size must be divisible by 64");
+    }
+    if (p.p_dropout > 0.f) return fail(FA_ERR_UNSUPPORTED, "dropout is not implemented in this build yet");
+    if (p.total_q == 0 || p.seqlen_q == 0) return FA_OK;
+    normalize(p, false);
+    fa::KArgs a = make_args(p, 128);
+    a.seqlens_k = p.seqused_k;
+    rc = fa::launch_fwd(a, static_cast<hipStream_t>(stream));
+    if (rc) return fail(FA_ERR_UNSUPPORTED, "no varlen forward kernel for this configuration");
+    return check_hip("fa_varlen_fwd launch");
+}
+
+int fa_fwd_kvcache(const fa_params* pp, void* stream) {
+    if (!pp) return fail(FA_ERR_INVALID_ARGUMENT, "params is NULL");
+    fa_params p = *pp;
+    p.cu_seqlens_q = p.cu_seqlens_k = p.seqused_k = nullptr;
+    int rc = check_common(p, true);
+    if (rc) return rc;
+    FA_CHECK(p.kv_dtype == p.dtype || p.kv_dtype == FA_FP8_E4M3, "kcache/vcache must match q dtype or be fp8-e4m3");
+    FA_CHECK(p.p_dropout == 0.f, "kvcache attention has no dropout");
+    const bool paged = p.block_table != nullptr;
+    if (paged) {
+        FA_CHECK(!p.cache_batch_idx, "Paged KVcache does not support cache_batch_idx");
+        FA_CHECK(p.page_block_size > 0 && p.page_block_size % 64 == 0,
+                 "Paged KV cache block size must be divisible by 64");
+    }
+    if (p.k_new || p.v_new) {
+        FA_CHECK(p.k_new && p.v_new, "If key is supplied, value must also be passed in");
+        FA_CHECK(p.cache_seqlens, "If key is supplied, seqlens_k must also be passed in");
+        FA_CHECK(p.seqlen_new > 0, "seqlen_new must be positive when k/v are supplied");
+    } else {
+        p.seqlen_new = 0;
+    }
+    if (p.rotary_dim > 0) {
+        FA_CHECK(p.k_new, "If rotary cos/sin are provided, new key / value to be appended to KV cache must also be provided");
+        FA_CHECK(p.rotary_cos && p.rotary_sin, "rotary_cos and rotary_sin must both be given");
+        FA_CHECK(p.rotary_dim <= p.head_dim, "rotary_dim must be <= head_dim");
+        FA_CHECK(p.rotary_dim % 16 == 0, "rotary_dim must be divisible by 16");
+        FA_CHECK(p.seqlen_ro >= p.seqlen_k + p.seqlen_new || p.seqlen_ro >= p.seqlen_k,
+                 "rotary_cos seqlen too small");
+    }
+    if (p.num_splits < 0) return fail(FA_ERR_INVALID_ARGUMENT, "num_splits must be >= 0");
+    // reference: fused_mha_forward_kvcache.cu:465-472
+    normalize(p, true);
+    if (p.softcap > 0.f) {
+        FA_CHECK(p.window_left < 0 && p.window_right < 0, "Softcap + window not supported");
+        FA_CHECK(!p.alibi_slopes, "Softcap + ALiBi not supported");
+    }
+    if (p.seqlen_q == 0) return FA_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    fa::KArgs a = make_args(p, 128);
+    a.seqlens_k = p.cache_seqlens;
+    a.seqlen_k_add = p.seqlen_new;
+    a.kv_batch_idx = p.cache_batch_idx;
+    a.leftpad_k = p.cache_leftpad;
+    rc = fa::launch_decode(a, s);
+    if (rc == -2) return fail(FA_ERR_UNSUPPORTED, "no kvcache kernel for this configuration");
+    if (rc) return rc;
+    return check_hip("fa_fwd_kvcache launch");
+}
+
+int fa_bwd(const fa_params* pp, void* stream) {
+    if (!pp) return fail(FA_ERR_INVALID_ARGUMENT, "params is NULL");
+    fa_params p = *pp;
+    p.cu_seqlens_q = p.cu_seqlens_k = p.seqused_k = nullptr;
+    p.block_table = nullptr;
+    int rc = check_common(p, true);
+    if (rc) return rc;
+    FA_CHECK(p.dout && p.dq && p.dk && p.dv && p.softmax_d, "dout, dq, dk, dv, softmax_d must not be NULL");
+    FA_CHECK(p.kv_dtype == p.dtype, "k/v must have the same dtype as q");
+    if (p.p_dropout > 0.f) return fail(FA_ERR_UNSUPPORTED, "dropout is not implemented in this build yet");
+    if (p.seqlen_q == 0 && p.seqlen_k == 0) return FA_OK;
+    normalize(p, false);
+    fa::KArgs a = make_args(p, 128);
+    rc = fa::launch_bwd(a, static_cast<hipStream_t>(stream));
+    if (rc == -2) return fail(FA_ERR_UNSUPPORTED, "no backward kernel for this configuration");
+    if (rc) return rc;
+    return check_hip("fa_bwd launch");
+}
+
+int fa_varlen_bwd(const fa_params* pp, void* stream) {
+    if (!pp) return fail(FA_ERR_INVALID_ARGUMENT, "params is NULL");
+    fa_params p = *pp;
+    p.block_table = nullptr;
+    int rc = check_common(p, true);
+    if (rc) return rc;
+    FA_CHECK(p.dout && p.dq && p.dk && p.dv && p.softmax_d, "dout, dq, dk, dv, softmax_d must not be NULL");
+    FA_CHECK(p.cu_seqlens_q && p.cu_seqlens_k, "cu_seqlens_q and cu_seqlens_k are required");
+    FA_CHECK(p.kv_dtype == p.dtype, "k/v must have the same dtype as q");
+    if (p.p_dropout > 0.f) return fail(FA_ERR_UNSUPPORTED, "dropout is not implemented in this build yet");
+    if (p.total_q == 0) return FA_OK;
+    normalize(p, false);
+    fa::KArgs a = make_args(p, 128);
+    rc = fa::launch_bwd(a, static_cast<hipStream_t>(stream));
+    if (rc == -2) return fail(FA_ERR_UNSUPPORTED, "no varlen backward kernel for this configuration");
+    if (rc) return rc;
+    return check_hip("fa_varlen_bwd launch");
+}
+
+}  // extern "C"

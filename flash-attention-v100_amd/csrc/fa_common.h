@@ -1,0 +1,160 @@
+// fa_common.h - device-side building blocks shared by the gfx950 attention kernels.
+//
+// Fragment conventions (v_mfma_f32_32x32x16_{bf16,f16}, wave64):
+//   lane l: l31 = l & 31, g = l >> 5
+//   A operand: lane holds A[i = l31][k = 8g + j]  (j = 0..7, 16 bytes)
+//   B operand: lane holds B[k = 8g + j][n = l31]
+//   C/D:       lane holds D[row(r, g)][col = l31],  row(r, g) = (r & 3) + 8 (r >> 2) + 4 g
+// The contraction index k only has to be named consistently by A and B, which lets a
+// C/D fragment be fed straight back as a B operand ("slot order", see fa_fwd.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "fa_mi355.h"
+
+namespace fa {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+struct bf16_tag {};
+struct fp16_tag {};
+
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kLn2 = 0.6931471805599453f;
+
+template <typename T> struct Elem;
+
+template <> struct Elem<bf16_tag> {
+    static __device__ __forceinline__ f32x16 mfma(u32x4 a, u32x4 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a),
+                                                       __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
+        f32x2 v = {lo, hi};
+        return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+    }
+    static __device__ __forceinline__ float lo(uint32_t w) { return __builtin_bit_cast(float, w << 16); }
+    static __device__ __forceinline__ float hi(uint32_t w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
+};
+
+template <> struct Elem<fp16_tag> {
+    static __device__ __forceinline__ f32x16 mfma(u32x4 a, u32x4 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a),
+                                                      __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
+        f32x2 v = {lo, hi};
+        return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2));
+    }
+    static __device__ __forceinline__ float lo(uint32_t w) {
+        return (float)__builtin_bit_cast(f16x2, w)[0];
+    }
+    static __device__ __forceinline__ float hi(uint32_t w) {
+        return (float)__builtin_bit_cast(f16x2, w)[1];
+    }
+};
+
+// ---- LDS helpers -----------------------------------------------------------------
+typedef __attribute__((__vector_size__(4 * sizeof(short)))) short lds_i16x4_t;
+
+// ds_read_b64_tr_b16: within each 16-lane group the 16 x 8-byte loads form a
+// [4 rows][16 cols] matrix (lane i' supplies row i'>>2, cols 4(i'&3)..+3); lane i
+// receives column i: element j = M[j][i].
+__device__ __forceinline__ u32x2 lds_read_tr16(const char* smem_ptr) {
+    auto p = (__attribute__((address_space(3))) lds_i16x4_t*)(smem_ptr);
+    return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16(p));
+}
+
+__device__ __forceinline__ u32x4 lds_read_b128(const char* smem_ptr) {
+    return *reinterpret_cast<const u32x4*>(smem_ptr);
+}
+__device__ __forceinline__ void lds_write_b128(char* smem_ptr, u32x4 v) {
+    *reinterpret_cast<u32x4*>(smem_ptr) = v;
+}
+
+// Row-major [rows][D] 16-bit tile, XOR-swizzled in 16-byte slots so that ds_read_b128 of
+// one logical slot from 16 rows that differ mod 16 is bank-conflict free
+// (bank = (addr/4) % 64 over a 256-byte line).
+template <int D>
+__device__ __forceinline__ int swz_row_off(int row, int col_byte) {
+    constexpr int ROWB = D * 2;
+    constexpr int SPR = ROWB / 16;                       // 16-B slots per row
+    constexpr int MASK = (SPR < 16 ? SPR : 16) - 1;
+    constexpr int SHIFT = (SPR >= 16) ? 0 : (SPR == 8 ? 1 : (SPR == 4 ? 2 : 3));
+    const int f = (row >> SHIFT) & MASK;
+    return row * ROWB + (col_byte ^ (f << 4));
+}
+
+// [rows][D] 16-bit tile stored as [rows/4][D/32] blocks of [4 rows][32 cols] (256 B each):
+// a 32-lane ds_read_b64_tr_b16 then covers exactly one 256-byte bank line.
+template <int D>
+__device__ __forceinline__ int vtile_off(int row, int col) {
+    return (((row >> 2) * (D / 32) + (col >> 5)) << 8) + ((row & 3) << 6) + ((col & 31) << 1);
+}
+
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float fast_log2(float x) { return __builtin_amdgcn_logf(x); }
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
+// tanh via exp2: tanh(x) = 1 - 2 / (1 + e^{2x}); saturates correctly at +-inf.
+__device__ __forceinline__ float fast_tanh(float x) {
+    const float e = fast_exp2(x * (2.0f * kLog2e));
+    return 1.0f - 2.0f * fast_rcp(1.0f + e);
+}
+
+__device__ __forceinline__ float shfl_xor32(float v) {
+    // exchange between lane l and l ^ 32
+    return __shfl_xor(v, 32, 64);
+}
+
+// Work decomposition shared by forward-like kernels: 1-D grid, block id -> XCD-aware
+// (kv-head unit, q-head in group, q-block heavy-first).  Blocks observed to land on XCD
+// id % 8 (speed only, never correctness): all q-blocks of the q-heads sharing a kv-head
+// run on one XCD so K/V stay in that XCD's L2.
+struct WorkItem { int b, h, hk, qb; bool valid; };
+__device__ __forceinline__ WorkItem decode_work(int id, int batch, int nheads_q, int nheads_k,
+                                                int n_qblocks) {
+    WorkItem w;
+    const int group = nheads_q / nheads_k;
+    const int units = batch * nheads_k;
+    const int xcd = id & 7;
+    const int j = id >> 3;
+    const int per_unit = group * n_qblocks;
+    const int ul = j / per_unit;
+    const int rem = j - ul * per_unit;
+    const int gq = rem / n_qblocks;
+    const int unit = ul * 8 + xcd;
+    w.valid = unit < units;
+    w.qb = n_qblocks - 1 - (rem - gq * n_qblocks);
+    w.b = unit / nheads_k;
+    w.hk = unit - w.b * nheads_k;
+    w.h = w.hk * group + gq;
+    return w;
+}
+static inline int work_grid(int batch, int nheads_q, int nheads_k, int n_qblocks) {
+    const int units = batch * nheads_k;
+    const int upx = (units + 7) / 8;
+    return 8 * upx * (nheads_q / nheads_k) * n_qblocks;
+}
+
+// Host-side launch args: the ABI struct plus derived values.
+struct KArgs {
+    fa_params p;
+    int n_qblocks;
+    int has_bias;          // alibi or softcap
+    float scale_log2e;
+    const int32_t* seqlens_k;      // per-batch key count (seqused_k or cache_seqlens), or NULL
+    int seqlen_k_add;              // added to seqlens_k[b] (kvcache: T_new)
+    const int32_t* kv_batch_idx;   // cache_batch_idx or NULL
+    const int32_t* leftpad_k;      // or NULL
+};
+
+}  // namespace fa

@@ -1,0 +1,451 @@
+"""Python operator API of the MI355X fused attention path.
+
+Mirrors the reference's operator layer name for name
+(flash_attn_v100/flash_attn_interface.py:115-127, :272-289, :323-343, :393-401):
+`flash_attn_func`, `flash_attn_varlen_func`, `flash_attn_with_kvcache` (+ `_gpu` aliases),
+same positional/keyword arguments, defaults and return conventions.  Differences, all
+deliberate (DESIGN.md "divergences"):
+  * tensors are handed to the C ABI (include/fa_mi355.h) with their strides - none of the
+    reference's permute().contiguous() copies (flash_attn_interface.py:36-53,67);
+  * fp16 AND bf16; any head_dim <= 128 (zero-padded to 64/128 on the host);
+  * `return_attn_probs=True` works with dropout_p == 0 (returns an empty dmask) instead of
+    raising (kernel/fused_mha_forward.cu:371);
+  * `flash_attn_with_kvcache` accepts fp8-e4m3 caches with `k_descale` / `v_descale`.
+There is no CPU fallback: tensors must live on an AMD GPU and the HIP library must load.
+"""
+import ctypes
+import traceback
+import warnings
+from typing import Optional, Tuple, Union
+
+import torch
+
+from . import _lib
+from ._lib import FaParams
+
+_DTYPES = {torch.float16: _lib.FA_FP16, torch.bfloat16: _lib.FA_BF16}
+
+
+def maybe_contiguous(x):
+    return x.contiguous() if x is not None and not x.is_contiguous() else x
+
+
+def _padded_head_dim(d: int) -> int:
+    if d <= 64:
+        return 64
+    if d <= 128:
+        return 128
+    raise RuntimeError(f"head dimension {d} > 128 has no gfx950 kernel in this build")
+
+
+def _prep(x: torch.Tensor, dpad: int) -> torch.Tensor:
+    """Last dim contiguous, 16-byte aligned rows, head dim padded with zeros to `dpad`."""
+    d = x.shape[-1]
+    if d != dpad:
+        x = torch.nn.functional.pad(x, [0, dpad - d])
+    ok = x.stride(-1) == 1 and x.data_ptr() % 16 == 0 and all(s % 8 == 0 for s in x.stride()[:-1])
+    return x if ok else x.contiguous()
+
+
+def _check_device(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("flash_attn_mi355: tensors must be on the GPU (no CPU fallback)")
+
+
+def _stream(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _set3(p, name, t, layout):
+    """layout 'bshd': [B,S,H,D]; 'thd': [T,H,D]; 'pshd': paged [nblk,page,H,D]."""
+    if layout in ("bshd", "pshd"):
+        setattr(p, name + "_batch_stride", t.stride(0))
+        setattr(p, name + "_row_stride", t.stride(1))
+        setattr(p, name + "_head_stride", t.stride(2))
+    else:
+        setattr(p, name + "_batch_stride", 0)
+        setattr(p, name + "_row_stride", t.stride(0))
+        setattr(p, name + "_head_stride", t.stride(1))
+
+
+def _alibi(p, alibi_slopes, batch, nheads, device):
+    if alibi_slopes is None:
+        return None
+    if alibi_slopes.dtype != torch.float32 or not alibi_slopes.is_cuda:
+        raise RuntimeError("alibi_slopes must be fp32 on the GPU")
+    if alibi_slopes.stride(-1) != 1:
+        raise RuntimeError("alibi_slopes last dim must be contiguous")
+    if not (tuple(alibi_slopes.shape) == (nheads,) or tuple(alibi_slopes.shape) == (batch, nheads)):
+        raise RuntimeError("alibi_slopes must be [H_Q] or [B, H_Q]")
+    p.alibi_slopes = _ptr(alibi_slopes)
+    p.alibi_batch_stride = alibi_slopes.stride(0) if alibi_slopes.dim() == 2 else 0
+    return alibi_slopes
+
+
+def _philox(p, dropout_p, batch, nheads, device, rng=None):
+    """Seed/offset from the default GPU generator; the offset advances by B*H*32 per call
+    (kernel/fused_mha_forward.cu:377-386)."""
+    p.p_dropout = float(dropout_p)
+    if dropout_p <= 0.0:
+        return (0, 0)
+    if rng is None:
+        gen = torch.cuda.default_generators[device.index if device.index is not None
+                                            else torch.cuda.current_device()]
+        seed, offset = gen.initial_seed(), gen.get_offset()
+        gen.set_offset(offset + batch * nheads * 32)
+        rng = (seed, offset)
+    p.philox_seed, p.philox_offset = rng[0] & 0xFFFFFFFFFFFFFFFF, rng[1]
+    return rng
+
+
+def _workspace(nbytes, device):
+    if nbytes <= 0:
+        return None
+    return torch.empty(nbytes, dtype=torch.uint8, device=device)
+
+
+def _base_params(q, dtype, scale, causal, window_size, softcap):
+    p = FaParams()
+    p.dtype = p.kv_dtype = _DTYPES[dtype]
+    p.softmax_scale = float(scale)
+    p.softcap = float(softcap)
+    p.is_causal = int(bool(causal))
+    p.window_left, p.window_right = int(window_size[0]), int(window_size[1])
+    p.k_descale = p.v_descale = 1.0
+    return p
+
+
+# ======================================================================================
+# DENSE ATTENTION (B, M, H, D)
+# ======================================================================================
+class FlashAttnFunc(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, dropout_p, softmax_scale, causal, window_size, softcap,
+                alibi_slopes, deterministic, return_softmax, is_grad_enabled):
+        is_grad = is_grad_enabled and any(x.requires_grad for x in [q, k, v])
+        _check_device(q, k, v)
+        if q.dtype not in _DTYPES:
+            raise RuntimeError("q must be fp16 or bf16")
+        B, M, H_Q, head_size_og = q.shape
+        N, H_K = k.shape[1], k.shape[2]
+        dpad = _padded_head_dim(head_size_og)
+        q_, k_, v_ = _prep(q, dpad), _prep(k, dpad), _prep(v, dpad)
+        if softmax_scale is None:
+            softmax_scale = head_size_og ** -0.5
+
+        out_ = torch.empty((B, M, H_Q, dpad), dtype=q.dtype, device=q.device)
+        lse = torch.empty((B, H_Q, M), dtype=torch.float32, device=q.device)
+        p = _base_params(q_, q.dtype, softmax_scale, causal, window_size, softcap)
+        p.q, p.k, p.v, p.o, p.lse = _ptr(q_), _ptr(k_), _ptr(v_), _ptr(out_), _ptr(lse)
+        _set3(p, "q", q_, "bshd"); _set3(p, "k", k_, "bshd"); _set3(p, "v", v_, "bshd")
+        _set3(p, "o", out_, "bshd")
+        p.lse_batch_stride, p.lse_head_stride = lse.stride(0), lse.stride(1)
+        p.batch, p.nheads_q, p.nheads_k = B, H_Q, H_K
+        p.seqlen_q, p.seqlen_k, p.head_dim = M, N, dpad
+        _alibi(p, alibi_slopes, B, H_Q, q.device)
+        rng = _philox(p, dropout_p, B, H_Q, q.device)
+        dmask = torch.empty((0,), dtype=q.dtype, device=q.device)
+        if return_softmax and dropout_p > 0.0:
+            dmask = torch.empty((B, H_Q, M, N), dtype=q.dtype, device=q.device)
+            p.dmask = _ptr(dmask)
+        with torch.cuda.device(q.device):
+            _lib.call("fa_fwd", p, _stream(q.device))
+        out = out_ if dpad == head_size_og else out_[..., :head_size_og].contiguous()
+
+        if is_grad:
+            ctx.save_for_backward(q_, k_, v_, out_, lse, alibi_slopes)
+            ctx.dropout_p = dropout_p
+            ctx.softmax_scale = softmax_scale
+            ctx.causal = causal
+            ctx.window_size = window_size
+            ctx.softcap = softcap
+            ctx.deterministic = deterministic
+            ctx.head_size_og = head_size_og
+            ctx.rng = rng
+        return (out, lse, dmask) if return_softmax else out
+
+    @staticmethod
+    def backward(ctx, dout, *args):
+        q_, k_, v_, out_, lse, alibi_slopes = ctx.saved_tensors
+        head_size_og = ctx.head_size_og
+        B, M, H_Q, dpad = q_.shape
+        N, H_K = k_.shape[1], k_.shape[2]
+        dout_ = _prep(dout, dpad)
+        dq_, dk_, dv_ = torch.empty_like(q_), torch.empty_like(k_), torch.empty_like(v_)
+        dq_, dk_, dv_ = (_prep(t, dpad) for t in (dq_, dk_, dv_))
+        softmax_d = torch.empty((B, H_Q, M), dtype=torch.float32, device=q_.device)
+        p = _base_params(q_, q_.dtype, ctx.softmax_scale, ctx.causal, ctx.window_size, ctx.softcap)
+        p.q, p.k, p.v, p.o, p.lse = _ptr(q_), _ptr(k_), _ptr(v_), _ptr(out_), _ptr(lse)
+        p.dout, p.dq, p.dk, p.dv, p.softmax_d = _ptr(dout_), _ptr(dq_), _ptr(dk_), _ptr(dv_), _ptr(softmax_d)
+        for name, t in (("q", q_), ("k", k_), ("v", v_), ("o", out_), ("do", dout_),
+                        ("dq", dq_), ("dk", dk_), ("dv", dv_)):
+            _set3(p, name, t, "bshd")
+        p.lse_batch_stride, p.lse_head_stride = lse.stride(0), lse.stride(1)
+        p.batch, p.nheads_q, p.nheads_k = B, H_Q, H_K
+        p.seqlen_q, p.seqlen_k, p.head_dim = M, N, dpad
+        _alibi(p, alibi_slopes, B, H_Q, q_.device)
+        _philox(p, ctx.dropout_p, B, H_Q, q_.device, rng=ctx.rng)
+        ws = _workspace(_lib.lib.fa_bwd_workspace_bytes(ctypes.byref(p)), q_.device)
+        if ws is not None:
+            p.workspace, p.workspace_bytes = _ptr(ws), ws.numel()
+        with torch.cuda.device(q_.device):
+            _lib.call("fa_bwd", p, _stream(q_.device))
+        dq = dq_[..., :head_size_og]
+        dk = dk_[..., :head_size_og]
+        dv = dv_[..., :head_size_og]
+        return dq, dk, dv, None, None, None, None, None, None, None, None, None, None
+
+
+def flash_attn_func(q, k, v, dropout_p: float = 0.0, softmax_scale: float = None,
+                    causal: bool = False, window_size: Tuple[int, int] = (-1, -1),
+                    softcap: float = 0.0, alibi_slopes: Optional[torch.Tensor] = None,
+                    deterministic: bool = False, return_attn_probs: bool = False):
+    """Dense Flash Attention (B, M, H, D)"""
+    if deterministic:
+        # the reference warns and clears the flag (flash_attn_interface.py:129-131); our
+        # backward is atomic-free, i.e. always deterministic, so the request is honoured.
+        warnings.warn("Forward is always deterministic. Backward on gfx950 is atomic-free and "
+                      "deterministic as well.", RuntimeWarning)
+        deterministic = False
+    try:
+        return FlashAttnFunc.apply(q, k, v, dropout_p, softmax_scale, causal, window_size, softcap,
+                                   alibi_slopes, deterministic, return_attn_probs,
+                                   torch.is_grad_enabled())
+    except Exception as e:
+        print(f"[MI355X FA2 DENSE FAILED] {type(e).__name__}: {e}")
+        traceback.print_exc()
+        raise
+
+
+# ======================================================================================
+# VARLEN ATTENTION (T, H, D)
+# ======================================================================================
+class FlashAttnVarlenFunc(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, dropout_p,
+                softmax_scale, causal, window_size, softcap, alibi_slopes, deterministic,
+                return_attn_probs, block_table, is_grad_enabled):
+        is_grad = is_grad_enabled and any(x.requires_grad for x in [q, k, v])
+        _check_device(q, k, v, cu_seqlens_q, cu_seqlens_k)
+        if q.dtype not in _DTYPES:
+            raise RuntimeError("q must be fp16 or bf16")
+        cu_seqlens_q = cu_seqlens_q.to(torch.int32).contiguous()
+        cu_seqlens_k = cu_seqlens_k.to(torch.int32).contiguous()
+        head_size_og = q.size(-1)
+        dpad = _padded_head_dim(head_size_og)
+        q_, k_, v_ = _prep(q, dpad), _prep(k, dpad), _prep(v, dpad)
+        if softmax_scale is None:
+            softmax_scale = head_size_og ** -0.5
+        T_Q, H_Q = q_.shape[0], q_.shape[1]
+        H_K = k_.shape[-2]
+        B = cu_seqlens_q.numel() - 1
+        paged = block_table is not None
+
+        out_ = torch.empty((T_Q, H_Q, dpad), dtype=q.dtype, device=q.device)
+        lse = torch.empty((H_Q, T_Q), dtype=torch.float32, device=q.device)
+        p = _base_params(q_, q.dtype, softmax_scale, causal, window_size, softcap)
+        p.q, p.k, p.v, p.o, p.lse = _ptr(q_), _ptr(k_), _ptr(v_), _ptr(out_), _ptr(lse)
+        _set3(p, "q", q_, "thd"); _set3(p, "o", out_, "thd")
+        _set3(p, "k", k_, "pshd" if paged else "thd"); _set3(p, "v", v_, "pshd" if paged else "thd")
+        p.lse_batch_stride, p.lse_head_stride = 0, lse.stride(0)
+        p.batch, p.nheads_q, p.nheads_k = B, H_Q, H_K
+        p.seqlen_q, p.seqlen_k, p.head_dim = int(max_seqlen_q), int(max_seqlen_k), dpad
+        p.cu_seqlens_q, p.cu_seqlens_k = _ptr(cu_seqlens_q), _ptr(cu_seqlens_k)
+        p.total_q = T_Q
+        p.total_k = 0 if paged else k_.shape[0]
+        if paged:
+            block_table = block_table.to(torch.int32).contiguous()
+            p.block_table = _ptr(block_table)
+            p.block_table_batch_stride = block_table.stride(0)
+            p.page_block_size = k_.shape[1]
+        _alibi(p, alibi_slopes, B, H_Q, q.device)
+        rng = _philox(p, dropout_p, B, H_Q, q.device)
+        dmask = torch.empty((0,), dtype=q.dtype, device=q.device)
+        if return_attn_probs and dropout_p > 0.0:
+            dmask = torch.empty((T_Q, H_Q, max_seqlen_k), dtype=q.dtype, device=q.device)
+            p.dmask = _ptr(dmask)
+        with torch.cuda.device(q.device):
+            _lib.call("fa_varlen_fwd", p, _stream(q.device))
+        out = out_ if dpad == head_size_og else out_[..., :head_size_og].contiguous()
+
+        if is_grad:
+            if paged:
+                raise RuntimeError("backward through paged K/V (block_table) is not supported")
+            ctx.save_for_backward(q_, k_, v_, out_, lse, cu_seqlens_q, cu_seqlens_k, alibi_slopes)
+            ctx.dropout_p = dropout_p
+            ctx.softmax_scale = softmax_scale
+            ctx.causal = causal
+            ctx.window_size = window_size
+            ctx.softcap = softcap
+            ctx.deterministic = deterministic
+            ctx.head_size_og = head_size_og
+            ctx.max_seqlen_q = max_seqlen_q
+            ctx.max_seqlen_k = max_seqlen_k
+            ctx.rng = rng
+        return (out, lse, dmask) if return_attn_probs else out
+
+    @staticmethod
+    def backward(ctx, dout, *args):
+        q_, k_, v_, out_, lse, cu_seqlens_q, cu_seqlens_k, alibi_slopes = ctx.saved_tensors
+        head_size_og = ctx.head_size_og
+        T_Q, H_Q, dpad = q_.shape
+        H_K = k_.shape[1]
+        B = cu_seqlens_q.numel() - 1
+        dout_ = _prep(dout, dpad)
+        dq_, dk_, dv_ = torch.empty_like(q_), torch.empty_like(k_), torch.empty_like(v_)
+        dq_, dk_, dv_ = (_prep(t, dpad) for t in (dq_, dk_, dv_))
+        softmax_d = torch.empty((H_Q, T_Q), dtype=torch.float32, device=q_.device)
+        p = _base_params(q_, q_.dtype, ctx.softmax_scale, ctx.causal, ctx.window_size, ctx.softcap)
+        p.q, p.k, p.v, p.o, p.lse = _ptr(q_), _ptr(k_), _ptr(v_), _ptr(out_), _ptr(lse)
+        p.dout, p.dq, p.dk, p.dv, p.softmax_d = _ptr(dout_), _ptr(dq_), _ptr(dk_), _ptr(dv_), _ptr(softmax_d)
+        for name, t in (("q", q_), ("k", k_), ("v", v_), ("o", out_), ("do", dout_),
+                        ("dq", dq_), ("dk", dk_), ("dv", dv_)):
+            _set3(p, name, t, "thd")
+        p.lse_batch_stride, p.lse_head_stride = 0, lse.stride(0)
+        p.batch, p.nheads_q, p.nheads_k = B, H_Q, H_K
+        p.seqlen_q, p.seqlen_k, p.head_dim = int(ctx.max_seqlen_q), int(ctx.max_seqlen_k), dpad
+        p.cu_seqlens_q, p.cu_seqlens_k = _ptr(cu_seqlens_q), _ptr(cu_seqlens_k)
+        p.total_q, p.total_k = T_Q, k_.shape[0]
+        _alibi(p, alibi_slopes, B, H_Q, q_.device)
+        _philox(p, ctx.dropout_p, B, H_Q, q_.device, rng=ctx.rng)
+        ws = _workspace(_lib.lib.fa_bwd_workspace_bytes(ctypes.byref(p)), q_.device)
+        if ws is not None:
+            p.workspace, p.workspace_bytes = _ptr(ws), ws.numel()
+        with torch.cuda.device(q_.device):
+            _lib.call("fa_varlen_bwd", p, _stream(q_.device))
+        dq = dq_[..., :head_size_og]
+        dk = dk_[..., :head_size_og]
+        dv = dv_[..., :head_size_og]
+        return (dq, dk, dv) + (None,) * 14
+
+
+def flash_attn_varlen_func(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q: int,
+                           max_seqlen_k: int, dropout_p: float = 0.0, softmax_scale: float = None,
+                           causal: bool = False, window_size: Tuple[int, int] = (-1, -1),
+                           softcap: float = 0.0, alibi_slopes: Optional[torch.Tensor] = None,
+                           deterministic: bool = False, return_attn_probs: bool = False,
+                           block_table: Optional[torch.Tensor] = None):
+    """Varlen Flash Attention (T, H, D)"""
+    if deterministic:
+        warnings.warn("Forward is always deterministic. Backward on gfx950 is atomic-free and "
+                      "deterministic as well.", RuntimeWarning)
+        deterministic = False
+    try:
+        return FlashAttnVarlenFunc.apply(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q,
+                                         max_seqlen_k, dropout_p, softmax_scale, causal,
+                                         window_size, softcap, alibi_slopes, deterministic,
+                                         return_attn_probs, block_table, torch.is_grad_enabled())
+    except Exception as e:
+        print(f"[MI355X FA2 VARLEN FAILED] {type(e).__name__}: {e}")
+        traceback.print_exc()
+        raise
+
+
+# ======================================================================================
+# KV ATTENTION
+# ======================================================================================
+def flash_attn_with_kvcache(q, k_cache, v_cache, k=None, v=None, rotary_cos=None, rotary_sin=None,
+                            cache_seqlens: Optional[Union[int, torch.Tensor]] = None,
+                            cache_batch_idx: Optional[torch.Tensor] = None,
+                            cache_leftpad: Optional[torch.Tensor] = None,
+                            block_table: Optional[torch.Tensor] = None,
+                            softmax_scale: Optional[float] = None, causal: bool = False,
+                            window_size: Tuple[int, int] = (-1, -1), softcap: float = 0.0,
+                            rotary_interleaved: bool = True,
+                            alibi_slopes: Optional[torch.Tensor] = None, num_splits: int = 0,
+                            return_softmax_lse: bool = False, *,
+                            k_descale: Optional[float] = None, v_descale: Optional[float] = None):
+    """FlashAttention with KV cache (B, M, H, D). k_cache / v_cache are updated in place."""
+    assert k_cache.stride(-1) == 1, "k_cache must have contiguous last dimension"
+    assert v_cache.stride(-1) == 1, "v_cache must have contiguous last dimension"
+    _check_device(q, k_cache, v_cache, k, v)
+    if q.dtype not in _DTYPES:
+        raise RuntimeError("q must be fp16 or bf16")
+    q, k, v = [maybe_contiguous(x) for x in (q, k, v)]
+    B, T_Q, H_Q, D = q.shape
+    if softmax_scale is None:
+        softmax_scale = D ** (-0.5)
+    if cache_seqlens is not None and isinstance(cache_seqlens, int):
+        cache_seqlens = torch.full((B,), cache_seqlens, dtype=torch.int32, device=k_cache.device)
+    cache_seqlens = maybe_contiguous(cache_seqlens)
+    cache_batch_idx = maybe_contiguous(cache_batch_idx)
+    cache_leftpad = maybe_contiguous(cache_leftpad)
+    block_table = maybe_contiguous(block_table)
+    for name, t in (("cache_seqlens", cache_seqlens), ("cache_batch_idx", cache_batch_idx),
+                    ("cache_leftpad", cache_leftpad), ("block_table", block_table)):
+        if t is not None and t.dtype != torch.int32:
+            raise RuntimeError(f"{name} must have dtype int32")
+    if D not in (64, 128):
+        raise RuntimeError(f"kvcache head dimension {D} has no gfx950 kernel in this build (64, 128)")
+    fp8 = k_cache.dtype == torch.float8_e4m3fn
+    if not fp8 and (k_cache.dtype != q.dtype or v_cache.dtype != q.dtype):
+        raise RuntimeError("kcache/vcache must have the same dtype as q (or float8_e4m3fn)")
+    paged = block_table is not None
+    H_K = k_cache.shape[2]
+
+    out = torch.empty_like(q)
+    lse = torch.empty((B, H_Q, T_Q), dtype=torch.float32, device=q.device)
+    p = _base_params(q, q.dtype, softmax_scale, causal, window_size, softcap)
+    if fp8:
+        p.kv_dtype = _lib.FA_FP8_E4M3
+        p.k_descale = 1.0 if k_descale is None else float(k_descale)
+        p.v_descale = 1.0 if v_descale is None else float(v_descale)
+    p.q, p.k, p.v, p.o, p.lse = _ptr(q), _ptr(k_cache), _ptr(v_cache), _ptr(out), _ptr(lse)
+    _set3(p, "q", q, "bshd"); _set3(p, "o", out, "bshd")
+    _set3(p, "k", k_cache, "bshd"); _set3(p, "v", v_cache, "bshd")
+    p.lse_batch_stride, p.lse_head_stride = lse.stride(0), lse.stride(1)
+    p.batch, p.nheads_q, p.nheads_k = B, H_Q, H_K
+    p.seqlen_q, p.head_dim = T_Q, D
+    if paged:
+        p.block_table = _ptr(block_table)
+        p.block_table_batch_stride = block_table.stride(0)
+        p.page_block_size = k_cache.shape[1]
+        p.seqlen_k = block_table.shape[1] * k_cache.shape[1]
+    else:
+        p.seqlen_k = k_cache.shape[1]
+    p.cache_seqlens = _ptr(cache_seqlens)
+    p.cache_batch_idx = _ptr(cache_batch_idx)
+    p.cache_leftpad = _ptr(cache_leftpad)
+    if k is not None:
+        if v is None:
+            raise RuntimeError("If key is supplied, value must also be passed in")
+        p.k_new, p.v_new = _ptr(k), _ptr(v)
+        _set3(p, "knew", k, "bshd"); _set3(p, "vnew", v, "bshd")
+        p.seqlen_new = k.shape[1]
+    if rotary_cos is not None:
+        if rotary_sin is None:
+            raise RuntimeError("rotary_sin must be given with rotary_cos")
+        if rotary_cos.dtype != q.dtype or rotary_sin.dtype != q.dtype:
+            raise RuntimeError("rotary_cos must have the same dtype as query")
+        if rotary_cos.dim() != 2 or not rotary_cos.is_contiguous() or not rotary_sin.is_contiguous():
+            raise RuntimeError("rotary_cos/rotary_sin must be contiguous 2D tensors")
+        p.rotary_cos, p.rotary_sin = _ptr(rotary_cos), _ptr(rotary_sin)
+        p.rotary_dim = rotary_cos.shape[1] * 2
+        p.seqlen_ro = rotary_cos.shape[0]
+        p.rotary_interleaved = int(bool(rotary_interleaved))
+    _alibi(p, alibi_slopes, B, H_Q, q.device)
+    p.num_splits = int(num_splits)
+    ws = _workspace(_lib.lib.fa_fwd_kvcache_workspace_bytes(ctypes.byref(p)), q.device)
+    if ws is not None:
+        p.workspace, p.workspace_bytes = _ptr(ws), ws.numel()
+    with torch.cuda.device(q.device):
+        _lib.call("fa_fwd_kvcache", p, _stream(q.device))
+    if return_softmax_lse:
+        return out, lse
+    return out
+
+
+flash_attn_gpu = flash_attn_func
+flash_attn_varlen_gpu = flash_attn_varlen_func
+flash_attn_with_kvcache_gpu = flash_attn_with_kvcache
+
+__all__ = [
+    "flash_attn_func", "flash_attn_gpu",
+    "flash_attn_varlen_func", "flash_attn_varlen_gpu",
+    "flash_attn_with_kvcache", "flash_attn_with_kvcache_gpu",
+]

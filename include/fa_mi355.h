@@ -1,0 +1,195 @@
+/*
+ * fa_mi355.h - C ABI of libfa_mi355.so: the MI355X (gfx950 / CDNA4) fused attention path.
+ *
+ * This is the drop-in boundary for the reference's private extension module
+ * `flash_attn_v100_cuda` (ai-bond/flash-attention-v100).  Each entry point replaces one
+ * op of that module; the reference prototypes are cited per function below
+ * (include/mha.h and kernel/fused_mha_api.cpp of the reference).
+ *
+ * Conventions
+ *   - plain C: raw device pointers, sizes, strides IN ELEMENTS, POD structs, an explicit
+ *     HIP stream (void* == hipStream_t).  No torch / ATen types.
+ *   - never allocates: the caller owns every buffer (outputs, workspaces).  Workspace
+ *     sizes come from the *_workspace_bytes() queries.
+ *   - never throws: returns FA_OK (0) or a negative fa_status; the message of the last
+ *     failure on the calling thread is returned by fa_last_error().
+ *   - inputs are borrowed; outputs are written in place; k_cache / v_cache are mutated
+ *     in place by fa_fwd_kvcache (reference: kernel/fused_mha_forward_kvcache.cu:134-141).
+ *   - launches are asynchronous on `stream`; no host synchronisation inside.
+ *   - Tensor layouts are described by strides, so the (B,S,H,D) tensors of the Python API
+ *     are passed as they are (the reference permutes + copies to (B,H,S,D) first,
+ *     flash_attn_v100/flash_attn_interface.py:36-53).
+ */
+#ifndef FA_MI355_H
+#define FA_MI355_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FA_ABI_VERSION 1
+
+typedef enum fa_dtype {
+    FA_FP16 = 0,      /* IEEE half */
+    FA_BF16 = 1,      /* bfloat16 */
+    FA_FP8_E4M3 = 2   /* OCP e4m3fn, KV cache only */
+} fa_dtype;
+
+typedef enum fa_status {
+    FA_OK = 0,
+    FA_ERR_INVALID_ARGUMENT = -1,   /* a TORCH_CHECK of the reference would have fired */
+    FA_ERR_UNSUPPORTED = -2,        /* valid request this build has no kernel for */
+    FA_ERR_LAUNCH = -3,             /* HIP runtime reported an error */
+    FA_ERR_NO_DEVICE = -4
+} fa_status;
+
+/*
+ * One parameter block serves all five ops; each op reads the fields that apply to it
+ * and ignores the rest (zero-initialise the struct).  Index conventions:
+ *   element (b, i, h, d) of q  =  q[b*q_batch_stride + i*q_row_stride + h*q_head_stride + d]
+ *   (last dimension contiguous).  Varlen: b*batch_stride is replaced by cu_seqlens[b]*row_stride.
+ *   Paged K/V: logical key j of batch b lives in page block_table[b*block_table_batch_stride
+ *   + j / page_block_size], row j % page_block_size; k_batch_stride is then the PAGE stride.
+ */
+typedef struct fa_params {
+    /* ---- forward tensors ---- */
+    const void* q;            /* [B, Sq, Hq, D]  (varlen: [Tq, Hq, D]) */
+    const void* k;            /* [B, Sk, Hk, D]  (varlen: [Tk, Hk, D]; paged: [nblk, page, Hk, D]) */
+    const void* v;
+    void*       o;            /* same shape as q */
+    float*      lse;          /* dense/kvcache [B, Hq, Sq]; varlen [Hq, Tq]  (natural log) */
+    int64_t q_batch_stride, q_row_stride, q_head_stride;
+    int64_t k_batch_stride, k_row_stride, k_head_stride;
+    int64_t v_batch_stride, v_row_stride, v_head_stride;
+    int64_t o_batch_stride, o_row_stride, o_head_stride;
+    int64_t lse_batch_stride, lse_head_stride;   /* row stride is 1 */
+
+    /* ---- backward tensors (fa_bwd / fa_varlen_bwd) ---- */
+    const void* dout;         /* same layout family as o, own strides */
+    void*       dq;
+    void*       dk;
+    void*       dv;
+    float*      softmax_d;    /* rowsum(dO * O), same layout as lse; REQUIRED (written) */
+    int64_t do_batch_stride, do_row_stride, do_head_stride;
+    int64_t dq_batch_stride, dq_row_stride, dq_head_stride;
+    int64_t dk_batch_stride, dk_row_stride, dk_head_stride;
+    int64_t dv_batch_stride, dv_row_stride, dv_head_stride;
+
+    /* ---- sizes ---- */
+    int32_t batch;
+    int32_t nheads_q;
+    int32_t nheads_k;
+    int32_t seqlen_q;         /* dense: Sq; varlen: max_seqlen_q; kvcache: Tq */
+    int32_t seqlen_k;         /* dense: Sk; varlen: max_seqlen_k; kvcache: cache capacity
+                                 (S_max, or pages_per_seq * page_block_size when paged) */
+    int32_t head_dim;         /* 32, 64, 128 or 256 (multiple of 8 <= 256 is padded by the host layer) */
+    int32_t dtype;            /* fa_dtype of q/o/dout/dq/dk/dv */
+    int32_t kv_dtype;         /* fa_dtype of k/v (== dtype, or FA_FP8_E4M3 for fa_fwd_kvcache) */
+
+    /* ---- attention options ---- */
+    float   softmax_scale;
+    float   softcap;          /* 0 = off.  s = softcap * tanh(s / softcap), applied AFTER ALiBi
+                                 (reference order, include/mat_mul.h:113-116) */
+    int32_t is_causal;        /* bottom-right aligned: key j visible iff j - (Sk - Sq) <= i */
+    int32_t window_left;      /* -1 = unbounded */
+    int32_t window_right;     /* -1 = unbounded */
+    const float* alibi_slopes;      /* fp32 [Hq] or [B, Hq]; NULL = off */
+    int64_t alibi_batch_stride;     /* 0 for [Hq] */
+
+    /* ---- dropout (Philox-4x32-10, reference stream: include/softmax.h:97-104) ---- */
+    float    p_dropout;       /* probability of dropping */
+    uint64_t philox_seed;
+    uint64_t philox_offset;
+    void*    dmask;           /* optional [B,Hq,Sq,Sk] (varlen: [Tq,Hq,max_sk]) of `dtype`:
+                                 +1 kept / -1 dropped; NULL = not requested */
+
+    /* ---- varlen ---- */
+    const int32_t* cu_seqlens_q;    /* [B+1] */
+    const int32_t* cu_seqlens_k;    /* [B+1] */
+    const int32_t* seqused_k;       /* [B] or NULL */
+    int32_t        total_q;         /* Tq (varlen) */
+    int32_t        total_k;         /* Tk (varlen, non-paged) */
+
+    /* ---- paged KV ---- */
+    const int32_t* block_table;     /* [B, max_blocks] or NULL */
+    int64_t        block_table_batch_stride;
+    int32_t        page_block_size;
+    int32_t        _pad0;
+
+    /* ---- KV cache (fa_fwd_kvcache) ---- */
+    const int32_t* cache_seqlens;   /* [B] or NULL (=0) */
+    const int32_t* cache_batch_idx; /* [B] or NULL */
+    const int32_t* cache_leftpad;   /* [B] or NULL */
+    const void*    k_new;           /* [B, T_new, Hk, D] of `dtype`, or NULL */
+    const void*    v_new;
+    int64_t knew_batch_stride, knew_row_stride, knew_head_stride;
+    int64_t vnew_batch_stride, vnew_row_stride, vnew_head_stride;
+    int32_t        seqlen_new;      /* T_new */
+    int32_t        rotary_dim;      /* 0 = no rotary */
+    const void*    rotary_cos;      /* [seqlen_ro, rotary_dim/2] of `dtype` */
+    const void*    rotary_sin;
+    int32_t        rotary_interleaved;
+    int32_t        seqlen_ro;
+    float          k_descale;       /* fp8 cache: value = code * descale (1.0 otherwise) */
+    float          v_descale;
+
+    /* ---- split-KV (decode) ---- */
+    int32_t num_splits;             /* 0 = heuristic, 1 = no split */
+    int32_t _pad1;
+    void*   workspace;              /* >= fa_*_workspace_bytes(params) bytes, or NULL if 0 */
+    size_t  workspace_bytes;
+} fa_params;
+
+/* ABI self-description (checked by the Python ctypes mirror at load time). */
+int         fa_abi_version(void);
+size_t      fa_params_size(void);
+const char* fa_last_error(void);
+const char* fa_build_info(void);           /* arch, compiler, kernel variants */
+
+/* Workspace queries (bytes; 0 = none needed). */
+size_t fa_fwd_workspace_bytes(const fa_params* p);
+size_t fa_bwd_workspace_bytes(const fa_params* p);
+size_t fa_fwd_kvcache_workspace_bytes(const fa_params* p);
+
+/*
+ * fa_fwd - dense forward.  Replaces `flash_attn_v100_cuda.fwd`
+ *   reference: include/mha.h:27-41, kernel/fused_mha_forward.cu:301-432
+ *   writes o, lse (and dmask when requested and p_dropout > 0).
+ */
+int fa_fwd(const fa_params* p, void* stream);
+
+/*
+ * fa_bwd - dense backward.  Replaces `flash_attn_v100_cuda.bwd`
+ *   reference: include/mha.h:67-87, kernel/fused_mha_backward.cu:577-721
+ *   reads dout, q, k, v, o, lse; writes dq, dk, dv, softmax_d.  Deterministic
+ *   (no atomics).  GQA: dk/dv are summed over the q-heads of each kv-head in-kernel.
+ */
+int fa_bwd(const fa_params* p, void* stream);
+
+/*
+ * fa_varlen_fwd - packed variable-length forward (optionally paged K/V).
+ *   Replaces `flash_attn_v100_cuda.varlen_fwd`
+ *   reference: include/mha.h:116-139, kernel/fused_mha_forward_varlen.cu:371-566
+ */
+int fa_varlen_fwd(const fa_params* p, void* stream);
+
+/*
+ * fa_varlen_bwd - packed variable-length backward.  Replaces `flash_attn_v100_cuda.varlen_bwd`
+ *   reference: include/mha.h:170-195, kernel/fused_mha_backward_varlen.cu:636-807
+ */
+int fa_varlen_bwd(const fa_params* p, void* stream);
+
+/*
+ * fa_fwd_kvcache - append new K/V (+RoPE) into the cache, then attention of q over the
+ *   cache (decode / chunked prefill).  Replaces `flash_attn_v100_cuda.fwd_kvcache`
+ *   reference: include/mha.h:224-245, kernel/fused_mha_forward_kvcache.cu:416-652
+ */
+int fa_fwd_kvcache(const fa_params* p, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FA_MI355_H */

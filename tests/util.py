@@ -1,0 +1,58 @@
+"""Shared helpers for the GPU parity tests (oracle = checker, never the product path)."""
+import numpy as np
+import torch
+
+DT = {"fp16": torch.float16, "bf16": torch.bfloat16}
+# normalised max error |got-ref|_max / |ref|_max and relative Frobenius error.  The io
+# rounding floor alone is 2^-11 (fp16) / 2^-8 (bf16) relative per element.
+TOL_MAXREL = {"fp16": 2e-3, "bf16": 1.6e-2}
+TOL_FRO = {"fp16": 1e-3, "bf16": 6e-3}
+
+
+def rand16(shape, dtype, seed, scale=1.0, device="cuda"):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    x = (torch.randn(shape, generator=g, dtype=torch.float32) * scale).to(DT[dtype])
+    return x.to(device)
+
+
+def f64(t):
+    return t.detach().to(torch.float64).cpu().numpy()
+
+
+def errs(got, ref):
+    got = np.asarray(got, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    assert np.isfinite(got).all(), "non-finite values in kernel output"
+    d = np.abs(got - ref)
+    scale = max(np.abs(ref).max(), 1e-30)
+    fro = np.sqrt((d ** 2).sum()) / max(np.sqrt((ref ** 2).sum()), 1e-30)
+    return d.max() / scale, fro, d.max()
+
+
+def assert_close(got, ref, dtype, name, mult=1.0):
+    mr, fro, mabs = errs(got, ref)
+    assert mr <= TOL_MAXREL[dtype] * mult and fro <= TOL_FRO[dtype] * mult, \
+        f"{name}: max-rel {mr:.3e} (tol {TOL_MAXREL[dtype]*mult:.1e}) fro {fro:.3e} (tol {TOL_FRO[dtype]*mult:.1e}) max-abs {mabs:.3e}"
+    return mr, fro
+
+
+def assert_lse_close(got, ref, name, atol=2e-3):
+    got = np.asarray(got, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    inf_ref = np.isneginf(ref)
+    assert (np.isneginf(got) == inf_ref).all(), f"{name}: -inf pattern differs"
+    d = np.abs(got[~inf_ref] - ref[~inf_ref])
+    if d.size:
+        assert d.max() <= atol, f"{name}: LSE max abs diff {d.max():.3e}"
+    return d.max() if d.size else 0.0
+
+
+def lowp_attention_bhsd(q, k, v, scale, causal):
+    """The reference test's 16-bit PyTorch comparator (test.py:18-34 with upcast=False)."""
+    s = torch.einsum("bhmd,bhnd->bhmn", q, k) * scale
+    if causal:
+        m = torch.triu(torch.ones(s.shape[-2], s.shape[-1], device=s.device, dtype=torch.bool), 1)
+        s = s.masked_fill(m, float("-inf"))
+    p = torch.softmax(s, dim=-1)
+    return torch.einsum("bhmn,bhnd->bhmd", p, v)
