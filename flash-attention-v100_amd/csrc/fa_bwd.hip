@@ -1,6 +1,629 @@
-// placeholder until the backward kernels land
+// fa_bwd.hip - fused attention backward for gfx950 (dense + varlen).
+//
+// Replaces kernel/fused_mha_backward.cu:26-489 and kernel/fused_mha_backward_varlen.cu:26-540
+// of the reference.  Like the reference the backward is atomic-free and deterministic and
+// is split by the output it owns (reference: blockIdx.y == 0 -> dQ, == 1 -> dK/dV,
+// fused_mha_backward.cu:58,257); here those are three launches on one stream:
+//   1. bwd_preprocess   softmax_d[b,h,i] = sum_d O[i,d] dO[i,d]   (include/product.h:72-94;
+//                       computed ONCE, the reference recomputes it per Q tile in the dKV phase)
+//   2. bwd_dkdv         a workgroup owns 128 keys (32 per wave, K/V fragments in registers),
+//                       streams Q/dO tiles through LDS, accumulates dK^T, dV^T in registers
+//                       across the q-heads of its kv-head (GQA sum in-kernel, like
+//                       fused_mha_backward.cu:351)
+//   3. bwd_dq           a workgroup owns 128 query rows (Q/dO fragments in registers),
+//                       streams K/V tiles through LDS, accumulates dQ^T in registers.
+// Math (include/softmax.h:282-314):  P = exp(S - LSE), dP = dO V^T,
+//   dS = P o (dP - D) * scale  [softcap: * (1 - (S/c)^2)],  dV = P^T dO, dK = dS^T Q, dQ = dS K.
+// Every GEMM runs on v_mfma_f32_32x32x16; P and dS are rounded to the 16-bit io type before
+// their GEMMs (as the reference does) and the MFMA C-layout is reused as the next B operand.
+#include <cstdlib>
 #include "fa_common.h"
+
 namespace fa {
-size_t bwd_workspace_bytes(const fa_params&) { return 0; }
-int launch_bwd(const KArgs&, hipStream_t) { return -2; }
+
+constexpr int BWD_THREADS = 256;
+
+// ---------------------------------------------------------------------------------------------
+// 1. preprocess: D_i = rowsum(O o dO)
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) bwd_preprocess_kernel(const KArgs a) {
+    using E = Elem<T>;
+    const fa_params& p = a.p;
+    const int cpr = p.head_dim / 8;                     // lanes per row (8 or 16)
+    const int rows_per_block = 256 / cpr;
+    const int64_t total_rows = p.cu_seqlens_q ? (int64_t)p.total_q : (int64_t)p.batch * p.seqlen_q;
+    const int64_t row = (int64_t)blockIdx.x * rows_per_block + threadIdx.x / cpr;
+    const int h = blockIdx.y;
+    const int cc = threadIdx.x % cpr;
+    float acc = 0.f;
+    int64_t b = 0, i = row;
+    if (!p.cu_seqlens_q) { b = row / p.seqlen_q; i = row - b * p.seqlen_q; }
+    if (row < total_rows) {
+        const uint16_t* op = reinterpret_cast<const uint16_t*>(p.o) + b * p.o_batch_stride + i * p.o_row_stride +
+                             (int64_t)h * p.o_head_stride + cc * 8;
+        const uint16_t* dp = reinterpret_cast<const uint16_t*>(p.dout) + b * p.do_batch_stride + i * p.do_row_stride +
+                             (int64_t)h * p.do_head_stride + cc * 8;
+        const u32x4 ov = *reinterpret_cast<const u32x4*>(op);
+        const u32x4 dv = *reinterpret_cast<const u32x4*>(dp);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            acc = fmaf(E::lo(ov[j]), E::lo(dv[j]), acc);
+            acc = fmaf(E::hi(ov[j]), E::hi(dv[j]), acc);
+        }
+    }
+    for (int m = cpr >> 1; m > 0; m >>= 1) acc += __shfl_xor(acc, m, 64);
+    if (row < total_rows && cc == 0)
+        p.softmax_d[b * p.lse_batch_stride + (int64_t)h * p.lse_head_stride + i] = acc;
 }
+
+// ---------------------------------------------------------------------------------------------
+// shared geometry
+// ---------------------------------------------------------------------------------------------
+struct SeqGeom {
+    int seqlen_q, seqlen_k, off;
+    int64_t q_row0, k_row0;
+};
+__device__ __forceinline__ SeqGeom seq_geom(const fa_params& p, int b) {
+    SeqGeom s;
+    s.seqlen_q = p.seqlen_q; s.seqlen_k = p.seqlen_k; s.q_row0 = 0; s.k_row0 = 0;
+    if (p.cu_seqlens_q) { s.q_row0 = p.cu_seqlens_q[b]; s.seqlen_q = p.cu_seqlens_q[b + 1] - (int)s.q_row0; }
+    if (p.cu_seqlens_k) { s.k_row0 = p.cu_seqlens_k[b]; s.seqlen_k = p.cu_seqlens_k[b + 1] - (int)s.k_row0; }
+    s.off = s.seqlen_k - s.seqlen_q;
+    return s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// 2. dK / dV
+// ---------------------------------------------------------------------------------------------
+constexpr int DKV_BN = 128;     // keys per workgroup (32 per wave)
+constexpr int DKV_BQ = 64;      // query rows per LDS stage
+
+template <int D> struct DkvSmem {
+    static constexpr int TILE = DKV_BQ * D * 2;         // one Q (or dO) tile
+    static constexpr int STATS = DKV_BQ * 4 * 2;        // lse2 + D, fp32
+    static constexpr int STAGE = 2 * TILE + STATS;
+    static constexpr int TOTAL = 2 * STAGE;
+};
+
+template <typename T, int D, bool BIAS>
+__global__ void __launch_bounds__(BWD_THREADS, 1) fa_bwd_dkdv_kernel(const KArgs a) {
+    using E = Elem<T>;
+    constexpr int KSTEPS = D / 16;
+    constexpr int DBLKS = D / 32;
+    constexpr int CPR = D / 8;
+    constexpr int CHUNKS = DKV_BQ * CPR / BWD_THREADS;
+    constexpr int TILE = DkvSmem<D>::TILE;
+    constexpr int STAGE = DkvSmem<D>::STAGE;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const fa_params& p = a.p;
+    const int n_kblocks = (p.seqlen_k + DKV_BN - 1) / DKV_BN;
+    // unit = (b, hk); key blocks ascending == heavy first for causal
+    int b, hk, nb;
+    {
+        const int id = blockIdx.x, xcd = id & 7, j = id >> 3;
+        const int ul = j / n_kblocks;
+        nb = j - ul * n_kblocks;
+        const int unit = ul * 8 + xcd;
+        if (unit >= p.batch * p.nheads_k) return;
+        b = unit / p.nheads_k; hk = unit - b * p.nheads_k;
+    }
+    const SeqGeom sg = seq_geom(p, b);
+    const int n0 = nb * DKV_BN;
+    if (n0 >= sg.seqlen_k) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, g = lane >> 5;
+    const int group = p.nheads_q / p.nheads_k;
+    const int off = sg.off;
+    const int wl = p.window_left;
+    const int wr = p.is_causal ? 0 : p.window_right;
+
+    const int kw0 = n0 + wave * 32;
+    const int my_key = kw0 + l31;
+    // visible queries of my key: qlo <= i <= qhi      (j <= i + off + wr ; j >= i + off - wl)
+    int qlo = 0, qhi = sg.seqlen_q - 1;
+    if (wr >= 0) { const int t = my_key - off - wr; qlo = t > qlo ? t : qlo; }
+    if (wl >= 0) { const int t = my_key - off + wl; qhi = t < qhi ? t : qhi; }
+    if (my_key >= sg.seqlen_k) { qlo = 0x7fffffff; qhi = -1; }
+    // wave-uniform query bounds for skipping / mask elision
+    const int kw_last = (kw0 + 31 < sg.seqlen_k ? kw0 + 31 : sg.seqlen_k - 1);
+    int w_qlo_min = 0, w_qlo_max = 0, w_qhi_min = sg.seqlen_q - 1, w_qhi_max = sg.seqlen_q - 1;
+    if (wr >= 0) {
+        const int t0 = kw0 - off - wr, t1 = kw_last - off - wr;
+        w_qlo_min = t0 > 0 ? t0 : 0; w_qlo_max = t1 > 0 ? t1 : 0;
+    }
+    if (wl >= 0) {
+        const int t0 = kw0 - off + wl, t1 = kw_last - off + wl;
+        w_qhi_min = t0 < w_qhi_min ? t0 : w_qhi_min; w_qhi_max = t1 < w_qhi_max ? t1 : w_qhi_max;
+    }
+    const bool wave_has_keys = kw0 < sg.seqlen_k;
+    const bool key_tail = kw0 + 31 >= sg.seqlen_k;       // some lanes of this wave hold no key
+
+    // query-tile range of the whole 128-key block
+    int m_lo = 0, m_hi = sg.seqlen_q;                    // [m_lo, m_hi)
+    {
+        const int n_last = (n0 + DKV_BN < sg.seqlen_k ? n0 + DKV_BN : sg.seqlen_k) - 1;
+        if (wr >= 0) { const int t = n0 - off - wr; m_lo = t > 0 ? t : 0; }
+        if (wl >= 0) { const int t = n_last - off + wl + 1; m_hi = t < m_hi ? t : m_hi; }
+    }
+    const int mt0 = m_lo / DKV_BQ;
+    const int mt1 = m_hi > m_lo ? (m_hi + DKV_BQ - 1) / DKV_BQ : mt0;
+    const int n_tiles = mt1 - mt0;
+    const int n_iter = n_tiles * group;
+
+    // ---- K, V fragments of my 32 keys: B operands, lane holds X[my_key][16ks + 8g .. +7] ----
+    u32x4 kf[KSTEPS], vf[KSTEPS];
+    {
+        const int64_t kb_off = p.cu_seqlens_k ? 0 : (int64_t)b * p.k_batch_stride;
+        const int64_t vb_off = p.cu_seqlens_k ? 0 : (int64_t)b * p.v_batch_stride;
+        const uint16_t* kr = reinterpret_cast<const uint16_t*>(p.k) + kb_off + (sg.k_row0 + my_key) * p.k_row_stride +
+                             (int64_t)hk * p.k_head_stride + 8 * g;
+        const uint16_t* vr = reinterpret_cast<const uint16_t*>(p.v) + vb_off + (sg.k_row0 + my_key) * p.v_row_stride +
+                             (int64_t)hk * p.v_head_stride + 8 * g;
+        const bool ok = my_key < sg.seqlen_k;
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            u32x4 z = {0, 0, 0, 0};
+            kf[ks] = ok ? *reinterpret_cast<const u32x4*>(kr + 16 * ks) : z;
+            vf[ks] = ok ? *reinterpret_cast<const u32x4*>(vr + 16 * ks) : z;
+        }
+    }
+
+    // ---- staging of Q / dO / lse / D tiles ----
+    const int64_t qb_off = p.cu_seqlens_q ? 0 : (int64_t)b * p.q_batch_stride;
+    const int64_t dob_off = p.cu_seqlens_q ? 0 : (int64_t)b * p.do_batch_stride;
+    const uint16_t* q_base = reinterpret_cast<const uint16_t*>(p.q) + qb_off + sg.q_row0 * p.q_row_stride;
+    const uint16_t* do_base = reinterpret_cast<const uint16_t*>(p.dout) + dob_off + sg.q_row0 * p.do_row_stride;
+    const float* lse_base = p.lse + (int64_t)b * p.lse_batch_stride + sg.q_row0;
+    const float* dsum_base = p.softmax_d + (int64_t)b * p.lse_batch_stride + sg.q_row0;
+
+    u32x4 qreg[CHUNKS], doreg[CHUNKS];
+    float statreg = 0.f;
+    auto load_tile = [&](int it) {
+        const int gq = it / n_tiles;
+        const int m0 = (mt0 + it - gq * n_tiles) * DKV_BQ;
+        const int h = hk * group + gq;
+#pragma unroll
+        for (int i = 0; i < CHUNKS; ++i) {
+            const int c = tid + i * BWD_THREADS;
+            const int row = c / CPR, cc = c % CPR;
+            const int qi = m0 + row;
+            u32x4 z = {0, 0, 0, 0};
+            qreg[i] = z; doreg[i] = z;
+            if (qi < sg.seqlen_q) {
+                qreg[i] = *reinterpret_cast<const u32x4*>(q_base + (int64_t)qi * p.q_row_stride + (int64_t)h * p.q_head_stride + cc * 8);
+                doreg[i] = *reinterpret_cast<const u32x4*>(do_base + (int64_t)qi * p.do_row_stride + (int64_t)h * p.do_head_stride + cc * 8);
+            }
+        }
+        if (tid < 2 * DKV_BQ) {
+            const int r = tid & (DKV_BQ - 1);
+            const int qi = m0 + r;
+            statreg = 0.f;
+            if (qi < sg.seqlen_q) {
+                if (tid < DKV_BQ) statreg = lse_base[(int64_t)h * p.lse_head_stride + qi] * kLog2e;
+                else statreg = dsum_base[(int64_t)h * p.lse_head_stride + qi];
+            }
+        }
+    };
+    auto store_tile = [&](int stage) {
+        char* qs = smem + stage * STAGE;
+        char* dos = qs + TILE;
+        float* st = reinterpret_cast<float*>(dos + TILE);
+#pragma unroll
+        for (int i = 0; i < CHUNKS; ++i) {
+            const int c = tid + i * BWD_THREADS;
+            const int row = c / CPR, cc = c % CPR;
+            lds_write_b128(qs + swzt_row_off<D>(row, cc * 16), qreg[i]);
+            lds_write_b128(dos + swzt_row_off<D>(row, cc * 16), doreg[i]);
+        }
+        if (tid < 2 * DKV_BQ) st[tid] = statreg;          // [0,64): lse2, [64,128): D
+    };
+
+    f32x16 dk_acc[DBLKS], dv_acc[DBLKS];
+#pragma unroll
+    for (int d = 0; d < DBLKS; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dk_acc[d][r] = 0.f; dv_acc[d][r] = 0.f; }
+
+    float slope = 0.f;
+
+    if (n_iter > 0) { load_tile(0); store_tile(0); }
+    __syncthreads();
+
+    for (int it = 0; it < n_iter; ++it) {
+        const int stage = it & 1;
+        const bool has_next = it + 1 < n_iter;
+        if (has_next) load_tile(it + 1);
+        const int gq = it / n_tiles;
+        const int m0 = (mt0 + it - gq * n_tiles) * DKV_BQ;
+        if (BIAS && p.alibi_slopes) slope = p.alibi_slopes[b * p.alibi_batch_stride + hk * group + gq];
+
+        const char* qs = smem + stage * STAGE;
+        const char* dos = qs + TILE;
+        const float* st = reinterpret_cast<const float*>(dos + TILE);
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const int q0 = m0 + sub * 32;
+            // any visible (query, key) pair for this wave in rows [q0, q0+31]?
+            const bool active = wave_has_keys && (q0 <= w_qhi_max) && (q0 + 31 >= w_qlo_min);
+            if (!active) continue;
+            // ---- S = Q K^T, dP = dO V^T : acc[r] = X[q0 + row(r,g)][my_key] ----
+            f32x16 s_acc, dp_acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s_acc[r] = 0.f; dp_acc[r] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < KSTEPS; ++ks) {
+                const u32x4 qa = lds_read_b128(qs + swzt_row_off<D>(sub * 32 + l31, 32 * ks + 16 * g));
+                s_acc = E::mfma(qa, kf[ks], s_acc);
+            }
+#pragma unroll
+            for (int ks = 0; ks < KSTEPS; ++ks) {
+                const u32x4 da = lds_read_b128(dos + swzt_row_off<D>(sub * 32 + l31, 32 * ks + 16 * g));
+                dp_acc = E::mfma(da, vf[ks], dp_acc);
+            }
+            // row statistics for q = q0 + 8 i + 4 g + (0..3)
+            f32x4 lse2[4], dsum[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                lse2[i] = *reinterpret_cast<const f32x4*>(st + sub * 32 + 8 * i + 4 * g);
+                dsum[i] = *reinterpret_cast<const f32x4*>(st + DKV_BQ + sub * 32 + 8 * i + 4 * g);
+            }
+            const bool need_mask = key_tail || (q0 < w_qlo_max) || (q0 + 31 > w_qhi_min);
+            float pv[16], dsv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int qi = q0 + (r & 3) + 8 * (r >> 2) + 4 * g;
+                const float l2 = lse2[r >> 2][r & 3];
+                float pr, dsr;
+                if (BIAS) {
+                    float s = s_acc[r] * p.softmax_scale;
+                    s = fmaf(-slope, fabsf((float)(qi + off - my_key)), s);
+                    float chain = 1.f;
+                    if (p.softcap > 0.f) {
+                        const float t = fast_tanh(s / p.softcap);
+                        s = p.softcap * t;
+                        chain = 1.f - t * t;
+                    }
+                    pr = fast_exp2(fmaf(s, kLog2e, -l2));
+                    dsr = pr * (dp_acc[r] - dsum[r >> 2][r & 3]) * chain;
+                } else {
+                    pr = fast_exp2(fmaf(s_acc[r], a.scale_log2e, -l2));
+                    dsr = pr * (dp_acc[r] - dsum[r >> 2][r & 3]);
+                }
+                if (need_mask && (qi < qlo || qi > qhi)) { pr = 0.f; dsr = 0.f; }
+                pv[r] = pr; dsv[r] = dsr;
+            }
+            // ---- dV^T += dO^T P,  dK^T += Q^T dS : k-step t covers regs 8t .. 8t+7 ----
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                u32x4 pf, dsf;
+#pragma unroll
+                for (int w2 = 0; w2 < 4; ++w2) {
+                    pf[w2] = E::pack2(pv[8 * t + 2 * w2], pv[8 * t + 2 * w2 + 1]);
+                    dsf[w2] = E::pack2(dsv[8 * t + 2 * w2], dsv[8 * t + 2 * w2 + 1]);
+                }
+                // rows sub*32 + 16 t + 8 hf + 4 g + rr ; cols 32 d + 16 ((lane>>4)&1) + 4 (lane&3)
+                const int rr = (lane & 15) >> 2;
+                const int cb = (((lane >> 4) & 1) << 5) + ((lane & 3) << 3);
+                const int row_a = sub * 32 + 16 * t + 4 * g + rr;
+#pragma unroll
+                for (int d = 0; d < DBLKS; ++d) {
+                    const u32x2 a0 = lds_read_tr16(dos + swzt_row_off<D>(row_a, d * 64 + cb));
+                    const u32x2 a1 = lds_read_tr16(dos + swzt_row_off<D>(row_a + 8, d * 64 + cb));
+                    u32x4 af = {a0[0], a0[1], a1[0], a1[1]};
+                    dv_acc[d] = E::mfma(af, pf, dv_acc[d]);
+                    const u32x2 b0 = lds_read_tr16(qs + swzt_row_off<D>(row_a, d * 64 + cb));
+                    const u32x2 b1 = lds_read_tr16(qs + swzt_row_off<D>(row_a + 8, d * 64 + cb));
+                    u32x4 bfr = {b0[0], b0[1], b1[0], b1[1]};
+                    dk_acc[d] = E::mfma(bfr, dsf, dk_acc[d]);
+                }
+            }
+        }
+        if (has_next) store_tile(stage ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane (key = l31, g) holds dX[my_key][32 d + 8 rq + 4 g + (0..3)] ----
+    if (my_key < sg.seqlen_k) {
+        const int64_t dkb = p.cu_seqlens_k ? 0 : (int64_t)b * p.dk_batch_stride;
+        const int64_t dvb = p.cu_seqlens_k ? 0 : (int64_t)b * p.dv_batch_stride;
+        uint16_t* dkp = reinterpret_cast<uint16_t*>(p.dk) + dkb + (sg.k_row0 + my_key) * p.dk_row_stride + (int64_t)hk * p.dk_head_stride;
+        uint16_t* dvp = reinterpret_cast<uint16_t*>(p.dv) + dvb + (sg.k_row0 + my_key) * p.dv_row_stride + (int64_t)hk * p.dv_head_stride;
+        const float sc = p.softmax_scale;
+#pragma unroll
+        for (int d = 0; d < DBLKS; ++d)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                u32x2 k2, v2;
+                k2[0] = E::pack2(dk_acc[d][4 * rq + 0] * sc, dk_acc[d][4 * rq + 1] * sc);
+                k2[1] = E::pack2(dk_acc[d][4 * rq + 2] * sc, dk_acc[d][4 * rq + 3] * sc);
+                v2[0] = E::pack2(dv_acc[d][4 * rq + 0], dv_acc[d][4 * rq + 1]);
+                v2[1] = E::pack2(dv_acc[d][4 * rq + 2], dv_acc[d][4 * rq + 3]);
+                *reinterpret_cast<u32x2*>(dkp + d * 32 + 8 * rq + 4 * g) = k2;
+                *reinterpret_cast<u32x2*>(dvp + d * 32 + 8 * rq + 4 * g) = v2;
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// 3. dQ
+// ---------------------------------------------------------------------------------------------
+constexpr int DQ_BM = 128;
+constexpr int DQ_BN = 64;
+
+template <int D> struct DqSmem {
+    static constexpr int TILE = DQ_BN * D * 2;
+    static constexpr int STAGE = 2 * TILE;
+    static constexpr int TOTAL = 2 * STAGE;
+};
+
+template <typename T, int D, bool BIAS, int OCC>
+__global__ void __launch_bounds__(BWD_THREADS, OCC) fa_bwd_dq_kernel(const KArgs a) {
+    using E = Elem<T>;
+    constexpr int KSTEPS = D / 16;
+    constexpr int DBLKS = D / 32;
+    constexpr int CPR = D / 8;
+    constexpr int CHUNKS = DQ_BN * CPR / BWD_THREADS;
+    constexpr int TILE = DqSmem<D>::TILE;
+    constexpr int STAGE = DqSmem<D>::STAGE;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const fa_params& p = a.p;
+    const WorkItem w = decode_work(blockIdx.x, p.batch, p.nheads_q, p.nheads_k, a.n_qblocks);
+    if (!w.valid) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, g = lane >> 5;
+    const SeqGeom sg = seq_geom(p, w.b);
+    const int m_block = w.qb * DQ_BM;
+    if (m_block >= sg.seqlen_q) return;
+    const int off = sg.off;
+    const int wl = p.window_left;
+    const int wr = p.is_causal ? 0 : p.window_right;
+    int n_min = 0, n_max = (sg.seqlen_k + DQ_BN - 1) / DQ_BN;
+    {
+        const int m_last = (m_block + DQ_BM < sg.seqlen_q ? m_block + DQ_BM : sg.seqlen_q) - 1;
+        if (wr >= 0) {
+            const int kmax = m_last + off + wr;
+            const int t = kmax < 0 ? 0 : kmax / DQ_BN + 1;
+            n_max = t < n_max ? t : n_max;
+        }
+        if (wl >= 0) { const int kmin = m_block + off - wl; if (kmin > 0) n_min = kmin / DQ_BN; }
+    }
+    const int wave_row0 = m_block + wave * 32;
+    const int my_row = wave_row0 + l31;
+    int lo = 0, hi = sg.seqlen_k - 1;
+    if (wr >= 0) { const int h2 = my_row + off + wr; hi = h2 < hi ? h2 : hi; }
+    if (wl >= 0) { const int l2 = my_row + off - wl; lo = l2 > lo ? l2 : lo; }
+    if (my_row >= sg.seqlen_q) { lo = 0x7fffffff; hi = -1; }
+    const int wrow_last = wave_row0 + 31;
+    int w_hi_min = sg.seqlen_k - 1, w_hi_max = sg.seqlen_k - 1, w_lo_max = 0;
+    if (wr >= 0) {
+        const int h0 = wave_row0 + off + wr, h1 = wrow_last + off + wr;
+        w_hi_min = h0 < w_hi_min ? h0 : w_hi_min; w_hi_max = h1 < w_hi_max ? h1 : w_hi_max;
+    }
+    if (wl >= 0) { const int l1 = wrow_last + off - wl; w_lo_max = l1 > 0 ? l1 : 0; }
+    const int w_lo_min = (wl >= 0 && wave_row0 + off - wl > 0) ? wave_row0 + off - wl : 0;
+    const bool row_tail = wrow_last >= sg.seqlen_q;
+
+    // ---- Q, dO fragments (B operands) + row statistics ----
+    u32x4 qf[KSTEPS], dof[KSTEPS];
+    float lse2 = 0.f, dsum = 0.f;
+    {
+        const bool ok = my_row < sg.seqlen_q;
+        const int64_t qb_off = p.cu_seqlens_q ? 0 : (int64_t)w.b * p.q_batch_stride;
+        const int64_t dob_off = p.cu_seqlens_q ? 0 : (int64_t)w.b * p.do_batch_stride;
+        const uint16_t* qrow = reinterpret_cast<const uint16_t*>(p.q) + qb_off + (sg.q_row0 + my_row) * p.q_row_stride +
+                               (int64_t)w.h * p.q_head_stride + 8 * g;
+        const uint16_t* dorow = reinterpret_cast<const uint16_t*>(p.dout) + dob_off + (sg.q_row0 + my_row) * p.do_row_stride +
+                                (int64_t)w.h * p.do_head_stride + 8 * g;
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            u32x4 z = {0, 0, 0, 0};
+            qf[ks] = ok ? *reinterpret_cast<const u32x4*>(qrow + 16 * ks) : z;
+            dof[ks] = ok ? *reinterpret_cast<const u32x4*>(dorow + 16 * ks) : z;
+        }
+        if (ok) {
+            const int64_t so = (int64_t)w.b * p.lse_batch_stride + (int64_t)w.h * p.lse_head_stride + sg.q_row0 + my_row;
+            lse2 = p.lse[so] * kLog2e;
+            dsum = p.softmax_d[so];
+        }
+    }
+    float slope = 0.f;
+    if (BIAS && p.alibi_slopes) slope = p.alibi_slopes[w.b * p.alibi_batch_stride + w.h];
+
+    const int64_t kb_off = p.cu_seqlens_k ? 0 : (int64_t)w.b * p.k_batch_stride;
+    const int64_t vb_off = p.cu_seqlens_k ? 0 : (int64_t)w.b * p.v_batch_stride;
+    const uint16_t* kp = reinterpret_cast<const uint16_t*>(p.k) + kb_off + sg.k_row0 * p.k_row_stride + (int64_t)w.hk * p.k_head_stride;
+    const uint16_t* vp = reinterpret_cast<const uint16_t*>(p.v) + vb_off + sg.k_row0 * p.v_row_stride + (int64_t)w.hk * p.v_head_stride;
+
+    u32x4 kreg[CHUNKS], vreg[CHUNKS];
+    auto load_tile = [&](int nb) {
+        const int n0 = nb * DQ_BN;
+#pragma unroll
+        for (int i = 0; i < CHUNKS; ++i) {
+            const int c = tid + i * BWD_THREADS;
+            const int row = c / CPR, cc = c % CPR;
+            const int j = n0 + row;
+            u32x4 z = {0, 0, 0, 0};
+            kreg[i] = z; vreg[i] = z;
+            if (j < sg.seqlen_k) {
+                kreg[i] = *reinterpret_cast<const u32x4*>(kp + (int64_t)j * p.k_row_stride + cc * 8);
+                vreg[i] = *reinterpret_cast<const u32x4*>(vp + (int64_t)j * p.v_row_stride + cc * 8);
+            }
+        }
+    };
+    auto store_tile = [&](int stage) {
+        char* ks = smem + stage * STAGE;
+        char* vs = ks + TILE;
+#pragma unroll
+        for (int i = 0; i < CHUNKS; ++i) {
+            const int c = tid + i * BWD_THREADS;
+            const int row = c / CPR, cc = c % CPR;
+            lds_write_b128(ks + swzt_row_off<D>(row, cc * 16), kreg[i]);
+            lds_write_b128(vs + swz_row_off<D>(row, cc * 16), vreg[i]);
+        }
+    };
+
+    f32x16 dq_acc[DBLKS];
+#pragma unroll
+    for (int d = 0; d < DBLKS; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dq_acc[d][r] = 0.f;
+
+    if (n_min < n_max) { load_tile(n_min); store_tile(0); }
+    __syncthreads();
+
+    for (int nb = n_min; nb < n_max; ++nb) {
+        const int stage = (nb - n_min) & 1;
+        const bool has_next = nb + 1 < n_max;
+        if (has_next) load_tile(nb + 1);
+        const int n0 = nb * DQ_BN;
+        const bool wave_active = (n0 <= w_hi_max) && (n0 + DQ_BN - 1 >= w_lo_min) && (wave_row0 < sg.seqlen_q);
+        if (wave_active) {
+            const char* ks_base = smem + stage * STAGE;
+            const char* vs_base = ks_base + TILE;
+            const bool need_mask = row_tail || (n0 + DQ_BN - 1 > w_hi_min) || (n0 < w_lo_max);
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                // S^T, dP^T : acc[r] = X[my_row][n0 + 32 kb + row(r,g)]
+                f32x16 s_acc, dp_acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { s_acc[r] = 0.f; dp_acc[r] = 0.f; }
+#pragma unroll
+                for (int ks = 0; ks < KSTEPS; ++ks) {
+                    const u32x4 ka = lds_read_b128(ks_base + swzt_row_off<D>(kb * 32 + l31, 32 * ks + 16 * g));
+                    s_acc = E::mfma(ka, qf[ks], s_acc);
+                }
+#pragma unroll
+                for (int ks = 0; ks < KSTEPS; ++ks) {
+                    const u32x4 va = lds_read_b128(vs_base + swz_row_off<D>(kb * 32 + l31, 32 * ks + 16 * g));
+                    dp_acc = E::mfma(va, dof[ks], dp_acc);
+                }
+                float dsv[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int j = n0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+                    float pr, dsr;
+                    if (BIAS) {
+                        float s = s_acc[r] * p.softmax_scale;
+                        s = fmaf(-slope, fabsf((float)(my_row + off - j)), s);
+                        float chain = 1.f;
+                        if (p.softcap > 0.f) {
+                            const float t = fast_tanh(s / p.softcap);
+                            s = p.softcap * t;
+                            chain = 1.f - t * t;
+                        }
+                        pr = fast_exp2(fmaf(s, kLog2e, -lse2));
+                        dsr = pr * (dp_acc[r] - dsum) * chain;
+                    } else {
+                        pr = fast_exp2(fmaf(s_acc[r], a.scale_log2e, -lse2));
+                        dsr = pr * (dp_acc[r] - dsum);
+                    }
+                    if (need_mask && (j < lo || j > hi)) dsr = 0.f;
+                    dsv[r] = dsr;
+                }
+                // dQ^T += K^T dS^T
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    u32x4 dsf;
+#pragma unroll
+                    for (int w2 = 0; w2 < 4; ++w2) dsf[w2] = E::pack2(dsv[8 * t + 2 * w2], dsv[8 * t + 2 * w2 + 1]);
+                    const int rr = (lane & 15) >> 2;
+                    const int cb = (((lane >> 4) & 1) << 5) + ((lane & 3) << 3);
+                    const int row_a = kb * 32 + 16 * t + 4 * g + rr;
+#pragma unroll
+                    for (int d = 0; d < DBLKS; ++d) {
+                        const u32x2 a0 = lds_read_tr16(ks_base + swzt_row_off<D>(row_a, d * 64 + cb));
+                        const u32x2 a1 = lds_read_tr16(ks_base + swzt_row_off<D>(row_a + 8, d * 64 + cb));
+                        u32x4 af = {a0[0], a0[1], a1[0], a1[1]};
+                        dq_acc[d] = E::mfma(af, dsf, dq_acc[d]);
+                    }
+                }
+            }
+        }
+        if (has_next) store_tile(stage ^ 1);
+        __syncthreads();
+    }
+
+    if (my_row < sg.seqlen_q) {
+        const int64_t dqb = p.cu_seqlens_q ? 0 : (int64_t)w.b * p.dq_batch_stride;
+        uint16_t* dqp = reinterpret_cast<uint16_t*>(p.dq) + dqb + (sg.q_row0 + my_row) * p.dq_row_stride + (int64_t)w.h * p.dq_head_stride;
+        const float sc = p.softmax_scale;
+#pragma unroll
+        for (int d = 0; d < DBLKS; ++d)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                u32x2 o2;
+                o2[0] = E::pack2(dq_acc[d][4 * rq + 0] * sc, dq_acc[d][4 * rq + 1] * sc);
+                o2[1] = E::pack2(dq_acc[d][4 * rq + 2] * sc, dq_acc[d][4 * rq + 3] * sc);
+                *reinterpret_cast<u32x2*>(dqp + d * 32 + 8 * rq + 4 * g) = o2;
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host
+// ---------------------------------------------------------------------------------------------
+size_t bwd_workspace_bytes(const fa_params&) { return 0; }
+int g_bwd_phase_mask = 7;     // fa_debug_set_bwd_phases(): measurement aid
+
+template <typename T, int D>
+static int launch_bwd_td(const KArgs& a, hipStream_t stream) {
+    const fa_params& p = a.p;
+    // 1. preprocess
+    if (g_bwd_phase_mask & 1) {
+        const int cpr = D / 8, rows_per_block = 256 / cpr;
+        const int64_t total_rows = p.cu_seqlens_q ? (int64_t)p.total_q : (int64_t)p.batch * p.seqlen_q;
+        if (total_rows > 0) {
+            dim3 grid((unsigned)((total_rows + rows_per_block - 1) / rows_per_block), p.nheads_q);
+            hipLaunchKernelGGL(bwd_preprocess_kernel<T>, grid, dim3(256), 0, stream, a);
+        }
+    }
+    // 2. dK/dV
+    if (g_bwd_phase_mask & 2) {
+        const int n_kblocks = (p.seqlen_k + DKV_BN - 1) / DKV_BN;
+        const int units = p.batch * p.nheads_k;
+        const int grid = 8 * ((units + 7) / 8) * n_kblocks;
+        const size_t smem = DkvSmem<D>::TOTAL;
+        if (grid > 0) {
+            if (a.has_bias) {
+                auto kern = fa_bwd_dkdv_kernel<T, D, true>;
+                hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+                hipLaunchKernelGGL(kern, dim3(grid), dim3(BWD_THREADS), smem, stream, a);
+            } else {
+                auto kern = fa_bwd_dkdv_kernel<T, D, false>;
+                hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+                hipLaunchKernelGGL(kern, dim3(grid), dim3(BWD_THREADS), smem, stream, a);
+            }
+        }
+    }
+    // 3. dQ  (D = 128 needs > 256 registers at two waves per SIMD: development switch FA_DQ_OCC)
+    if (g_bwd_phase_mask & 4) {
+        const int grid = work_grid(p.batch, p.nheads_q, p.nheads_k, a.n_qblocks);
+        const size_t smem = DqSmem<D>::TOTAL;
+        static const int occ_env = getenv("FA_DQ_OCC") ? atoi(getenv("FA_DQ_OCC")) : 0;
+        const int occ = occ_env ? occ_env : (D >= 128 ? 1 : 2);
+#define FA_LAUNCH_DQ(BIAS, OCC)                                                                                   \
+        do {                                                                                                      \
+            auto kern = fa_bwd_dq_kernel<T, D, BIAS, OCC>;                                                        \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(BWD_THREADS), smem, stream, a);                             \
+        } while (0)
+        if (grid > 0) {
+            if (a.has_bias) { if (occ == 1) FA_LAUNCH_DQ(true, 1); else FA_LAUNCH_DQ(true, 2); }
+            else            { if (occ == 1) FA_LAUNCH_DQ(false, 1); else FA_LAUNCH_DQ(false, 2); }
+        }
+#undef FA_LAUNCH_DQ
+    }
+    return 0;
+}
+
+int launch_bwd(const KArgs& a, hipStream_t stream) {
+    const bool bf = a.p.dtype == FA_BF16;
+    switch (a.p.head_dim) {
+        case 64:  return bf ? launch_bwd_td<bf16_tag, 64>(a, stream) : launch_bwd_td<fp16_tag, 64>(a, stream);
+        case 128: return bf ? launch_bwd_td<bf16_tag, 128>(a, stream) : launch_bwd_td<fp16_tag, 128>(a, stream);
+        default:  return -2;
+    }
+}
+
+}  // namespace fa

@@ -93,6 +93,19 @@ __device__ __forceinline__ int swz_row_off(int row, int col_byte) {
     return row * ROWB + (col_byte ^ (f << 4));
 }
 
+// Row-major [rows][D] tile that is read BOTH by rows (ds_read_b128, A operand) and
+// transposed (ds_read_b64_tr_b16 on 4 consecutive rows x 64 bytes).  The slot XOR uses
+// row bits (1:0 -> slot bits 3:2) so that the 4 rows of a transpose read land in four
+// different 64-byte bank groups, and stays a bijection over 16 rows for the row reads.
+template <int D>
+__device__ __forceinline__ int swzt_row_off(int row, int col_byte) {
+    constexpr int ROWB = D * 2;
+    static_assert(D == 64 || D == 128, "swzt layout defined for D = 64, 128");
+    const int f = (D == 128) ? (((row & 3) << 2) | ((row >> 2) & 3))
+                             : ((((row >> 1) & 1) << 2) | ((row >> 2) & 3));
+    return row * ROWB + (col_byte ^ (f << 4));
+}
+
 // [rows][D] 16-bit tile stored as [rows/4][D/32] blocks of [4 rows][32 cols] (256 B each):
 // a 32-lane ds_read_b64_tr_b16 then covers exactly one 256-byte bank line.
 template <int D>

@@ -1,0 +1,110 @@
+"""GPU parity: dense backward (autograd through the Python API -> fa_bwd) vs the oracle and
+the reference-generated golden gradients."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from util import assert_close, f64, rand16
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _fa():
+    import flash_attn
+    return flash_attn
+
+
+def _lowp_grads(q, k, v, do, scale, causal):
+    q, k, v = (t.detach().clone().requires_grad_(True) for t in (q, k, v))
+    s = torch.einsum("bhmd,bhnd->bhmn", q, k) * scale
+    if causal:
+        m = torch.triu(torch.ones(s.shape[-2], s.shape[-1], device=s.device, dtype=torch.bool), 1)
+        s = s.masked_fill(m, float("-inf"))
+    o = torch.einsum("bhmn,bhnd->bhmd", torch.softmax(s, -1), v)
+    return torch.autograd.grad(o, (q, k, v), do)
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "dense_*.npz"))))
+def test_golden_dense_bwd(path):
+    """Reference protocol (test.py:322-334): err <= 3 err_fp16torch + 1e-4 per gradient."""
+    g = np.load(path)
+    q, k, v, do = (torch.from_numpy(g[n]).cuda() for n in ("q", "k", "v", "do"))   # [B,H,S,D]
+    causal, scale = bool(g["causal"]), float(g["scale"])
+    qq, kk, vv = (t.transpose(1, 2).contiguous().requires_grad_(True) for t in (q, k, v))
+    out = _fa().flash_attn_func(qq, kk, vv, softmax_scale=scale, causal=causal)
+    dq, dk, dv = torch.autograd.grad(out, (qq, kk, vv), do.transpose(1, 2))
+    pt = _lowp_grads(q, k, v, do, scale, causal)
+    for name, got, lp in (("dq", dq, pt[0]), ("dk", dk, pt[1]), ("dv", dv, pt[2])):
+        ref = torch.from_numpy(g[name]).cuda()
+        got = got.transpose(1, 2).float()
+        assert torch.isfinite(got).all()
+        err = (got - ref).abs().max().item()
+        err_pt = (lp.float() - ref).abs().max().item()
+        assert err <= 3 * err_pt + 1e-4, (name, err, err_pt)
+
+
+CASES = [
+    # B, Hq, Hk, Sq, Sk, D, dtype, causal, window, softcap, alibi
+    (2, 4, 4, 128, 128, 128, "bf16", False, (-1, -1), 0.0, False),
+    (2, 4, 4, 128, 128, 128, "fp16", True, (-1, -1), 0.0, False),
+    (1, 4, 2, 200, 200, 128, "bf16", True, (-1, -1), 0.0, False),     # GQA, ragged
+    (1, 4, 1, 257, 300, 64, "fp16", True, (-1, -1), 0.0, False),      # MQA, Sq < Sk
+    (1, 2, 2, 300, 130, 64, "bf16", True, (-1, -1), 0.0, False),      # Sq > Sk: empty rows
+    (2, 2, 2, 33, 65, 128, "fp16", False, (-1, -1), 0.0, False),
+    (1, 4, 4, 384, 384, 128, "bf16", False, (100, 0), 0.0, False),    # sliding window
+    (1, 4, 4, 384, 384, 64, "fp16", False, (64, 32), 0.0, False),
+    (1, 4, 4, 256, 256, 128, "fp16", True, (-1, -1), 0.0, True),      # ALiBi
+    (2, 4, 2, 256, 256, 128, "bf16", False, (-1, -1), 30.0, False),   # softcap
+    (1, 4, 4, 192, 192, 64, "fp16", True, (-1, -1), 15.0, True),
+    (1, 2, 2, 512, 512, 128, "bf16", True, (-1, -1), 0.0, False),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "-".join(map(str, c)))
+def test_dense_bwd_vs_oracle(case):
+    B, Hq, Hk, Sq, Sk, D, dt, causal, window, softcap, alibi = case
+    q = rand16((B, Sq, Hq, D), dt, 421).requires_grad_(True)
+    k = rand16((B, Sk, Hk, D), dt, 422).requires_grad_(True)
+    v = rand16((B, Sk, Hk, D), dt, 423).requires_grad_(True)
+    do = rand16((B, Sq, Hq, D), dt, 424)
+    slopes = None
+    if alibi:
+        slopes = (2.0 ** (-8.0 * (torch.arange(Hq) + 1) / Hq)).float().cuda()
+    out = _fa().flash_attn_func(q, k, v, causal=causal, window_size=window, softcap=softcap,
+                                alibi_slopes=slopes)
+    dq, dk, dv = torch.autograd.grad(out, (q, k, v), do)
+    assert dq.shape == q.shape and dk.shape == k.shape and dv.shape == v.shape
+    t = lambda x: f64(x).transpose(0, 2, 1, 3)
+    kw = dict(causal=causal, window=window, softcap=softcap,
+              alibi_slopes=None if slopes is None else f64(slopes))
+    o_ref, lse_ref, _ = oracle.attn_fwd(t(q), t(k), t(v), D ** -0.5, **kw)
+    dq_r, dk_r, dv_r, _ = oracle.attn_bwd(t(do), t(q), t(k), t(v), o_ref, lse_ref.astype(np.float64),
+                                          D ** -0.5, **kw)
+    assert_close(t(dq), dq_r, dt, "dq", mult=2.0)
+    assert_close(t(dk), dk_r, dt, "dk", mult=2.0)
+    assert_close(t(dv), dv_r, dt, "dv", mult=2.0)
+
+
+def test_bwd_deterministic_and_linear():
+    """Size-independent properties at a large shape: bitwise repeatability (atomic-free) and
+    linearity of the gradients in dO."""
+    B, S, H, D = 2, 2048, 8, 128
+    q = rand16((B, S, H, D), "bf16", 1).requires_grad_(True)
+    k = rand16((B, S, H, D), "bf16", 2).requires_grad_(True)
+    v = rand16((B, S, H, D), "bf16", 3).requires_grad_(True)
+    do = rand16((B, S, H, D), "bf16", 4)
+    out = _fa().flash_attn_func(q, k, v, causal=True)
+    g1 = torch.autograd.grad(out, (q, k, v), do, retain_graph=True)
+    g2 = torch.autograd.grad(out, (q, k, v), do, retain_graph=True)
+    for a_, b_ in zip(g1, g2):
+        assert torch.equal(a_, b_)
+    g3 = torch.autograd.grad(out, (q, k, v), do * 2)
+    for a_, b_ in zip(g1, g3):
+        assert torch.isfinite(a_).all()
+        rel = ((b_.float() - 2 * a_.float()).abs().max() / (2 * a_.float()).abs().max()).item()
+        assert rel < 2e-2, rel
