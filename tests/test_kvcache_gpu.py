@@ -1,0 +1,106 @@
+"""GPU parity: flash_attn_with_kvcache (append + RoPE + paged + cache_batch_idx + leftpad)."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from util import DT, assert_close, assert_lse_close, f64, rand16
+
+pytestmark = pytest.mark.gpu
+
+
+def _fa():
+    import flash_attn
+    return flash_attn
+
+
+def _rotary(seqlen_ro, rd, dt):
+    pos = torch.arange(seqlen_ro, dtype=torch.float32)[:, None]
+    inv = 1.0 / (10000 ** (torch.arange(0, rd, 2, dtype=torch.float32) / rd))[None, :]
+    ang = pos * inv
+    return torch.cos(ang).to(DT[dt]).cuda(), torch.sin(ang).to(DT[dt]).cuda()
+
+
+KCASES = [
+    # B, Tq, Hq, Hk, D, Smax, T_new, dtype, causal, window, rotary_dim, interleaved, batch_idx, leftpad, alibi
+    (3, 1, 8, 2, 128, 512, 1, "fp16", False, (-1, -1), 0, True, False, False, False),      # plain decode GQA
+    (3, 1, 8, 2, 128, 512, 1, "bf16", True, (-1, -1), 128, False, False, False, False),    # NeoX rope
+    (2, 1, 4, 4, 64, 300, 1, "fp16", True, (-1, -1), 32, True, True, False, False),        # GPT-J rope, partial
+    (2, 5, 4, 2, 128, 400, 5, "fp16", True, (-1, -1), 64, False, False, True, False),      # chunk prefill + leftpad
+    (2, 3, 4, 4, 64, 256, 3, "bf16", False, (100, -1), 64, True, False, False, False),     # window -> local rope
+    (2, 1, 4, 4, 128, 256, 0, "fp16", False, (-1, -1), 0, True, True, False, True),        # no append, alibi
+    (2, 130, 4, 2, 128, 512, 130, "bf16", True, (-1, -1), 128, True, False, False, False), # long chunk
+]
+
+
+@pytest.mark.parametrize("case", KCASES, ids=lambda c: "-".join(map(str, c)))
+def test_kvcache_vs_oracle(case):
+    B, Tq, Hq, Hk, D, Smax, Tn, dt, causal, window, rd, inter, use_bidx, use_lp, alibi = case
+    Bc = B + 2 if use_bidx else B
+    q = rand16((B, Tq, Hq, D), dt, 1)
+    kc = rand16((Bc, Smax, Hk, D), dt, 2)
+    vc = rand16((Bc, Smax, Hk, D), dt, 3)
+    knew = rand16((B, Tn, Hk, D), dt, 4) if Tn else None
+    vnew = rand16((B, Tn, Hk, D), dt, 5) if Tn else None
+    g = torch.Generator().manual_seed(9)
+    lp = torch.randint(0, 17, (B,), generator=g, dtype=torch.int32) if use_lp else None
+    seqlens = torch.randint(1, Smax - Tn - 20, (B,), generator=g, dtype=torch.int32)
+    bidx = torch.tensor([Bc - 1 - i for i in range(B)], dtype=torch.int32) if use_bidx else None
+    cos, sin = _rotary(Smax + 8, rd, dt) if rd else (None, None)
+    slopes = torch.tensor([0.1 * (i + 1) for i in range(Hq)], dtype=torch.float32, device="cuda") if alibi else None
+    kc_ref, vc_ref = f64(kc).copy(), f64(vc).copy()
+    out, lse = _fa().flash_attn_with_kvcache(
+        q, kc, vc, k=knew, v=vnew, rotary_cos=cos, rotary_sin=sin, cache_seqlens=seqlens.cuda(),
+        cache_batch_idx=None if bidx is None else bidx.cuda(),
+        cache_leftpad=None if lp is None else lp.cuda(), causal=causal, window_size=window,
+        rotary_interleaved=inter, alibi_slopes=slopes, return_softmax_lse=True)
+    o_ref, lse_ref = oracle.kvcache_fwd(
+        f64(q), kc_ref, vc_ref, k=None if knew is None else f64(knew), v=None if vnew is None else f64(vnew),
+        rotary_cos=None if cos is None else f64(cos), rotary_sin=None if sin is None else f64(sin),
+        cache_seqlens=seqlens.numpy(), cache_batch_idx=None if bidx is None else bidx.numpy(),
+        cache_leftpad=None if lp is None else lp.numpy(), causal=causal, window=window,
+        rotary_interleaved=inter, alibi_slopes=None if slopes is None else f64(slopes), io_dtype=dt)
+    # the cache must hold the appended (rotated) rows: 1-ulp slack for fp32-vs-fp64 rounding ties
+    tol = 2.0 ** (-7 if dt == "bf16" else -10)
+    assert np.abs(f64(kc) - kc_ref).max() <= tol * max(1.0, np.abs(kc_ref).max())
+    assert np.array_equal(f64(vc), vc_ref)
+    assert_close(f64(out), o_ref, dt, "out", mult=2.0 if rd else 1.0)
+    assert_lse_close(f64(lse), lse_ref, "lse", atol=2e-2 if rd else 2e-3)
+
+
+@pytest.mark.parametrize("page", [64, 256])
+def test_kvcache_paged_with_rotary(page):
+    B, Hq, Hk, D, dt = 4, 8, 2, 128, "fp16"
+    pages_per_seq = 1024 // page
+    nblk = B * pages_per_seq + 5
+    kc = rand16((nblk, page, Hk, D), dt, 2)
+    vc = rand16((nblk, page, Hk, D), dt, 3)
+    perm = torch.randperm(nblk, generator=torch.Generator().manual_seed(3))[: B * pages_per_seq]
+    bt = perm.reshape(B, pages_per_seq).to(torch.int32)
+    q = rand16((B, 1, Hq, D), dt, 1)
+    knew = rand16((B, 1, Hk, D), dt, 4); vnew = rand16((B, 1, Hk, D), dt, 5)
+    seqlens = torch.tensor([1000, 63, 64, 511], dtype=torch.int32)
+    cos, sin = _rotary(1100, D, dt)
+    kc_ref, vc_ref = f64(kc).copy(), f64(vc).copy()
+    out, lse = _fa().flash_attn_with_kvcache(q, kc, vc, k=knew, v=vnew, rotary_cos=cos, rotary_sin=sin,
+                                             cache_seqlens=seqlens.cuda(), block_table=bt.cuda(), causal=True,
+                                             rotary_interleaved=False, return_softmax_lse=True)
+    o_ref, lse_ref = oracle.kvcache_fwd(f64(q), kc_ref, vc_ref, k=f64(knew), v=f64(vnew), rotary_cos=f64(cos),
+                                        rotary_sin=f64(sin), cache_seqlens=seqlens.numpy(),
+                                        block_table=bt.numpy(), causal=True, rotary_interleaved=False,
+                                        io_dtype=dt)
+    assert np.abs(f64(kc) - kc_ref).max() <= 2.0 ** -10 * max(1.0, np.abs(kc_ref).max())
+    assert np.array_equal(f64(vc), vc_ref)
+    assert_close(f64(out), o_ref, dt, "out", mult=2.0)
+    assert_lse_close(f64(lse), lse_ref, "lse", atol=2e-2)
+
+
+def test_kvcache_argument_errors():
+    q = rand16((2, 1, 4, 128), "fp16", 1)
+    kc = rand16((2, 128, 2, 128), "fp16", 2)
+    with pytest.raises(RuntimeError):          # k without cache_seqlens
+        _fa().flash_attn_with_kvcache(q, kc, kc.clone(), k=rand16((2, 1, 2, 128), "fp16", 3),
+                                      v=rand16((2, 1, 2, 128), "fp16", 4))
+    with pytest.raises(RuntimeError):          # rotary without k
+        cos = torch.zeros(256, 32, dtype=torch.float16, device="cuda")
+        _fa().flash_attn_with_kvcache(q, kc, kc.clone(), rotary_cos=cos, rotary_sin=cos, cache_seqlens=5)

@@ -1,0 +1,112 @@
+"""GPU parity: packed variable-length forward/backward (and paged K/V) vs the oracle."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from util import assert_close, assert_lse_close, f64, rand16
+
+pytestmark = pytest.mark.gpu
+
+
+def _fa():
+    import flash_attn
+    return flash_attn
+
+
+def _cu(lens):
+    return torch.tensor(np.concatenate([[0], np.cumsum(lens)]), dtype=torch.int32, device="cuda")
+
+
+VCASES = [
+    # lens_q, lens_k, Hq, Hk, D, dtype, causal, window, softcap, alibi
+    ([5, 128, 77, 1], None, 4, 4, 64, "fp16", True, (-1, -1), 0.0, False),
+    ([200, 3, 129, 64], None, 4, 2, 128, "bf16", False, (-1, -1), 0.0, False),
+    ([130, 257], [300, 257], 2, 1, 64, "fp16", True, (-1, -1), 0.0, False),      # Sq != Sk
+    ([100, 260, 31], None, 4, 4, 64, "fp16", False, (64, 0), 0.0, False),         # sliding window
+    ([100, 260, 31], None, 2, 2, 128, "bf16", True, (-1, -1), 20.0, True),        # alibi + softcap
+    ([0, 40, 0, 9], None, 2, 2, 64, "fp16", True, (-1, -1), 0.0, False),          # empty sequences
+]
+
+
+@pytest.mark.parametrize("case", VCASES, ids=lambda c: "-".join(map(str, c)))
+def test_varlen_fwd_bwd_vs_oracle(case):
+    lens_q, lens_k, Hq, Hk, D, dt, causal, window, softcap, alibi = case
+    lens_k = lens_k or lens_q
+    B = len(lens_q)
+    Tq, Tk = sum(lens_q), sum(lens_k)
+    q = rand16((Tq, Hq, D), dt, 1).requires_grad_(True)
+    k = rand16((Tk, Hk, D), dt, 2).requires_grad_(True)
+    v = rand16((Tk, Hk, D), dt, 3).requires_grad_(True)
+    do = rand16((Tq, Hq, D), dt, 4)
+    cu_q, cu_k = _cu(lens_q), _cu(lens_k)
+    slopes = torch.tensor([0.25 * (i + 1) / Hq for i in range(Hq)], dtype=torch.float32, device="cuda") \
+        if alibi else None
+    mq, mk = max(lens_q), max(lens_k)
+    out, lse, _ = _fa().flash_attn_varlen_func(q, k, v, cu_q, cu_k, mq, mk, causal=causal,
+                                               window_size=window, softcap=softcap, alibi_slopes=slopes,
+                                               return_attn_probs=True)
+    assert out.shape == q.shape and lse.shape == (Hq, Tq)
+    kw = dict(causal=causal, window=window, softcap=softcap,
+              alibi_slopes=None if slopes is None else f64(slopes))
+    cq, ck = cu_q.cpu().numpy(), cu_k.cpu().numpy()
+    o_ref, lse_ref = oracle.varlen_fwd(f64(q), f64(k), f64(v), cq, ck, mq, mk, D ** -0.5, **kw)
+    assert_close(f64(out), o_ref, dt, "out")
+    assert_lse_close(f64(lse), lse_ref, "lse")
+    dq, dk, dv = torch.autograd.grad(out, (q, k, v), do)
+    dq_r, dk_r, dv_r, _ = oracle.varlen_bwd(f64(do), f64(q), f64(k), f64(v), o_ref,
+                                            lse_ref.astype(np.float64), cq, ck, mq, mk, D ** -0.5, **kw)
+    assert_close(f64(dq), dq_r, dt, "dq", mult=2.0)
+    assert_close(f64(dk), dk_r, dt, "dk", mult=2.0)
+    assert_close(f64(dv), dv_r, dt, "dv", mult=2.0)
+
+
+@pytest.mark.parametrize("page", [64, 256])
+def test_varlen_paged_kv(page):
+    lens_q, lens_k = [70, 1, 300], [200, 513, 300]
+    Hq, Hk, D, dt = 4, 2, 128, "fp16"
+    B = len(lens_q)
+    nblk_per_seq = [(l + page - 1) // page for l in lens_k]
+    max_blocks = max(nblk_per_seq)
+    total_blocks = sum(nblk_per_seq) + 3
+    perm = torch.randperm(total_blocks, generator=torch.Generator().manual_seed(5)).tolist()
+    block_table = torch.zeros((B, max_blocks), dtype=torch.int32)
+    it = iter(perm)
+    for b in range(B):
+        for j in range(nblk_per_seq[b]):
+            block_table[b, j] = next(it)
+    kp = rand16((total_blocks, page, Hk, D), dt, 11)
+    vp = rand16((total_blocks, page, Hk, D), dt, 12)
+    q = rand16((sum(lens_q), Hq, D), dt, 13)
+    cu_q, cu_k = _cu(lens_q), _cu(lens_k)
+    out, lse, _ = _fa().flash_attn_varlen_func(q, kp, vp, cu_q, cu_k, max(lens_q), max(lens_k), causal=True,
+                                               return_attn_probs=True, block_table=block_table.cuda())
+    o_ref, lse_ref = oracle.varlen_fwd(f64(q), f64(kp), f64(vp), cu_q.cpu().numpy(), cu_k.cpu().numpy(),
+                                       max(lens_q), max(lens_k), D ** -0.5, causal=True,
+                                       block_table=block_table.numpy())
+    assert_close(f64(out), o_ref, dt, "out")
+    assert_lse_close(f64(lse), lse_ref, "lse")
+
+
+def test_config3_shape_properties():
+    """BASELINE config 3: fp16 packed batch 64, seqlens in [64, 2048] (max forced to 2048), H32 D64,
+    window (512, 0).  Full size via properties: window (512,0) == causal + window_left 512, and a few
+    sequences equal the oracle."""
+    g = torch.Generator().manual_seed(421)
+    lens = torch.randint(64, 2049, (64,), generator=g).tolist()
+    lens[7] = 2048
+    H, D = 32, 64
+    T = sum(lens)
+    q = rand16((T, H, D), "fp16", 1); k = rand16((T, H, D), "fp16", 2); v = rand16((T, H, D), "fp16", 3)
+    cu = _cu(lens)
+    o1 = _fa().flash_attn_varlen_func(q, k, v, cu, cu, 2048, 2048, window_size=(512, 0))
+    o2 = _fa().flash_attn_varlen_func(q, k, v, cu, cu, 2048, 2048, causal=True, window_size=(512, -1))
+    assert torch.isfinite(o1).all() and torch.equal(o1, o2)
+    cun = cu.cpu().numpy()
+    for b in (0, 7, 63):
+        s0, s1 = int(cun[b]), int(cun[b + 1])
+        hs = slice(3, 5)
+        o_ref, _, _ = oracle.attn_fwd(f64(q[s0:s1, hs]).transpose(1, 0, 2)[None],
+                                      f64(k[s0:s1, hs]).transpose(1, 0, 2)[None],
+                                      f64(v[s0:s1, hs]).transpose(1, 0, 2)[None], D ** -0.5, window=(512, 0))
+        assert_close(f64(o1[s0:s1, hs]).transpose(1, 0, 2)[None], o_ref, "fp16", f"seq {b}")
