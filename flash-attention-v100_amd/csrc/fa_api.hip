@@ -82,7 +82,10 @@ static fa::KArgs make_args(const fa_params& p, int block_m) {
     fa::KArgs a;
     memset(&a, 0, sizeof(a));
     a.p = p;
-    a.n_qblocks = (p.seqlen_q + block_m - 1) / block_m;
+    a.n_qblocks_total = (p.seqlen_q + block_m - 1) / block_m;
+    // causal-like masks make late q-blocks heavier: pair block i with its mirror (equal work)
+    a.pair_qblocks = ((p.is_causal || p.window_right >= 0) && p.window_left < 0 && a.n_qblocks_total >= 2) ? 1 : 0;
+    a.n_qblocks = a.pair_qblocks ? (a.n_qblocks_total + 1) / 2 : a.n_qblocks_total;
     a.has_bias = (p.alibi_slopes != nullptr) || (p.softcap > 0.f);
     a.scale_log2e = p.softmax_scale * fa::kLog2e;
     return a;

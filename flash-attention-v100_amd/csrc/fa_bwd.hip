@@ -17,6 +17,7 @@
 // Every GEMM runs on v_mfma_f32_32x32x16; P and dS are rounded to the 16-bit io type before
 // their GEMMs (as the reference does) and the MFMA C-layout is reused as the next B operand.
 #include <cstdlib>
+#include <type_traits>
 #include "fa_common.h"
 
 namespace fa {
@@ -99,24 +100,56 @@ __global__ void __launch_bounds__(BWD_THREADS, 1) fa_bwd_dkdv_kernel(const KArgs
 
     const fa_params& p = a.p;
     const int n_kblocks = (p.seqlen_k + DKV_BN - 1) / DKV_BN;
-    // unit = (b, hk); key blocks ascending == heavy first for causal
-    int b, hk, nb;
+    // causal load balance: key block i is paired with its mirror (heavy + light = constant)
+    const bool pair = a.pair_qblocks && n_kblocks >= 2;
+    const int n_kb_grid = pair ? (n_kblocks + 1) / 2 : n_kblocks;
+    int b, hk, nb0;
     {
         const int id = blockIdx.x, xcd = id & 7, j = id >> 3;
-        const int ul = j / n_kblocks;
-        nb = j - ul * n_kblocks;
+        const int ul = j / n_kb_grid;
+        nb0 = j - ul * n_kb_grid;
         const int unit = ul * 8 + xcd;
         if (unit >= p.batch * p.nheads_k) return;
         b = unit / p.nheads_k; hk = unit - b * p.nheads_k;
     }
     const SeqGeom sg = seq_geom(p, b);
-    const int n0 = nb * DKV_BN;
-    if (n0 >= sg.seqlen_k) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, g = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, g = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int group = p.nheads_q / p.nheads_k;
     const int off = sg.off;
     const int wl = p.window_left;
     const int wr = p.is_causal ? 0 : p.window_right;
+    const float c = a.scale_log2e;
+
+    // loop-invariant staging geometry
+    uint32_t q_voff[CHUNKS], do_voff[CHUNKS];
+    int t_lds[CHUNKS];
+#pragma unroll
+    for (int i = 0; i < CHUNKS; ++i) {
+        const int cidx = tid + i * BWD_THREADS;
+        const int row = cidx / CPR, cc = cidx % CPR;
+        q_voff[i] = (uint32_t)(row * p.q_row_stride + cc * 8) * 2u;
+        do_voff[i] = (uint32_t)(row * p.do_row_stride + cc * 8) * 2u;
+        t_lds[i] = swzt_row_off<D>(row, cc * 16);
+    }
+    const int64_t qb_off = p.cu_seqlens_q ? 0 : (int64_t)b * p.q_batch_stride;
+    const int64_t dob_off = p.cu_seqlens_q ? 0 : (int64_t)b * p.do_batch_stride;
+    const uint16_t* q_base = reinterpret_cast<const uint16_t*>(p.q) + qb_off + sg.q_row0 * p.q_row_stride;
+    const uint16_t* do_base = reinterpret_cast<const uint16_t*>(p.dout) + dob_off + sg.q_row0 * p.do_row_stride;
+    const float* lse_base = p.lse + (int64_t)b * p.lse_batch_stride + sg.q_row0;
+    const float* dsum_base = p.softmax_d + (int64_t)b * p.lse_batch_stride + sg.q_row0;
+    // lane-constant LDS read offsets
+    int a_rd[KSTEPS];
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) a_rd[ks] = swzt_row_off<D>(l31, 32 * ks + 16 * g);
+    const int rr = (lane & 15) >> 2;
+    const int cb = (((lane >> 4) & 1) << 5) + ((lane & 3) << 3);
+
+    const int n_pass = (pair && (n_kblocks - 1 - nb0) != nb0) ? 2 : 1;
+    for (int pass = 0; pass < n_pass; ++pass) {
+    const int nb = pass == 0 ? nb0 : n_kblocks - 1 - nb0;
+    const int n0 = nb * DKV_BN;
+    if (n0 >= sg.seqlen_k) continue;
 
     const int kw0 = n0 + wave * 32;
     const int my_key = kw0 + l31;
@@ -169,32 +202,21 @@ __global__ void __launch_bounds__(BWD_THREADS, 1) fa_bwd_dkdv_kernel(const KArgs
         }
     }
 
-    // ---- staging of Q / dO / lse / D tiles ----
-    const int64_t qb_off = p.cu_seqlens_q ? 0 : (int64_t)b * p.q_batch_stride;
-    const int64_t dob_off = p.cu_seqlens_q ? 0 : (int64_t)b * p.do_batch_stride;
-    const uint16_t* q_base = reinterpret_cast<const uint16_t*>(p.q) + qb_off + sg.q_row0 * p.q_row_stride;
-    const uint16_t* do_base = reinterpret_cast<const uint16_t*>(p.dout) + dob_off + sg.q_row0 * p.do_row_stride;
-    const float* lse_base = p.lse + (int64_t)b * p.lse_batch_stride + sg.q_row0;
-    const float* dsum_base = p.softmax_d + (int64_t)b * p.lse_batch_stride + sg.q_row0;
-
+    // ---- staging of Q / dO / lse / D tiles (rows past seqlen_q read as zero) ----
     u32x4 qreg[CHUNKS], doreg[CHUNKS];
     float statreg = 0.f;
     auto load_tile = [&](int it) {
         const int gq = it / n_tiles;
         const int m0 = (mt0 + it - gq * n_tiles) * DKV_BQ;
         const int h = hk * group + gq;
+        const __amdgpu_buffer_rsrc_t q_rsrc = make_rsrc(q_base + (int64_t)h * p.q_head_stride, p.q_row_stride, sg.seqlen_q, D);
+        const __amdgpu_buffer_rsrc_t do_rsrc = make_rsrc(do_base + (int64_t)h * p.do_head_stride, p.do_row_stride, sg.seqlen_q, D);
+        const uint32_t q_soff = (uint32_t)(m0 * p.q_row_stride * 2);
+        const uint32_t do_soff = (uint32_t)(m0 * p.do_row_stride * 2);
 #pragma unroll
-        for (int i = 0; i < CHUNKS; ++i) {
-            const int c = tid + i * BWD_THREADS;
-            const int row = c / CPR, cc = c % CPR;
-            const int qi = m0 + row;
-            u32x4 z = {0, 0, 0, 0};
-            qreg[i] = z; doreg[i] = z;
-            if (qi < sg.seqlen_q) {
-                qreg[i] = *reinterpret_cast<const u32x4*>(q_base + (int64_t)qi * p.q_row_stride + (int64_t)h * p.q_head_stride + cc * 8);
-                doreg[i] = *reinterpret_cast<const u32x4*>(do_base + (int64_t)qi * p.do_row_stride + (int64_t)h * p.do_head_stride + cc * 8);
-            }
-        }
+        for (int i = 0; i < CHUNKS; ++i) qreg[i] = buf_load_b128(q_rsrc, q_voff[i], q_soff);
+#pragma unroll
+        for (int i = 0; i < CHUNKS; ++i) doreg[i] = buf_load_b128(do_rsrc, do_voff[i], do_soff);
         if (tid < 2 * DKV_BQ) {
             const int r = tid & (DKV_BQ - 1);
             const int qi = m0 + r;
@@ -205,16 +227,15 @@ __global__ void __launch_bounds__(BWD_THREADS, 1) fa_bwd_dkdv_kernel(const KArgs
             }
         }
     };
-    auto store_tile = [&](int stage) {
+    auto store_tile = [&](auto stage_c) {
+        constexpr int stage = decltype(stage_c)::value;
         char* qs = smem + stage * STAGE;
         char* dos = qs + TILE;
         float* st = reinterpret_cast<float*>(dos + TILE);
 #pragma unroll
         for (int i = 0; i < CHUNKS; ++i) {
-            const int c = tid + i * BWD_THREADS;
-            const int row = c / CPR, cc = c % CPR;
-            lds_write_b128(qs + swzt_row_off<D>(row, cc * 16), qreg[i]);
-            lds_write_b128(dos + swzt_row_off<D>(row, cc * 16), doreg[i]);
+            lds_write_b128(qs + t_lds[i], qreg[i]);
+            lds_write_b128(dos + t_lds[i], doreg[i]);
         }
         if (tid < 2 * DKV_BQ) st[tid] = statreg;          // [0,64): lse2, [64,128): D
     };
@@ -227,17 +248,11 @@ __global__ void __launch_bounds__(BWD_THREADS, 1) fa_bwd_dkdv_kernel(const KArgs
 
     float slope = 0.f;
 
-    if (n_iter > 0) { load_tile(0); store_tile(0); }
-    __syncthreads();
-
-    for (int it = 0; it < n_iter; ++it) {
-        const int stage = it & 1;
-        const bool has_next = it + 1 < n_iter;
-        if (has_next) load_tile(it + 1);
+    auto compute = [&](auto stage_c, int it) {
+        constexpr int stage = decltype(stage_c)::value;
         const int gq = it / n_tiles;
         const int m0 = (mt0 + it - gq * n_tiles) * DKV_BQ;
         if (BIAS && p.alibi_slopes) slope = p.alibi_slopes[b * p.alibi_batch_stride + hk * group + gq];
-
         const char* qs = smem + stage * STAGE;
         const char* dos = qs + TILE;
         const float* st = reinterpret_cast<const float*>(dos + TILE);
@@ -253,12 +268,12 @@ __global__ void __launch_bounds__(BWD_THREADS, 1) fa_bwd_dkdv_kernel(const KArgs
             for (int r = 0; r < 16; ++r) { s_acc[r] = 0.f; dp_acc[r] = 0.f; }
 #pragma unroll
             for (int ks = 0; ks < KSTEPS; ++ks) {
-                const u32x4 qa = lds_read_b128(qs + swzt_row_off<D>(sub * 32 + l31, 32 * ks + 16 * g));
+                const u32x4 qa = lds_read_b128(qs + a_rd[ks] + sub * 32 * D * 2);
                 s_acc = E::mfma(qa, kf[ks], s_acc);
             }
 #pragma unroll
             for (int ks = 0; ks < KSTEPS; ++ks) {
-                const u32x4 da = lds_read_b128(dos + swzt_row_off<D>(sub * 32 + l31, 32 * ks + 16 * g));
+                const u32x4 da = lds_read_b128(dos + a_rd[ks] + sub * 32 * D * 2);
                 dp_acc = E::mfma(da, vf[ks], dp_acc);
             }
             // row statistics for q = q0 + 8 i + 4 g + (0..3)
@@ -268,14 +283,13 @@ __global__ void __launch_bounds__(BWD_THREADS, 1) fa_bwd_dkdv_kernel(const KArgs
                 lse2[i] = *reinterpret_cast<const f32x4*>(st + sub * 32 + 8 * i + 4 * g);
                 dsum[i] = *reinterpret_cast<const f32x4*>(st + DKV_BQ + sub * 32 + 8 * i + 4 * g);
             }
-            const bool need_mask = key_tail || (q0 < w_qlo_max) || (q0 + 31 > w_qhi_min);
             float pv[16], dsv[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int qi = q0 + (r & 3) + 8 * (r >> 2) + 4 * g;
                 const float l2 = lse2[r >> 2][r & 3];
                 float pr, dsr;
                 if (BIAS) {
+                    const int qi = q0 + (r & 3) + 8 * (r >> 2) + 4 * g;
                     float s = s_acc[r] * p.softmax_scale;
                     s = fmaf(-slope, fabsf((float)(qi + off - my_key)), s);
                     float chain = 1.f;
@@ -287,11 +301,18 @@ __global__ void __launch_bounds__(BWD_THREADS, 1) fa_bwd_dkdv_kernel(const KArgs
                     pr = fast_exp2(fmaf(s, kLog2e, -l2));
                     dsr = pr * (dp_acc[r] - dsum[r >> 2][r & 3]) * chain;
                 } else {
-                    pr = fast_exp2(fmaf(s_acc[r], a.scale_log2e, -l2));
+                    pr = fast_exp2(fmaf(s_acc[r], c, -l2));
                     dsr = pr * (dp_acc[r] - dsum[r >> 2][r & 3]);
                 }
-                if (need_mask && (qi < qlo || qi > qhi)) { pr = 0.f; dsr = 0.f; }
                 pv[r] = pr; dsv[r] = dsr;
+            }
+            const bool need_mask = key_tail || (q0 < w_qlo_max) || (q0 + 31 > w_qhi_min);
+            if (need_mask) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int qi = q0 + (r & 3) + 8 * (r >> 2) + 4 * g;
+                    if (qi < qlo || qi > qhi) { pv[r] = 0.f; dsv[r] = 0.f; }
+                }
             }
             // ---- dV^T += dO^T P,  dK^T += Q^T dS : k-step t covers regs 8t .. 8t+7 ----
 #pragma unroll
@@ -303,8 +324,6 @@ __global__ void __launch_bounds__(BWD_THREADS, 1) fa_bwd_dkdv_kernel(const KArgs
                     dsf[w2] = E::pack2(dsv[8 * t + 2 * w2], dsv[8 * t + 2 * w2 + 1]);
                 }
                 // rows sub*32 + 16 t + 8 hf + 4 g + rr ; cols 32 d + 16 ((lane>>4)&1) + 4 (lane&3)
-                const int rr = (lane & 15) >> 2;
-                const int cb = (((lane >> 4) & 1) << 5) + ((lane & 3) << 3);
                 const int row_a = sub * 32 + 16 * t + 4 * g + rr;
 #pragma unroll
                 for (int d = 0; d < DBLKS; ++d) {
@@ -319,8 +338,21 @@ __global__ void __launch_bounds__(BWD_THREADS, 1) fa_bwd_dkdv_kernel(const KArgs
                 }
             }
         }
-        if (has_next) store_tile(stage ^ 1);
+    };
+    auto step = [&](auto stage_c, int it) {
+        constexpr int stage = decltype(stage_c)::value;
+        const bool has_next = it + 1 < n_iter;
+        if (has_next) load_tile(it + 1);
+        compute(stage_c, it);
+        if (has_next) store_tile(std::integral_constant<int, stage ^ 1>{});
         __syncthreads();
+    };
+
+    if (n_iter > 0) { load_tile(0); store_tile(std::integral_constant<int, 0>{}); }
+    __syncthreads();
+    for (int it = 0; it < n_iter; it += 2) {
+        step(std::integral_constant<int, 0>{}, it);
+        if (it + 1 < n_iter) step(std::integral_constant<int, 1>{}, it + 1);
     }
 
     // ---- epilogue: lane (key = l31, g) holds dX[my_key][32 d + 8 rq + 4 g + (0..3)] ----
@@ -343,6 +375,7 @@ __global__ void __launch_bounds__(BWD_THREADS, 1) fa_bwd_dkdv_kernel(const KArgs
                 *reinterpret_cast<u32x2*>(dvp + d * 32 + 8 * rq + 4 * g) = v2;
             }
     }
+    }   // pass
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -371,13 +404,49 @@ __global__ void __launch_bounds__(BWD_THREADS, OCC) fa_bwd_dq_kernel(const KArgs
     const fa_params& p = a.p;
     const WorkItem w = decode_work(blockIdx.x, p.batch, p.nheads_q, p.nheads_k, a.n_qblocks);
     if (!w.valid) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, g = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, g = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const SeqGeom sg = seq_geom(p, w.b);
-    const int m_block = w.qb * DQ_BM;
-    if (m_block >= sg.seqlen_q) return;
     const int off = sg.off;
     const int wl = p.window_left;
     const int wr = p.is_causal ? 0 : p.window_right;
+    const float c = a.scale_log2e;
+
+    const int64_t kb_off = p.cu_seqlens_k ? 0 : (int64_t)w.b * p.k_batch_stride;
+    const int64_t vb_off = p.cu_seqlens_k ? 0 : (int64_t)w.b * p.v_batch_stride;
+    const uint16_t* kp = reinterpret_cast<const uint16_t*>(p.k) + kb_off + sg.k_row0 * p.k_row_stride + (int64_t)w.hk * p.k_head_stride;
+    const uint16_t* vp = reinterpret_cast<const uint16_t*>(p.v) + vb_off + sg.k_row0 * p.v_row_stride + (int64_t)w.hk * p.v_head_stride;
+    const __amdgpu_buffer_rsrc_t k_rsrc = make_rsrc(kp, p.k_row_stride, sg.seqlen_k, D);
+    const __amdgpu_buffer_rsrc_t v_rsrc = make_rsrc(vp, p.v_row_stride, sg.seqlen_k, D);
+    const uint32_t k_tile_bytes = (uint32_t)(DQ_BN * p.k_row_stride * 2);
+    const uint32_t v_tile_bytes = (uint32_t)(DQ_BN * p.v_row_stride * 2);
+    uint32_t k_voff[CHUNKS], v_voff[CHUNKS];
+    int k_lds[CHUNKS], v_lds[CHUNKS];
+#pragma unroll
+    for (int i = 0; i < CHUNKS; ++i) {
+        const int cidx = tid + i * BWD_THREADS;
+        const int row = cidx / CPR, cc = cidx % CPR;
+        k_voff[i] = (uint32_t)(row * p.k_row_stride + cc * 8) * 2u;
+        v_voff[i] = (uint32_t)(row * p.v_row_stride + cc * 8) * 2u;
+        k_lds[i] = swzt_row_off<D>(row, cc * 16);
+        v_lds[i] = TILE + swz_row_off<D>(row, cc * 16);
+    }
+    int k_rd[KSTEPS], v_rd[KSTEPS];
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+        k_rd[ks] = swzt_row_off<D>(l31, 32 * ks + 16 * g);
+        v_rd[ks] = TILE + swz_row_off<D>(l31, 32 * ks + 16 * g);
+    }
+    const int rr = (lane & 15) >> 2;
+    const int cb = (((lane >> 4) & 1) << 5) + ((lane & 3) << 3);
+    float slope = 0.f;
+    if (BIAS && p.alibi_slopes) slope = p.alibi_slopes[w.b * p.alibi_batch_stride + w.h];
+
+    const int n_pass = (a.pair_qblocks && (a.n_qblocks_total - 1 - w.qb) != w.qb) ? 2 : 1;
+    for (int pass = 0; pass < n_pass; ++pass) {
+    const int qb_cur = pass == 0 ? w.qb : a.n_qblocks_total - 1 - w.qb;
+    const int m_block = qb_cur * DQ_BM;
+    if (m_block >= sg.seqlen_q) continue;
     int n_min = 0, n_max = (sg.seqlen_k + DQ_BN - 1) / DQ_BN;
     {
         const int m_last = (m_block + DQ_BM < sg.seqlen_q ? m_block + DQ_BM : sg.seqlen_q) - 1;
@@ -427,39 +496,23 @@ __global__ void __launch_bounds__(BWD_THREADS, OCC) fa_bwd_dq_kernel(const KArgs
             dsum = p.softmax_d[so];
         }
     }
-    float slope = 0.f;
-    if (BIAS && p.alibi_slopes) slope = p.alibi_slopes[w.b * p.alibi_batch_stride + w.h];
-
-    const int64_t kb_off = p.cu_seqlens_k ? 0 : (int64_t)w.b * p.k_batch_stride;
-    const int64_t vb_off = p.cu_seqlens_k ? 0 : (int64_t)w.b * p.v_batch_stride;
-    const uint16_t* kp = reinterpret_cast<const uint16_t*>(p.k) + kb_off + sg.k_row0 * p.k_row_stride + (int64_t)w.hk * p.k_head_stride;
-    const uint16_t* vp = reinterpret_cast<const uint16_t*>(p.v) + vb_off + sg.k_row0 * p.v_row_stride + (int64_t)w.hk * p.v_head_stride;
 
     u32x4 kreg[CHUNKS], vreg[CHUNKS];
     auto load_tile = [&](int nb) {
-        const int n0 = nb * DQ_BN;
+        const uint32_t ks_off = (uint32_t)nb * k_tile_bytes;
+        const uint32_t vs_off = (uint32_t)nb * v_tile_bytes;
 #pragma unroll
-        for (int i = 0; i < CHUNKS; ++i) {
-            const int c = tid + i * BWD_THREADS;
-            const int row = c / CPR, cc = c % CPR;
-            const int j = n0 + row;
-            u32x4 z = {0, 0, 0, 0};
-            kreg[i] = z; vreg[i] = z;
-            if (j < sg.seqlen_k) {
-                kreg[i] = *reinterpret_cast<const u32x4*>(kp + (int64_t)j * p.k_row_stride + cc * 8);
-                vreg[i] = *reinterpret_cast<const u32x4*>(vp + (int64_t)j * p.v_row_stride + cc * 8);
-            }
-        }
+        for (int i = 0; i < CHUNKS; ++i) kreg[i] = buf_load_b128(k_rsrc, k_voff[i], ks_off);
+#pragma unroll
+        for (int i = 0; i < CHUNKS; ++i) vreg[i] = buf_load_b128(v_rsrc, v_voff[i], vs_off);
     };
-    auto store_tile = [&](int stage) {
-        char* ks = smem + stage * STAGE;
-        char* vs = ks + TILE;
+    auto store_tile = [&](auto stage_c) {
+        constexpr int stage = decltype(stage_c)::value;
+        char* base = smem + stage * STAGE;
 #pragma unroll
         for (int i = 0; i < CHUNKS; ++i) {
-            const int c = tid + i * BWD_THREADS;
-            const int row = c / CPR, cc = c % CPR;
-            lds_write_b128(ks + swzt_row_off<D>(row, cc * 16), kreg[i]);
-            lds_write_b128(vs + swz_row_off<D>(row, cc * 16), vreg[i]);
+            lds_write_b128(base + k_lds[i], kreg[i]);
+            lds_write_b128(base + v_lds[i], vreg[i]);
         }
     };
 
@@ -469,79 +522,89 @@ __global__ void __launch_bounds__(BWD_THREADS, OCC) fa_bwd_dq_kernel(const KArgs
 #pragma unroll
         for (int r = 0; r < 16; ++r) dq_acc[d][r] = 0.f;
 
-    if (n_min < n_max) { load_tile(n_min); store_tile(0); }
-    __syncthreads();
-
-    for (int nb = n_min; nb < n_max; ++nb) {
-        const int stage = (nb - n_min) & 1;
+    auto compute = [&](auto stage_c, int nb) {
+        constexpr int stage = decltype(stage_c)::value;
+        const int n0 = nb * DQ_BN;
+        const char* sbase = smem + stage * STAGE;
+        const bool need_mask = row_tail || (n0 + DQ_BN - 1 > w_hi_min) || (n0 < w_lo_max);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            // S^T, dP^T : acc[r] = X[my_row][n0 + 32 kb + row(r,g)]
+            f32x16 s_acc, dp_acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s_acc[r] = 0.f; dp_acc[r] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < KSTEPS; ++ks) {
+                const u32x4 ka = lds_read_b128(sbase + k_rd[ks] + kb * 32 * D * 2);
+                s_acc = E::mfma(ka, qf[ks], s_acc);
+            }
+#pragma unroll
+            for (int ks = 0; ks < KSTEPS; ++ks) {
+                const u32x4 va = lds_read_b128(sbase + v_rd[ks] + kb * 32 * D * 2);
+                dp_acc = E::mfma(va, dof[ks], dp_acc);
+            }
+            float dsv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float pr, dsr;
+                if (BIAS) {
+                    const int j = n0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+                    float s = s_acc[r] * p.softmax_scale;
+                    s = fmaf(-slope, fabsf((float)(my_row + off - j)), s);
+                    float chain = 1.f;
+                    if (p.softcap > 0.f) {
+                        const float t = fast_tanh(s / p.softcap);
+                        s = p.softcap * t;
+                        chain = 1.f - t * t;
+                    }
+                    pr = fast_exp2(fmaf(s, kLog2e, -lse2));
+                    dsr = pr * (dp_acc[r] - dsum) * chain;
+                } else {
+                    pr = fast_exp2(fmaf(s_acc[r], c, -lse2));
+                    dsr = pr * (dp_acc[r] - dsum);
+                }
+                dsv[r] = dsr;
+            }
+            if (need_mask) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int j = n0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+                    if (j < lo || j > hi) dsv[r] = 0.f;
+                }
+            }
+            // dQ^T += K^T dS^T
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                u32x4 dsf;
+#pragma unroll
+                for (int w2 = 0; w2 < 4; ++w2) dsf[w2] = E::pack2(dsv[8 * t + 2 * w2], dsv[8 * t + 2 * w2 + 1]);
+                const int row_a = kb * 32 + 16 * t + 4 * g + rr;
+#pragma unroll
+                for (int d = 0; d < DBLKS; ++d) {
+                    const u32x2 a0 = lds_read_tr16(sbase + swzt_row_off<D>(row_a, d * 64 + cb));
+                    const u32x2 a1 = lds_read_tr16(sbase + swzt_row_off<D>(row_a + 8, d * 64 + cb));
+                    u32x4 af = {a0[0], a0[1], a1[0], a1[1]};
+                    dq_acc[d] = E::mfma(af, dsf, dq_acc[d]);
+                }
+            }
+        }
+    };
+    auto step = [&](auto stage_c, int nb) {
+        constexpr int stage = decltype(stage_c)::value;
         const bool has_next = nb + 1 < n_max;
         if (has_next) load_tile(nb + 1);
         const int n0 = nb * DQ_BN;
         const bool wave_active = (n0 <= w_hi_max) && (n0 + DQ_BN - 1 >= w_lo_min) && (wave_row0 < sg.seqlen_q);
-        if (wave_active) {
-            const char* ks_base = smem + stage * STAGE;
-            const char* vs_base = ks_base + TILE;
-            const bool need_mask = row_tail || (n0 + DQ_BN - 1 > w_hi_min) || (n0 < w_lo_max);
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
-                // S^T, dP^T : acc[r] = X[my_row][n0 + 32 kb + row(r,g)]
-                f32x16 s_acc, dp_acc;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { s_acc[r] = 0.f; dp_acc[r] = 0.f; }
-#pragma unroll
-                for (int ks = 0; ks < KSTEPS; ++ks) {
-                    const u32x4 ka = lds_read_b128(ks_base + swzt_row_off<D>(kb * 32 + l31, 32 * ks + 16 * g));
-                    s_acc = E::mfma(ka, qf[ks], s_acc);
-                }
-#pragma unroll
-                for (int ks = 0; ks < KSTEPS; ++ks) {
-                    const u32x4 va = lds_read_b128(vs_base + swz_row_off<D>(kb * 32 + l31, 32 * ks + 16 * g));
-                    dp_acc = E::mfma(va, dof[ks], dp_acc);
-                }
-                float dsv[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int j = n0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
-                    float pr, dsr;
-                    if (BIAS) {
-                        float s = s_acc[r] * p.softmax_scale;
-                        s = fmaf(-slope, fabsf((float)(my_row + off - j)), s);
-                        float chain = 1.f;
-                        if (p.softcap > 0.f) {
-                            const float t = fast_tanh(s / p.softcap);
-                            s = p.softcap * t;
-                            chain = 1.f - t * t;
-                        }
-                        pr = fast_exp2(fmaf(s, kLog2e, -lse2));
-                        dsr = pr * (dp_acc[r] - dsum) * chain;
-                    } else {
-                        pr = fast_exp2(fmaf(s_acc[r], a.scale_log2e, -lse2));
-                        dsr = pr * (dp_acc[r] - dsum);
-                    }
-                    if (need_mask && (j < lo || j > hi)) dsr = 0.f;
-                    dsv[r] = dsr;
-                }
-                // dQ^T += K^T dS^T
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    u32x4 dsf;
-#pragma unroll
-                    for (int w2 = 0; w2 < 4; ++w2) dsf[w2] = E::pack2(dsv[8 * t + 2 * w2], dsv[8 * t + 2 * w2 + 1]);
-                    const int rr = (lane & 15) >> 2;
-                    const int cb = (((lane >> 4) & 1) << 5) + ((lane & 3) << 3);
-                    const int row_a = kb * 32 + 16 * t + 4 * g + rr;
-#pragma unroll
-                    for (int d = 0; d < DBLKS; ++d) {
-                        const u32x2 a0 = lds_read_tr16(ks_base + swzt_row_off<D>(row_a, d * 64 + cb));
-                        const u32x2 a1 = lds_read_tr16(ks_base + swzt_row_off<D>(row_a + 8, d * 64 + cb));
-                        u32x4 af = {a0[0], a0[1], a1[0], a1[1]};
-                        dq_acc[d] = E::mfma(af, dsf, dq_acc[d]);
-                    }
-                }
-            }
-        }
-        if (has_next) store_tile(stage ^ 1);
+        if (wave_active) compute(stage_c, nb);
+        if (has_next) store_tile(std::integral_constant<int, stage ^ 1>{});
         __syncthreads();
+    };
+
+    if (n_min < n_max) { load_tile(n_min); store_tile(std::integral_constant<int, 0>{}); }
+    __syncthreads();
+    for (int nb = n_min; nb < n_max; nb += 2) {
+        step(std::integral_constant<int, 0>{}, nb);
+        if (nb + 1 < n_max) step(std::integral_constant<int, 1>{}, nb + 1);
     }
 
     if (my_row < sg.seqlen_q) {
@@ -558,6 +621,7 @@ __global__ void __launch_bounds__(BWD_THREADS, OCC) fa_bwd_dq_kernel(const KArgs
                 *reinterpret_cast<u32x2*>(dqp + d * 32 + 8 * rq + 4 * g) = o2;
             }
     }
+    }   // pass
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -581,8 +645,9 @@ static int launch_bwd_td(const KArgs& a, hipStream_t stream) {
     // 2. dK/dV
     if (g_bwd_phase_mask & 2) {
         const int n_kblocks = (p.seqlen_k + DKV_BN - 1) / DKV_BN;
+        const int n_kb_grid = (a.pair_qblocks && n_kblocks >= 2) ? (n_kblocks + 1) / 2 : n_kblocks;
         const int units = p.batch * p.nheads_k;
-        const int grid = 8 * ((units + 7) / 8) * n_kblocks;
+        const int grid = 8 * ((units + 7) / 8) * n_kb_grid;
         const size_t smem = DkvSmem<D>::TOTAL;
         if (grid > 0) {
             if (a.has_bias) {

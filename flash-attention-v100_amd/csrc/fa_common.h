@@ -123,9 +123,42 @@ __device__ __forceinline__ float fast_tanh(float x) {
     return 1.0f - 2.0f * fast_rcp(1.0f + e);
 }
 
-__device__ __forceinline__ float shfl_xor32(float v) {
-    // exchange between lane l and l ^ 32
-    return __shfl_xor(v, 32, 64);
+// Cross-half (lane l <-> l ^ 32) reductions with one v_permlane32_swap (no LDS round trip).
+// v_permlane32_swap_b32 vdst, src: lanes 32-63 of vdst swap with lanes 0-31 of src.  With
+// a == b == x: a' = {lo: x_lo, hi: x_lo}, b' = {lo: x_hi, hi: x_hi}.
+// Inline asm on purpose: clang (ROCm 7.2) lowers r[1] of __builtin_amdgcn_permlane32_swap to
+// extractvalue 0, i.e. returns the first result twice.  "s_nop 1" = the 2 wait states a
+// VALU-written operand needs before v_permlane*_swap reads it.
+__device__ __forceinline__ void permlane32_swap(uint32_t& a, uint32_t& b) {
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ float xhalf_max(float v) {
+    uint32_t a = __builtin_bit_cast(uint32_t, v), b = a;
+    permlane32_swap(a, b);
+    return fmaxf(__builtin_bit_cast(float, a), __builtin_bit_cast(float, b));
+}
+__device__ __forceinline__ float xhalf_sum(float v) {
+    uint32_t a = __builtin_bit_cast(uint32_t, v), b = a;
+    permlane32_swap(a, b);
+    return __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b);
+}
+
+// ---- global -> register tile loads through a buffer descriptor ------------------------------
+// One descriptor per (batch, head) slice: rows past `nrows` read as zero (hardware range
+// check), so tail tiles need no predication and no zero-fill code.  voffset is per-lane and
+// loop-invariant; the tile / row offset travels in the scalar soffset.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, int64_t row_stride_elems,
+                                                            int nrows, int d) {
+    const uint64_t b = reinterpret_cast<uint64_t>(base);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)b);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
+    const int64_t bytes64 = nrows > 0 ? ((int64_t)(nrows - 1) * row_stride_elems + d) * 2 : 0;
+    const uint32_t bytes = __builtin_amdgcn_readfirstlane((uint32_t)(bytes64 > 0xffffffffll ? 0xffffffffll : bytes64));
+    void* ptr = reinterpret_cast<void*>(((uint64_t)hi << 32) | lo);
+    return __builtin_amdgcn_make_buffer_rsrc(ptr, 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ u32x4 buf_load_b128(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
+    return __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
 }
 
 // Work decomposition shared by forward-like kernels: 1-D grid, block id -> XCD-aware
@@ -161,7 +194,9 @@ static inline int work_grid(int batch, int nheads_q, int nheads_k, int n_qblocks
 // Host-side launch args: the ABI struct plus derived values.
 struct KArgs {
     fa_params p;
-    int n_qblocks;
+    int n_qblocks;         // q-blocks per (batch, head) in the GRID (halved when pairing)
+    int n_qblocks_total;   // ceil(seqlen_q / block_m)
+    int pair_qblocks;      // causal load balance: a workgroup owns q-blocks (i, total-1-i)
     int has_bias;          // alibi or softcap
     float scale_log2e;
     const int32_t* seqlens_k;      // per-batch key count (seqused_k or cache_seqlens), or NULL

@@ -6,15 +6,18 @@
 // with ONE CDNA4 design:
 //   * workgroup = 4 waves, 128 query rows (32 per wave), KV tile = 64 keys;
 //   * S^T = K Q^T on v_mfma_f32_32x32x16 ("swapped" so a lane owns ONE query row: the
-//     online-softmax max/sum are lane-local + one cross-half exchange, no LDS for S/P);
+//     online-softmax max/sum are lane-local + one v_permlane32_swap, no LDS for S/P);
 //   * the S^T accumulator registers are packed to 16-bit and fed straight back as the B
 //     operand of O^T = V^T P^T (the key index is only a contraction index, so the MFMA
 //     C-layout key order is used as-is: no permute, no LDS round trip);
 //   * V^T comes from LDS through ds_read_b64_tr_b16 (hardware 4x4 transpose), K through
-//     XOR-swizzled ds_read_b128; both tiles are double buffered, global->register loads
-//     of tile t+1 are issued before the MFMAs of tile t and written to LDS after them
-//     (one barrier per tile);
+//     XOR-swizzled ds_read_b128; both tiles are double buffered, buffer_load of tile t+1 is
+//     issued before the MFMAs of tile t and written to LDS after them (one barrier per tile);
+//     rows past the sequence end come back as zeros from the buffer range check;
+//   * the running max is only raised when a tile exceeds it by more than 2^8 ("deferred
+//     rescale"), so most tiles skip the O-accumulator rescale;
 //   * running max / sum and the O accumulator never leave registers.
+#include <type_traits>
 #include "fa_common.h"
 
 namespace fa {
@@ -22,6 +25,7 @@ namespace fa {
 constexpr int FWD_BM = 128;
 constexpr int FWD_BN = 64;
 constexpr int FWD_THREADS = 256;
+constexpr float FWD_RESCALE_THR = 8.0f;                // log2 units
 
 template <int D> struct FwdSmem {
     static constexpr int TILE = FWD_BN * D * 2;        // bytes of one K (or V) tile
@@ -45,7 +49,7 @@ __global__ void __launch_bounds__(FWD_THREADS, 2) fa_fwd_kernel(const KArgs a) {
     if (!w.valid) return;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform
     const int l31 = lane & 31;
     const int g = lane >> 5;
 
@@ -70,11 +74,16 @@ __global__ void __launch_bounds__(FWD_THREADS, 2) fa_fwd_kernel(const KArgs a) {
     if (a.kv_batch_idx) kv_b = a.kv_batch_idx[w.b];
     if (a.leftpad_k) k_row0 += a.leftpad_k[w.b];
 
-    const int m_block = w.qb * FWD_BM;
-    if (m_block >= seqlen_q) return;
     const int off = seqlen_k - seqlen_q;               // bottom-right alignment
     const int wl = p.window_left;
     const int wr = p.is_causal ? 0 : p.window_right;   // causal == window_right 0 (include/mat_mul.h:92,103)
+    // Causal load balance: with a.pair_qblocks the workgroup owns q-block qb (heavy) and then its
+    // mirror n_qblocks-1-qb (light), so every workgroup carries the same number of KV tiles.
+    const int n_pass = (a.pair_qblocks && (a.n_qblocks_total - 1 - w.qb) != w.qb) ? 2 : 1;
+    for (int pass = 0; pass < n_pass; ++pass) {
+    const int qb_cur = pass == 0 ? w.qb : a.n_qblocks_total - 1 - w.qb;
+    const int m_block = qb_cur * FWD_BM;
+    if (m_block >= seqlen_q) continue;
     // key-tile range for this 128-row block
     int n_min = 0, n_max = (seqlen_k + FWD_BN - 1) / FWD_BN;
     {
@@ -136,40 +145,59 @@ __global__ void __launch_bounds__(FWD_THREADS, 2) fa_fwd_kernel(const KArgs a) {
     }
 
     // ---- staging: global -> registers -> LDS ------------------------------------------------
+    // per-thread chunk c = tid + 256 i : row = c / CPR, 16-byte column cc = c % CPR
     u32x4 kreg[CHUNKS], vreg[CHUNKS];
-    auto load_tile = [&](int nb) {
-        const int n0 = nb * FWD_BN;
+    uint32_t k_voff[CHUNKS], v_voff[CHUNKS];
+    int k_lds[CHUNKS], v_lds[CHUNKS];
 #pragma unroll
-        for (int i = 0; i < CHUNKS; ++i) {
-            const int c = tid + i * FWD_THREADS;
-            const int row = c / CPR, cc = c % CPR;
-            const int j = n0 + row;
-            u32x4 z = {0, 0, 0, 0};
-            kreg[i] = z; vreg[i] = z;
-            if (j < seqlen_k) {
-                if (PAGED) {
+    for (int i = 0; i < CHUNKS; ++i) {
+        const int c = tid + i * FWD_THREADS;
+        const int row = c / CPR, cc = c % CPR;
+        k_voff[i] = (uint32_t)(row * p.k_row_stride + cc * 8) * 2u;
+        v_voff[i] = (uint32_t)(row * p.v_row_stride + cc * 8) * 2u;
+        k_lds[i] = swz_row_off<D>(row, cc * 16);
+        v_lds[i] = TILE + vtile_off<D>(row, cc * 8);
+    }
+    const __amdgpu_buffer_rsrc_t k_rsrc = make_rsrc(kp, p.k_row_stride, PAGED ? 0 : seqlen_k, D);
+    const __amdgpu_buffer_rsrc_t v_rsrc = make_rsrc(vp, p.v_row_stride, PAGED ? 0 : seqlen_k, D);
+    const uint32_t k_tile_bytes = (uint32_t)(FWD_BN * p.k_row_stride * 2);
+    const uint32_t v_tile_bytes = (uint32_t)(FWD_BN * p.v_row_stride * 2);
+
+    auto load_tile = [&](int nb) {
+        if (PAGED) {
+            const int n0 = nb * FWD_BN;
+#pragma unroll
+            for (int i = 0; i < CHUNKS; ++i) {
+                const int c = tid + i * FWD_THREADS;
+                const int row = c / CPR, cc = c % CPR;
+                const int j = n0 + row;
+                u32x4 z = {0, 0, 0, 0};
+                kreg[i] = z; vreg[i] = z;
+                if (j < seqlen_k) {
                     const int pos = j + (int)k_row0;
                     const int pg = pos / p.page_block_size;
                     const int pr = pos - pg * p.page_block_size;
                     const int64_t phys = btab[pg];
                     kreg[i] = *reinterpret_cast<const u32x4*>(kp + phys * p.k_batch_stride + (int64_t)pr * p.k_row_stride + cc * 8);
                     vreg[i] = *reinterpret_cast<const u32x4*>(vp + phys * p.v_batch_stride + (int64_t)pr * p.v_row_stride + cc * 8);
-                } else {
-                    kreg[i] = *reinterpret_cast<const u32x4*>(kp + (int64_t)j * p.k_row_stride + cc * 8);
-                    vreg[i] = *reinterpret_cast<const u32x4*>(vp + (int64_t)j * p.v_row_stride + cc * 8);
                 }
             }
+        } else {
+            const uint32_t ks_off = (uint32_t)nb * k_tile_bytes;
+            const uint32_t vs_off = (uint32_t)nb * v_tile_bytes;
+#pragma unroll
+            for (int i = 0; i < CHUNKS; ++i) kreg[i] = buf_load_b128(k_rsrc, k_voff[i], ks_off);
+#pragma unroll
+            for (int i = 0; i < CHUNKS; ++i) vreg[i] = buf_load_b128(v_rsrc, v_voff[i], vs_off);
         }
     };
-    auto store_tile = [&](int stage) {
-        char* ks = smem + stage * STAGE;
-        char* vs = ks + TILE;
+    auto store_tile = [&](auto stage_c) {
+        constexpr int stage = decltype(stage_c)::value;
+        char* base = smem + stage * STAGE;
 #pragma unroll
         for (int i = 0; i < CHUNKS; ++i) {
-            const int c = tid + i * FWD_THREADS;
-            const int row = c / CPR, cc = c % CPR;
-            lds_write_b128(ks + swz_row_off<D>(row, cc * 16), kreg[i]);
-            lds_write_b128(vs + vtile_off<D>(row, cc * 8), vreg[i]);
+            lds_write_b128(base + k_lds[i], kreg[i]);
+            lds_write_b128(base + v_lds[i], vreg[i]);
         }
     };
 
@@ -179,120 +207,136 @@ __global__ void __launch_bounds__(FWD_THREADS, 2) fa_fwd_kernel(const KArgs a) {
     for (int d = 0; d < DBLKS; ++d)
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
-    float m_run = -INFINITY;     // running max, log2 domain (scaled)
+    float m_run = -INFINITY;     // running (deferred) max, log2 domain (scaled)
     float l_run = 0.f;           // this lane's partial row sum (its 32 keys per tile)
 
     // lane-constant LDS read offsets
-    const int k_lane_row = l31;                                     // + 32 kb
-    const int v_lane_off = (g * DBLKS << 8) + (((lane & 15) >> 2) << 6) + (((lane >> 4) & 1) << 5) + ((lane & 3) << 3);
+    int k_rd[KSTEPS];
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) k_rd[ks] = swz_row_off<D>(l31, 32 * ks + 16 * g);
+    const int v_lane_off = TILE + (g * DBLKS << 8) + (((lane & 15) >> 2) << 6) + (((lane >> 4) & 1) << 5) + ((lane & 3) << 3);
+    const float c = BIAS ? 1.0f : a.scale_log2e;
 
-    if (n_min < n_max) {
-        load_tile(n_min);
-        store_tile(0);
-    }
-    __syncthreads();
-
-    for (int nb = n_min; nb < n_max; ++nb) {
-        const int stage = (nb - n_min) & 1;
-        const bool has_next = nb + 1 < n_max;
-        if (has_next) load_tile(nb + 1);
-
+    // one KV tile for this wave; STAGE is a compile-time constant (all LDS offsets immediates)
+    auto compute_tile = [&](auto stage_c, int nb) {
+        constexpr int stage = decltype(stage_c)::value;
         const int n0 = nb * FWD_BN;
-        // wave-uniform: does this wave see anything in this tile?
-        const bool wave_active = (n0 <= w_hi_max) && (n0 + FWD_BN - 1 >= w_lo_min);
-        if (wave_active) {
-            const char* ks_base = smem + stage * STAGE;
-            const char* vs_base = ks_base + TILE;
-            // ---- S^T = K Q^T : sacc[kb][r] = S[my_row][n0 + 32 kb + row(r, g)] ----
-            f32x16 sacc[2];
+        const char* sbase = smem + stage * STAGE;
+        // ---- S^T = K Q^T : sacc[kb][r] = S[my_row][n0 + 32 kb + row(r, g)] ----
+        f32x16 sacc[2];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { sacc[0][r] = 0.f; sacc[1][r] = 0.f; }
+        for (int r = 0; r < 16; ++r) { sacc[0][r] = 0.f; sacc[1][r] = 0.f; }
 #pragma unroll
-            for (int ks = 0; ks < KSTEPS; ++ks) {
-                const u32x4 k0 = lds_read_b128(ks_base + swz_row_off<D>(k_lane_row, 32 * ks + 16 * g));
-                const u32x4 k1 = lds_read_b128(ks_base + swz_row_off<D>(k_lane_row + 32, 32 * ks + 16 * g));
-                sacc[0] = E::mfma(k0, qf[ks], sacc[0]);
-                sacc[1] = E::mfma(k1, qf[ks], sacc[1]);
-            }
-            // ---- bias / softcap (rare variants), then masking on edge tiles ----
-            if (BIAS) {
-                const float cap = p.softcap;
-                const float rcap = cap > 0.f ? 1.0f / cap : 0.f;
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int j = n0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
-                        float s = sacc[kb][r] * p.softmax_scale;
-                        const int dist = my_row + off - j;
-                        s = fmaf(-slope, fabsf((float)dist), s);
-                        if (cap > 0.f) s = cap * fast_tanh(s * rcap);
-                        sacc[kb][r] = s * kLog2e;
-                    }
-            }
-            const bool need_mask = (n0 + FWD_BN - 1 > w_hi_min) || (n0 < w_lo_max);
-            if (need_mask) {
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int j = n0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
-                        if (j < lo || j > hi) sacc[kb][r] = -INFINITY;
-                    }
-            }
-            // ---- online softmax (log2 domain) ----
-            float mx = sacc[0][0];
-#pragma unroll
-            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sacc[0][r]);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[1][r]);
-            mx = fmaxf(mx, shfl_xor32(mx));
-            const float c = BIAS ? 1.0f : a.scale_log2e;
-            const float m_new = fmaxf(m_run, mx * c);
-            const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-            const float alpha = fast_exp2(m_run - m_use);
-            m_run = m_new;
-            float psum = 0.f;
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            const u32x4 k0 = lds_read_b128(sbase + k_rd[ks]);
+            const u32x4 k1 = lds_read_b128(sbase + k_rd[ks] + 32 * D * 2);
+            sacc[0] = E::mfma(k0, qf[ks], sacc[0]);
+            sacc[1] = E::mfma(k1, qf[ks], sacc[1]);
+        }
+        // ---- bias / softcap (rare variants), then masking on edge tiles ----
+        if (BIAS) {
+            const float cap = p.softcap;
+            const float rcap = cap > 0.f ? 1.0f / cap : 0.f;
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float e = fast_exp2(fmaf(sacc[kb][r], c, -m_use));
-                    sacc[kb][r] = e;
-                    psum += e;
+                    const int j = n0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+                    float s = sacc[kb][r] * p.softmax_scale;
+                    const int dist = my_row + off - j;
+                    s = fmaf(-slope, fabsf((float)dist), s);
+                    if (cap > 0.f) s = cap * fast_tanh(s * rcap);
+                    sacc[kb][r] = s * kLog2e;
                 }
-            l_run = fmaf(l_run, alpha, psum);
+        }
+        const bool need_mask = (n0 + FWD_BN - 1 > w_hi_min) || (n0 < w_lo_max);
+        if (need_mask) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int j = n0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+                    if (j < lo || j > hi) sacc[kb][r] = -INFINITY;
+                }
+        }
+        // ---- online softmax (log2 domain) with deferred rescale ----
+        float mx = sacc[0][0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sacc[0][r]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[1][r]);
+        mx = xhalf_max(mx) * c;
+        // keep the old max unless some row of the wave would exceed it by > 2^THR
+        // (NaN-safe: -inf - -inf compares false -> takes the rescale path)
+        if (!__all(mx - m_run <= FWD_RESCALE_THR)) {
+            const float m_new = fmaxf(m_run, mx);
+            const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+            const float alpha = fast_exp2(m_run - m_use);
+            m_run = m_new;
+            l_run *= alpha;
 #pragma unroll
             for (int d = 0; d < DBLKS; ++d)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
+        }
+        const float m_use = (m_run == -INFINITY) ? 0.f : m_run;
+        float psum = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float e = fast_exp2(fmaf(sacc[kb][r], c, -m_use));
+                sacc[kb][r] = e;
+                psum += e;
+            }
+        l_run += psum;
 
-            // ---- O^T += V^T P^T : k-step t covers C-layout regs 8 (t&1) .. +7 of sacc[t>>1] ----
+        // ---- O^T += V^T P^T : k-step t covers C-layout regs 8 (t&1) .. +7 of sacc[t>>1] ----
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int kb = t >> 1, ks2 = t & 1;
-                u32x4 pf;
-                pf[0] = E::pack2(sacc[kb][8 * ks2 + 0], sacc[kb][8 * ks2 + 1]);
-                pf[1] = E::pack2(sacc[kb][8 * ks2 + 2], sacc[kb][8 * ks2 + 3]);
-                pf[2] = E::pack2(sacc[kb][8 * ks2 + 4], sacc[kb][8 * ks2 + 5]);
-                pf[3] = E::pack2(sacc[kb][8 * ks2 + 6], sacc[kb][8 * ks2 + 7]);
+        for (int t = 0; t < 4; ++t) {
+            const int kb = t >> 1, ks2 = t & 1;
+            u32x4 pf;
+            pf[0] = E::pack2(sacc[kb][8 * ks2 + 0], sacc[kb][8 * ks2 + 1]);
+            pf[1] = E::pack2(sacc[kb][8 * ks2 + 2], sacc[kb][8 * ks2 + 3]);
+            pf[2] = E::pack2(sacc[kb][8 * ks2 + 4], sacc[kb][8 * ks2 + 5]);
+            pf[3] = E::pack2(sacc[kb][8 * ks2 + 6], sacc[kb][8 * ks2 + 7]);
 #pragma unroll
-                for (int d = 0; d < DBLKS; ++d) {
-                    // rows kb*32 + 16 ks2 + 8 hf + 4 g + (0..3) -> 4-row block index kb*8 + 4 ks2 + 2 hf + g
-                    const int blk0 = (kb * 8 + 4 * ks2) * DBLKS + d;
-                    const u32x2 v0 = lds_read_tr16(vs_base + v_lane_off + (blk0 << 8));
-                    const u32x2 v1 = lds_read_tr16(vs_base + v_lane_off + ((blk0 + 2 * DBLKS) << 8));
-                    u32x4 vf = {v0[0], v0[1], v1[0], v1[1]};
-                    oacc[d] = E::mfma(vf, pf, oacc[d]);
-                }
+            for (int d = 0; d < DBLKS; ++d) {
+                // rows kb*32 + 16 ks2 + 8 hf + 4 g + (0..3) -> 4-row block index kb*8 + 4 ks2 + 2 hf + g
+                const int blk0 = (kb * 8 + 4 * ks2) * DBLKS + d;
+                const u32x2 v0 = lds_read_tr16(sbase + v_lane_off + (blk0 << 8));
+                const u32x2 v1 = lds_read_tr16(sbase + v_lane_off + ((blk0 + 2 * DBLKS) << 8));
+                u32x4 vf = {v0[0], v0[1], v1[0], v1[1]};
+                oacc[d] = E::mfma(vf, pf, oacc[d]);
             }
         }
-        if (has_next) store_tile(stage ^ 1);
+    };
+
+    auto tile_step = [&](auto stage_c, int nb) {
+        constexpr int stage = decltype(stage_c)::value;
+        const bool has_next = nb + 1 < n_max;
+        if (has_next) load_tile(nb + 1);
+        const int n0 = nb * FWD_BN;
+        // wave-uniform: does this wave see anything in this tile?
+        const bool wave_active = (n0 <= w_hi_max) && (n0 + FWD_BN - 1 >= w_lo_min);
+        if (wave_active) compute_tile(stage_c, nb);
+        if (has_next) store_tile(std::integral_constant<int, stage ^ 1>{});
         __syncthreads();
+    };
+
+    if (n_min < n_max) {
+        load_tile(n_min);
+        store_tile(std::integral_constant<int, 0>{});
+    }
+    __syncthreads();
+
+    for (int nb = n_min; nb < n_max; nb += 2) {
+        tile_step(std::integral_constant<int, 0>{}, nb);
+        if (nb + 1 < n_max) tile_step(std::integral_constant<int, 1>{}, nb + 1);
     }
 
     // ---- epilogue: O / l, LSE ---------------------------------------------------------------
-    const float l_tot = l_run + shfl_xor32(l_run);
+    const float l_tot = xhalf_sum(l_run);
     const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
     if (my_row < seqlen_q) {
         uint16_t* op = reinterpret_cast<uint16_t*>(p.o) + (p.cu_seqlens_q ? 0 : (int64_t)w.b * p.o_batch_stride)
@@ -311,12 +355,13 @@ __global__ void __launch_bounds__(FWD_THREADS, 2) fa_fwd_kernel(const KArgs a) {
             p.lse[(int64_t)w.b * p.lse_batch_stride + (int64_t)w.h * p.lse_head_stride + q_row0 + my_row] = lse;
         }
     }
+    }   // pass
 }
 
 // ---- host launcher ---------------------------------------------------------------------------
 template <typename T, int D>
 static int launch_fwd_td(const KArgs& a, bool paged, hipStream_t stream) {
-    const int grid = work_grid(a.p.batch, a.p.nheads_q, a.p.nheads_k, a.n_qblocks);
+    const int grid = work_grid(a.p.batch, a.p.nheads_q, a.p.nheads_k, a.n_qblocks);   // n_qblocks = grid-level count
     const size_t smem = FwdSmem<D>::TOTAL;
     if (grid == 0) return 0;
 #define FA_LAUNCH(BIAS, PAGED)                                                                  \

@@ -1,0 +1,42 @@
+"""Summarise rocprofv3 rocpd (.db) outputs: per-kernel durations and PMC counter averages."""
+import re
+import sqlite3
+import sys
+
+
+def short(name):
+    name = re.sub(r"\(.*", "", name)
+    return name.replace("void ", "").replace("fa::", "")[:90]
+
+
+def main(paths):
+    for path in paths:
+        c = sqlite3.connect(path)
+        print(f"== {path}")
+        rows = c.execute("select name, count(*), avg(duration), min(duration), max(duration), sum(duration) "
+                         "from kernels group by name order by sum(duration) desc").fetchall()
+        tot = sum(r[5] for r in rows) or 1
+        print(f"{'kernel':90s} {'calls':>5s} {'avg_us':>10s} {'min_us':>10s} {'max_us':>10s} {'pct':>6s}")
+        for name, n, avg, mn, mx, sm in rows[:12]:
+            print(f"{short(name):90s} {n:5d} {avg/1e3:10.1f} {mn/1e3:10.1f} {mx/1e3:10.1f} {100*sm/tot:6.1f}")
+        try:
+            pm = c.execute("select name, counter_name, avg(counter_value), count(*) from pmc_events "
+                           "group by name, counter_name order by name, counter_name").fetchall()
+        except sqlite3.Error:
+            pm = []
+        cur = None
+        for name, cn, val, n in pm:
+            if "fa_" not in name:
+                continue
+            if name != cur:
+                cur = name
+                print(f"-- {short(name)}  (avg per dispatch over {n} dispatches)")
+            print(f"   {cn:32s} {val:18.1f}")
+        info = c.execute("select distinct name, vgpr_count, accum_vgpr_count, sgpr_count, lds_size, scratch_size, "
+                         "grid_x, workgroup_x from kernels where name like '%fa_%'").fetchall()
+        for r in info:
+            print(f"   [{short(r[0])}] vgpr={r[1]} agpr={r[2]} sgpr={r[3]} lds={r[4]} scratch={r[5]} grid={r[6]} wg={r[7]}")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])
