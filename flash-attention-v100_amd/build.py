@@ -34,8 +34,12 @@ def _digest(paths):
     return h.hexdigest()
 
 
-def build(force=False, verbose=False):
-    """Compile every HIP source for gfx950 and link libfa_mi355.so. Returns the path."""
+def build(force=False, verbose=False, defines=(), out=None):
+    """Compile every HIP source for gfx950 and link libfa_mi355.so. Returns the path.
+    `defines` / `out` build an experiment variant next to the product library (A/B runs
+    select it with FA_MI355_LIB=<path>)."""
+    if defines or out:
+        return _build_variant(list(defines), out, verbose)
     bdir = os.path.join(CSRC, "build")
     os.makedirs(bdir, exist_ok=True)
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
@@ -68,5 +72,32 @@ def build(force=False, verbose=False):
     return LIB
 
 
+def _build_variant(defines, out, verbose):
+    tag = hashlib.sha256(" ".join(defines).encode()).hexdigest()[:8]
+    bdir = os.path.join(CSRC, "build", "var_" + tag)
+    os.makedirs(bdir, exist_ok=True)
+    out = out or os.path.join(OUT_DIR, f"libfa_mi355_{tag}.so")
+    hipcc = _hipcc()
+    procs, objs = [], []
+    for src in SOURCES:
+        obj = os.path.join(bdir, src.replace(".hip", ".o"))
+        objs.append(obj)
+        cmd = [hipcc] + FLAGS + ["-D" + d for d in defines] + ["-c", os.path.join(CSRC, src), "-o", obj]
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for src, pr in procs:
+        o, _ = pr.communicate()
+        if pr.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {src}:\n{o.decode(errors='replace')}")
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    if r.returncode != 0:
+        raise RuntimeError("link failed:\n" + r.stdout.decode(errors="replace"))
+    return out
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 2 and sys.argv[1] == "--variant":
+        # python build.py --variant out.so DEF1 DEF2=3 ...
+        print(build(out=os.path.abspath(sys.argv[2]), defines=sys.argv[3:]))
+        sys.exit(0)
     print(build(force="--force" in sys.argv, verbose=True))

@@ -266,6 +266,21 @@ __global__ void __launch_bounds__(BWD_THREADS, 1) fa_bwd_dkdv_kernel(const KArgs
             f32x16 s_acc, dp_acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { s_acc[r] = 0.f; dp_acc[r] = 0.f; }
+#ifdef FA_PREFETCH
+            // one wave per SIMD: nothing else hides LDS latency, so fetch ALL row fragments of
+            // the sub-tile first and let the MFMAs stream behind counted lgkmcnt waits
+            u32x4 qa[KSTEPS], da[KSTEPS];
+#pragma unroll
+            for (int ks = 0; ks < KSTEPS; ++ks) qa[ks] = lds_read_b128(qs + a_rd[ks] + sub * 32 * D * 2);
+#pragma unroll
+            for (int ks = 0; ks < KSTEPS; ++ks) da[ks] = lds_read_b128(dos + a_rd[ks] + sub * 32 * D * 2);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * KSTEPS, 0);
+#pragma unroll
+            for (int ks = 0; ks < KSTEPS; ++ks) s_acc = E::mfma(qa[ks], kf[ks], s_acc);
+#pragma unroll
+            for (int ks = 0; ks < KSTEPS; ++ks) dp_acc = E::mfma(da[ks], vf[ks], dp_acc);
+            __builtin_amdgcn_sched_group_barrier(0x008, 2 * KSTEPS, 0);
+#else
 #pragma unroll
             for (int ks = 0; ks < KSTEPS; ++ks) {
                 const u32x4 qa = lds_read_b128(qs + a_rd[ks] + sub * 32 * D * 2);
@@ -276,6 +291,7 @@ __global__ void __launch_bounds__(BWD_THREADS, 1) fa_bwd_dkdv_kernel(const KArgs
                 const u32x4 da = lds_read_b128(dos + a_rd[ks] + sub * 32 * D * 2);
                 dp_acc = E::mfma(da, vf[ks], dp_acc);
             }
+#endif
             // row statistics for q = q0 + 8 i + 4 g + (0..3)
             f32x4 lse2[4], dsum[4];
 #pragma unroll
@@ -325,6 +341,25 @@ __global__ void __launch_bounds__(BWD_THREADS, 1) fa_bwd_dkdv_kernel(const KArgs
                 }
                 // rows sub*32 + 16 t + 8 hf + 4 g + rr ; cols 32 d + 16 ((lane>>4)&1) + 4 (lane&3)
                 const int row_a = sub * 32 + 16 * t + 4 * g + rr;
+#ifdef FA_PREFETCH
+                u32x4 af[DBLKS], bfr[DBLKS];
+#pragma unroll
+                for (int d = 0; d < DBLKS; ++d) {
+                    const u32x2 a0 = lds_read_tr16(dos + swzt_row_off<D>(row_a, d * 64 + cb));
+                    const u32x2 a1 = lds_read_tr16(dos + swzt_row_off<D>(row_a + 8, d * 64 + cb));
+                    const u32x2 b0 = lds_read_tr16(qs + swzt_row_off<D>(row_a, d * 64 + cb));
+                    const u32x2 b1 = lds_read_tr16(qs + swzt_row_off<D>(row_a + 8, d * 64 + cb));
+                    af[d] = u32x4{a0[0], a0[1], a1[0], a1[1]};
+                    bfr[d] = u32x4{b0[0], b0[1], b1[0], b1[1]};
+                }
+                __builtin_amdgcn_sched_group_barrier(0x100, 4 * DBLKS, 0);
+#pragma unroll
+                for (int d = 0; d < DBLKS; ++d) {
+                    dv_acc[d] = E::mfma(af[d], pf, dv_acc[d]);
+                    dk_acc[d] = E::mfma(bfr[d], dsf, dk_acc[d]);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 2 * DBLKS, 0);
+#else
 #pragma unroll
                 for (int d = 0; d < DBLKS; ++d) {
                     const u32x2 a0 = lds_read_tr16(dos + swzt_row_off<D>(row_a, d * 64 + cb));
@@ -336,6 +371,7 @@ __global__ void __launch_bounds__(BWD_THREADS, 1) fa_bwd_dkdv_kernel(const KArgs
                     u32x4 bfr = {b0[0], b0[1], b1[0], b1[1]};
                     dk_acc[d] = E::mfma(bfr, dsf, dk_acc[d]);
                 }
+#endif
             }
         }
     };

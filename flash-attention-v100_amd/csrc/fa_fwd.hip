@@ -156,7 +156,7 @@ __global__ void __launch_bounds__(FWD_THREADS, 2) fa_fwd_kernel(const KArgs a) {
         k_voff[i] = (uint32_t)(row * p.k_row_stride + cc * 8) * 2u;
         v_voff[i] = (uint32_t)(row * p.v_row_stride + cc * 8) * 2u;
         k_lds[i] = swz_row_off<D>(row, cc * 16);
-        v_lds[i] = TILE + vtile_off<D>(row, cc * 8);
+        v_lds[i] = TILE + swzt_row_off<D>(row, cc * 16);
     }
     const __amdgpu_buffer_rsrc_t k_rsrc = make_rsrc(kp, p.k_row_stride, PAGED ? 0 : seqlen_k, D);
     const __amdgpu_buffer_rsrc_t v_rsrc = make_rsrc(vp, p.v_row_stride, PAGED ? 0 : seqlen_k, D);
@@ -214,7 +214,8 @@ __global__ void __launch_bounds__(FWD_THREADS, 2) fa_fwd_kernel(const KArgs a) {
     int k_rd[KSTEPS];
 #pragma unroll
     for (int ks = 0; ks < KSTEPS; ++ks) k_rd[ks] = swz_row_off<D>(l31, 32 * ks + 16 * g);
-    const int v_lane_off = TILE + (g * DBLKS << 8) + (((lane & 15) >> 2) << 6) + (((lane >> 4) & 1) << 5) + ((lane & 3) << 3);
+    const int v_rr = (lane & 15) >> 2;                                  // row within a 4-row transpose group
+    const int v_cb = (((lane >> 4) & 1) << 5) + ((lane & 3) << 3);       // byte column within a 64-byte d-block
     const float c = BIAS ? 1.0f : a.scale_log2e;
 
     // one KV tile for this wave; STAGE is a compile-time constant (all LDS offsets immediates)
@@ -226,6 +227,9 @@ __global__ void __launch_bounds__(FWD_THREADS, 2) fa_fwd_kernel(const KArgs a) {
         f32x16 sacc[2];
 #pragma unroll
         for (int r = 0; r < 16; ++r) { sacc[0][r] = 0.f; sacc[1][r] = 0.f; }
+#ifndef FA_NO_SETPRIO
+        __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks) {
             const u32x4 k0 = lds_read_b128(sbase + k_rd[ks]);
@@ -233,6 +237,9 @@ __global__ void __launch_bounds__(FWD_THREADS, 2) fa_fwd_kernel(const KArgs a) {
             sacc[0] = E::mfma(k0, qf[ks], sacc[0]);
             sacc[1] = E::mfma(k1, qf[ks], sacc[1]);
         }
+#ifndef FA_NO_SETPRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         // ---- bias / softcap (rare variants), then masking on edge tiles ----
         if (BIAS) {
             const float cap = p.softcap;
@@ -302,10 +309,10 @@ __global__ void __launch_bounds__(FWD_THREADS, 2) fa_fwd_kernel(const KArgs a) {
             pf[3] = E::pack2(sacc[kb][8 * ks2 + 6], sacc[kb][8 * ks2 + 7]);
 #pragma unroll
             for (int d = 0; d < DBLKS; ++d) {
-                // rows kb*32 + 16 ks2 + 8 hf + 4 g + (0..3) -> 4-row block index kb*8 + 4 ks2 + 2 hf + g
-                const int blk0 = (kb * 8 + 4 * ks2) * DBLKS + d;
-                const u32x2 v0 = lds_read_tr16(sbase + v_lane_off + (blk0 << 8));
-                const u32x2 v1 = lds_read_tr16(sbase + v_lane_off + ((blk0 + 2 * DBLKS) << 8));
+                // rows kb*32 + 16 ks2 + 8 hf + 4 g + (0..3), 64-byte column block d
+                const int row_a = kb * 32 + 16 * ks2 + 4 * g + v_rr;
+                const u32x2 v0 = lds_read_tr16(sbase + TILE + swzt_row_off<D>(row_a, d * 64 + v_cb));
+                const u32x2 v1 = lds_read_tr16(sbase + TILE + swzt_row_off<D>(row_a + 8, d * 64 + v_cb));
                 u32x4 vf = {v0[0], v0[1], v1[0], v1[1]};
                 oacc[d] = E::mfma(vf, pf, oacc[d]);
             }

@@ -6,7 +6,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfa_mi355.so")
+LIB_PATH = os.environ.get("FA_MI355_LIB") or os.path.join(_HERE, "libfa_mi355.so")   # env: A/B experiment builds
 
 FA_FP16, FA_BF16, FA_FP8_E4M3 = 0, 1, 2
 FA_ABI_VERSION = 1
