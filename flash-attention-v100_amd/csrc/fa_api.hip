@@ -88,6 +88,13 @@ static fa::KArgs make_args(const fa_params& p, int block_m) {
     a.n_qblocks = a.pair_qblocks ? (a.n_qblocks_total + 1) / 2 : a.n_qblocks_total;
     a.has_bias = (p.alibi_slopes != nullptr) || (p.softcap > 0.f);
     a.scale_log2e = p.softmax_scale * fa::kLog2e;
+    a.rp_dropout = 1.0f;
+    if (p.p_dropout > 0.f) {
+        const float keep = 1.0f - p.p_dropout;
+        const float t = keep * 4294967295.0f;            // fp32 on purpose (== 2^32 * keep)
+        a.drop_thr = t >= 4294967295.0f ? 0xffffffffu : (uint32_t)t;
+        a.rp_dropout = 1.0f / keep;
+    }
     return a;
 }
 
@@ -115,7 +122,6 @@ int fa_fwd(const fa_params* pp, void* stream) {
     if (rc) return rc;
     FA_CHECK(p.kv_dtype == p.dtype, "k/v must have the same dtype as q");
     FA_CHECK(p.seqlen_q >= 0 && p.seqlen_k >= 0, "sequence lengths must be non-negative");
-    if (p.p_dropout > 0.f) return fail(FA_ERR_UNSUPPORTED, "dropout is not implemented in this build yet");
     if (p.seqlen_q == 0) return FA_OK;
     normalize(p, false);
     fa::KArgs a = make_args(p, 128);
@@ -135,7 +141,7 @@ int fa_varlen_fwd(const fa_params* pp, void* stream) {
         FA_CHECK(p.page_block_size > 0, "page_block_size must be positive");
         FA_CHECK(p.page_block_size % 64 == 0, "Paged KV cache block size must be divisible by 64");
     }
-    if (p.p_dropout > 0.f) return fail(FA_ERR_UNSUPPORTED, "dropout is not implemented in this build yet");
+    if (p.p_dropout > 0.f && p.block_table) return fail(FA_ERR_UNSUPPORTED, "dropout with paged K/V is not supported");
     if (p.total_q == 0 || p.seqlen_q == 0) return FA_OK;
     normalize(p, false);
     fa::KArgs a = make_args(p, 128);
@@ -203,7 +209,6 @@ int fa_bwd(const fa_params* pp, void* stream) {
     if (rc) return rc;
     FA_CHECK(p.dout && p.dq && p.dk && p.dv && p.softmax_d, "dout, dq, dk, dv, softmax_d must not be NULL");
     FA_CHECK(p.kv_dtype == p.dtype, "k/v must have the same dtype as q");
-    if (p.p_dropout > 0.f) return fail(FA_ERR_UNSUPPORTED, "dropout is not implemented in this build yet");
     if (p.seqlen_q == 0 && p.seqlen_k == 0) return FA_OK;
     normalize(p, false);
     fa::KArgs a = make_args(p, 128);
@@ -222,7 +227,6 @@ int fa_varlen_bwd(const fa_params* pp, void* stream) {
     FA_CHECK(p.dout && p.dq && p.dk && p.dv && p.softmax_d, "dout, dq, dk, dv, softmax_d must not be NULL");
     FA_CHECK(p.cu_seqlens_q && p.cu_seqlens_k, "cu_seqlens_q and cu_seqlens_k are required");
     FA_CHECK(p.kv_dtype == p.dtype, "k/v must have the same dtype as q");
-    if (p.p_dropout > 0.f) return fail(FA_ERR_UNSUPPORTED, "dropout is not implemented in this build yet");
     if (p.total_q == 0) return FA_OK;
     normalize(p, false);
     fa::KArgs a = make_args(p, 128);

@@ -87,7 +87,7 @@ template <int D> struct DkvSmem {
     static constexpr int TOTAL = 2 * STAGE;
 };
 
-template <typename T, int D, bool BIAS>
+template <typename T, int D, bool BIAS, bool DROPOUT>
 __global__ void __launch_bounds__(BWD_THREADS, 1) fa_bwd_dkdv_kernel(const KArgs a) {
     using E = Elem<T>;
     constexpr int KSTEPS = D / 16;
@@ -120,6 +120,12 @@ __global__ void __launch_bounds__(BWD_THREADS, 1) fa_bwd_dkdv_kernel(const KArgs
     const int wl = p.window_left;
     const int wr = p.is_causal ? 0 : p.window_right;
     const float c = a.scale_log2e;
+    DropCtx dc = {0, 0, 0, 0};
+    if (DROPOUT) {
+        dc.k0 = (uint32_t)p.philox_seed; dc.k1 = (uint32_t)(p.philox_seed >> 32);
+        dc.thr = a.drop_thr; dc.offset = p.philox_offset;
+    }
+    const uint64_t drop_n_glob = (uint64_t)p.seqlen_k;
 
     // loop-invariant staging geometry
     uint32_t q_voff[CHUNKS], do_voff[CHUNKS];
@@ -303,9 +309,16 @@ __global__ void __launch_bounds__(BWD_THREADS, 1) fa_bwd_dkdv_kernel(const KArgs
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float l2 = lse2[r >> 2][r & 3];
+                const int qi = q0 + (r & 3) + 8 * (r >> 2) + 4 * g;
+                float dpe = dp_acc[r];
+                bool keep = true;
+                if (DROPOUT) {
+                    // dS = P (keep rp dP - D); dV accumulates keep P (rp applied in the epilogue)
+                    keep = dropout_keep1(dc, (uint64_t)(sg.q_row0 + qi) * drop_n_glob + (uint64_t)my_key);
+                    dpe = keep ? dpe * a.rp_dropout : 0.f;
+                }
                 float pr, dsr;
                 if (BIAS) {
-                    const int qi = q0 + (r & 3) + 8 * (r >> 2) + 4 * g;
                     float s = s_acc[r] * p.softmax_scale;
                     s = fmaf(-slope, fabsf((float)(qi + off - my_key)), s);
                     float chain = 1.f;
@@ -315,12 +328,13 @@ __global__ void __launch_bounds__(BWD_THREADS, 1) fa_bwd_dkdv_kernel(const KArgs
                         chain = 1.f - t * t;
                     }
                     pr = fast_exp2(fmaf(s, kLog2e, -l2));
-                    dsr = pr * (dp_acc[r] - dsum[r >> 2][r & 3]) * chain;
+                    dsr = pr * (dpe - dsum[r >> 2][r & 3]) * chain;
                 } else {
                     pr = fast_exp2(fmaf(s_acc[r], c, -l2));
-                    dsr = pr * (dp_acc[r] - dsum[r >> 2][r & 3]);
+                    dsr = pr * (dpe - dsum[r >> 2][r & 3]);
                 }
-                pv[r] = pr; dsv[r] = dsr;
+                pv[r] = (DROPOUT && !keep) ? 0.f : pr;
+                dsv[r] = dsr;
             }
             const bool need_mask = key_tail || (q0 < w_qlo_max) || (q0 + 31 > w_qhi_min);
             if (need_mask) {
@@ -405,8 +419,9 @@ __global__ void __launch_bounds__(BWD_THREADS, 1) fa_bwd_dkdv_kernel(const KArgs
                 u32x2 k2, v2;
                 k2[0] = E::pack2(dk_acc[d][4 * rq + 0] * sc, dk_acc[d][4 * rq + 1] * sc);
                 k2[1] = E::pack2(dk_acc[d][4 * rq + 2] * sc, dk_acc[d][4 * rq + 3] * sc);
-                v2[0] = E::pack2(dv_acc[d][4 * rq + 0], dv_acc[d][4 * rq + 1]);
-                v2[1] = E::pack2(dv_acc[d][4 * rq + 2], dv_acc[d][4 * rq + 3]);
+                const float rp = DROPOUT ? a.rp_dropout : 1.0f;
+                v2[0] = E::pack2(dv_acc[d][4 * rq + 0] * rp, dv_acc[d][4 * rq + 1] * rp);
+                v2[1] = E::pack2(dv_acc[d][4 * rq + 2] * rp, dv_acc[d][4 * rq + 3] * rp);
                 *reinterpret_cast<u32x2*>(dkp + d * 32 + 8 * rq + 4 * g) = k2;
                 *reinterpret_cast<u32x2*>(dvp + d * 32 + 8 * rq + 4 * g) = v2;
             }
@@ -426,7 +441,7 @@ template <int D> struct DqSmem {
     static constexpr int TOTAL = 2 * STAGE;
 };
 
-template <typename T, int D, bool BIAS, int OCC>
+template <typename T, int D, bool BIAS, int OCC, bool DROPOUT>
 __global__ void __launch_bounds__(BWD_THREADS, OCC) fa_bwd_dq_kernel(const KArgs a) {
     using E = Elem<T>;
     constexpr int KSTEPS = D / 16;
@@ -477,6 +492,12 @@ __global__ void __launch_bounds__(BWD_THREADS, OCC) fa_bwd_dq_kernel(const KArgs
     const int cb = (((lane >> 4) & 1) << 5) + ((lane & 3) << 3);
     float slope = 0.f;
     if (BIAS && p.alibi_slopes) slope = p.alibi_slopes[w.b * p.alibi_batch_stride + w.h];
+    DropCtx dc = {0, 0, 0, 0};
+    if (DROPOUT) {
+        dc.k0 = (uint32_t)p.philox_seed; dc.k1 = (uint32_t)(p.philox_seed >> 32);
+        dc.thr = a.drop_thr; dc.offset = p.philox_offset;
+    }
+    const uint64_t drop_n_glob = (uint64_t)p.seqlen_k;
 
     const int n_pass = (a.pair_qblocks && (a.n_qblocks_total - 1 - w.qb) != w.qb) ? 2 : 1;
     for (int pass = 0; pass < n_pass; ++pass) {
@@ -580,8 +601,20 @@ __global__ void __launch_bounds__(BWD_THREADS, OCC) fa_bwd_dq_kernel(const KArgs
                 dp_acc = E::mfma(va, dof[ks], dp_acc);
             }
             float dsv[16];
+            uint32_t kbits = 0xffffu;
+            if (DROPOUT) {
+                kbits = 0;
+                const uint64_t row_g = (uint64_t)(sg.q_row0 + my_row);
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    const int j4 = n0 + kb * 32 + 8 * rg + 4 * g;
+                    kbits |= dropout_keep4(dc, row_g * drop_n_glob + (uint64_t)j4) << (4 * rg);
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
+                float dpe = dp_acc[r];
+                if (DROPOUT) dpe = ((kbits >> r) & 1u) ? dpe * a.rp_dropout : 0.f;   // dS = P (keep rp dP - D)
                 float pr, dsr;
                 if (BIAS) {
                     const int j = n0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
@@ -594,10 +627,10 @@ __global__ void __launch_bounds__(BWD_THREADS, OCC) fa_bwd_dq_kernel(const KArgs
                         chain = 1.f - t * t;
                     }
                     pr = fast_exp2(fmaf(s, kLog2e, -lse2));
-                    dsr = pr * (dp_acc[r] - dsum) * chain;
+                    dsr = pr * (dpe - dsum) * chain;
                 } else {
                     pr = fast_exp2(fmaf(s_acc[r], c, -lse2));
-                    dsr = pr * (dp_acc[r] - dsum);
+                    dsr = pr * (dpe - dsum);
                 }
                 dsv[r] = dsr;
             }
@@ -679,39 +712,39 @@ static int launch_bwd_td(const KArgs& a, hipStream_t stream) {
         }
     }
     // 2. dK/dV
+    const bool drop = p.p_dropout > 0.f;
     if (g_bwd_phase_mask & 2) {
         const int n_kblocks = (p.seqlen_k + DKV_BN - 1) / DKV_BN;
         const int n_kb_grid = (a.pair_qblocks && n_kblocks >= 2) ? (n_kblocks + 1) / 2 : n_kblocks;
         const int units = p.batch * p.nheads_k;
         const int grid = 8 * ((units + 7) / 8) * n_kb_grid;
         const size_t smem = DkvSmem<D>::TOTAL;
+#define FA_LAUNCH_DKV(BIAS, DROP)                                                                                 \
+        do {                                                                                                      \
+            auto kern = fa_bwd_dkdv_kernel<T, D, BIAS, DROP>;                                                     \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(BWD_THREADS), smem, stream, a);                             \
+        } while (0)
         if (grid > 0) {
-            if (a.has_bias) {
-                auto kern = fa_bwd_dkdv_kernel<T, D, true>;
-                hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-                hipLaunchKernelGGL(kern, dim3(grid), dim3(BWD_THREADS), smem, stream, a);
-            } else {
-                auto kern = fa_bwd_dkdv_kernel<T, D, false>;
-                hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-                hipLaunchKernelGGL(kern, dim3(grid), dim3(BWD_THREADS), smem, stream, a);
-            }
+            if (drop) { if (a.has_bias) FA_LAUNCH_DKV(true, true); else FA_LAUNCH_DKV(false, true); }
+            else      { if (a.has_bias) FA_LAUNCH_DKV(true, false); else FA_LAUNCH_DKV(false, false); }
         }
+#undef FA_LAUNCH_DKV
     }
     // 3. dQ  (D = 128 needs > 256 registers at two waves per SIMD: development switch FA_DQ_OCC)
     if (g_bwd_phase_mask & 4) {
         const int grid = work_grid(p.batch, p.nheads_q, p.nheads_k, a.n_qblocks);
         const size_t smem = DqSmem<D>::TOTAL;
-        static const int occ_env = getenv("FA_DQ_OCC") ? atoi(getenv("FA_DQ_OCC")) : 0;
-        const int occ = occ_env ? occ_env : (D >= 128 ? 1 : 2);
-#define FA_LAUNCH_DQ(BIAS, OCC)                                                                                   \
+        constexpr int OCC = (D >= 128) ? 1 : 2;
+#define FA_LAUNCH_DQ(BIAS, DROP)                                                                                  \
         do {                                                                                                      \
-            auto kern = fa_bwd_dq_kernel<T, D, BIAS, OCC>;                                                        \
-            hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
+            auto kern = fa_bwd_dq_kernel<T, D, BIAS, OCC, DROP>;                                                  \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
             hipLaunchKernelGGL(kern, dim3(grid), dim3(BWD_THREADS), smem, stream, a);                             \
         } while (0)
         if (grid > 0) {
-            if (a.has_bias) { if (occ == 1) FA_LAUNCH_DQ(true, 1); else FA_LAUNCH_DQ(true, 2); }
-            else            { if (occ == 1) FA_LAUNCH_DQ(false, 1); else FA_LAUNCH_DQ(false, 2); }
+            if (drop) { if (a.has_bias) FA_LAUNCH_DQ(true, true); else FA_LAUNCH_DQ(false, true); }
+            else      { if (a.has_bias) FA_LAUNCH_DQ(true, false); else FA_LAUNCH_DQ(false, false); }
         }
 #undef FA_LAUNCH_DQ
     }

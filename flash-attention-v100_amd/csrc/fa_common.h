@@ -161,6 +161,56 @@ __device__ __forceinline__ u32x4 buf_load_b128(__amdgpu_buffer_rsrc_t r, uint32_
     return __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
 }
 
+// ---- dropout: Philox-4x32-10, the reference's stream (include/philox.h:13-73) -----------------
+// element (i_glob, j): flat = i_glob * N_glob + j; counter = offset + (flat >> 2); word = flat & 3;
+// kept iff word <= thr  (include/softmax.h:97-114).
+__device__ __forceinline__ void philox_round(uint32_t& c0, uint32_t& c1, uint32_t& c2, uint32_t& c3,
+                                             uint32_t k0, uint32_t k1) {
+    const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+    c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+}
+__device__ __forceinline__ void philox4x32_10(uint64_t ctr, uint32_t k0, uint32_t k1, uint32_t (&out)[4]) {
+    uint32_t c0 = (uint32_t)ctr, c1 = (uint32_t)(ctr >> 32), c2 = 0, c3 = 0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        philox_round(c0, c1, c2, c3, k0, k1);
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    philox_round(c0, c1, c2, c3, k0, k1);
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+struct DropCtx { uint32_t k0, k1, thr; uint64_t offset; };
+// keep-mask (bit e = element flat0 + e kept) of 4 consecutive flat indices
+__device__ __forceinline__ uint32_t dropout_keep4(const DropCtx& dc, uint64_t flat0) {
+    uint32_t r[4];
+    philox4x32_10(dc.offset + (flat0 >> 2), dc.k0, dc.k1, r);
+    const int m = (int)(flat0 & 3);
+    uint32_t bits = 0;
+    if (m == 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bits |= (r[e] <= dc.thr ? 1u : 0u) << e;
+    } else {
+        uint32_t r2[4];
+        philox4x32_10(dc.offset + (flat0 >> 2) + 1, dc.k0, dc.k1, r2);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int w = m + e;
+            const uint32_t v = w < 4 ? (w == 1 ? r[1] : (w == 2 ? r[2] : r[3])) : (w == 4 ? r2[0] : (w == 5 ? r2[1] : r2[2]));
+            bits |= (v <= dc.thr ? 1u : 0u) << e;
+        }
+    }
+    return bits;
+}
+__device__ __forceinline__ bool dropout_keep1(const DropCtx& dc, uint64_t flat) {
+    uint32_t r[4];
+    philox4x32_10(dc.offset + (flat >> 2), dc.k0, dc.k1, r);
+    const int m = (int)(flat & 3);
+    const uint32_t v = m == 0 ? r[0] : (m == 1 ? r[1] : (m == 2 ? r[2] : r[3]));
+    return v <= dc.thr;
+}
+
 // Work decomposition shared by forward-like kernels: 1-D grid, block id -> XCD-aware
 // (kv-head unit, q-head in group, q-block heavy-first).  Blocks observed to land on XCD
 // id % 8 (speed only, never correctness): all q-blocks of the q-heads sharing a kv-head
@@ -199,6 +249,8 @@ struct KArgs {
     int pair_qblocks;      // causal load balance: a workgroup owns q-blocks (i, total-1-i)
     int has_bias;          // alibi or softcap
     float scale_log2e;
+    uint32_t drop_thr;     // uint32((1 - p) * 4294967295.0f), fp32 arithmetic (include/softmax.h:51)
+    float rp_dropout;      // 1 / (1 - p)
     const int32_t* seqlens_k;      // per-batch key count (seqused_k or cache_seqlens), or NULL
     int seqlen_k_add;              // added to seqlens_k[b] (kvcache: T_new)
     const int32_t* kv_batch_idx;   // cache_batch_idx or NULL

@@ -33,7 +33,7 @@ template <int D> struct FwdSmem {
     static constexpr int TOTAL = 2 * STAGE;            // double buffered
 };
 
-template <typename T, int D, bool BIAS, bool PAGED>
+template <typename T, int D, bool BIAS, bool PAGED, bool DROPOUT>
 __global__ void __launch_bounds__(FWD_THREADS, 2) fa_fwd_kernel(const KArgs a) {
     using E = Elem<T>;
     constexpr int KSTEPS = D / 16;
@@ -77,6 +77,12 @@ __global__ void __launch_bounds__(FWD_THREADS, 2) fa_fwd_kernel(const KArgs a) {
     const int off = seqlen_k - seqlen_q;               // bottom-right alignment
     const int wl = p.window_left;
     const int wr = p.is_causal ? 0 : p.window_right;   // causal == window_right 0 (include/mat_mul.h:92,103)
+    DropCtx dc = {0, 0, 0, 0};
+    if (DROPOUT) {
+        dc.k0 = (uint32_t)p.philox_seed; dc.k1 = (uint32_t)(p.philox_seed >> 32);
+        dc.thr = a.drop_thr; dc.offset = p.philox_offset;
+    }
+    const uint64_t drop_n_glob = (uint64_t)p.seqlen_k;        // dense: S_k; varlen: max_seqlen_k
     // Causal load balance: with a.pair_qblocks the workgroup owns q-block qb (heavy) and then its
     // mirror n_qblocks-1-qb (light), so every workgroup carries the same number of KV tiles.
     const int n_pass = (a.pair_qblocks && (a.n_qblocks_total - 1 - w.qb) != w.qb) ? 2 : 1;
@@ -296,7 +302,30 @@ __global__ void __launch_bounds__(FWD_THREADS, 2) fa_fwd_kernel(const KArgs a) {
                 sacc[kb][r] = e;
                 psum += e;
             }
-        l_run += psum;
+        l_run += psum;                                      // PRE-dropout sum (include/softmax.h:187)
+        if (DROPOUT) {
+            const uint64_t row_g = (uint64_t)(q_row0 + my_row);
+            uint16_t* dm = nullptr;
+            if (p.dmask && my_row < seqlen_q) {
+                dm = reinterpret_cast<uint16_t*>(p.dmask) +
+                     (p.cu_seqlens_q ? ((int64_t)(q_row0 + my_row) * p.nheads_q + w.h) * (int64_t)p.seqlen_k
+                                     : (((int64_t)w.b * p.nheads_q + w.h) * seqlen_q + my_row) * (int64_t)seqlen_k);
+            }
+            const uint16_t one = std::is_same<T, bf16_tag>::value ? 0x3F80 : 0x3C00;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    const int j4 = n0 + kb * 32 + 8 * rg + 4 * g;
+                    const uint32_t bits = dropout_keep4(dc, row_g * drop_n_glob + (uint64_t)j4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const bool keep = (bits >> e) & 1u;
+                        if (!keep) sacc[kb][4 * rg + e] = 0.f;
+                        if (dm && j4 + e < seqlen_k) dm[j4 + e] = keep ? one : (uint16_t)(one | 0x8000);
+                    }
+                }
+        }
 
         // ---- O^T += V^T P^T : k-step t covers C-layout regs 8 (t&1) .. +7 of sacc[t>>1] ----
 #pragma unroll
@@ -344,7 +373,7 @@ __global__ void __launch_bounds__(FWD_THREADS, 2) fa_fwd_kernel(const KArgs a) {
 
     // ---- epilogue: O / l, LSE ---------------------------------------------------------------
     const float l_tot = xhalf_sum(l_run);
-    const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+    const float inv = l_tot > 0.f ? (DROPOUT ? a.rp_dropout : 1.0f) / l_tot : 0.f;
     if (my_row < seqlen_q) {
         uint16_t* op = reinterpret_cast<uint16_t*>(p.o) + (p.cu_seqlens_q ? 0 : (int64_t)w.b * p.o_batch_stride)
                        + (q_row0 + my_row) * p.o_row_stride + (int64_t)w.h * p.o_head_stride;
@@ -371,15 +400,17 @@ static int launch_fwd_td(const KArgs& a, bool paged, hipStream_t stream) {
     const int grid = work_grid(a.p.batch, a.p.nheads_q, a.p.nheads_k, a.n_qblocks);   // n_qblocks = grid-level count
     const size_t smem = FwdSmem<D>::TOTAL;
     if (grid == 0) return 0;
-#define FA_LAUNCH(BIAS, PAGED)                                                                  \
+#define FA_LAUNCH(BIAS, PAGED, DROP)                                                            \
     do {                                                                                        \
-        auto kern = fa_fwd_kernel<T, D, BIAS, PAGED>;                                           \
+        auto kern = fa_fwd_kernel<T, D, BIAS, PAGED, DROP>;                                     \
         hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                \
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);             \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(FWD_THREADS), smem, stream, a);               \
     } while (0)
-    if (a.has_bias) { if (paged) FA_LAUNCH(true, true); else FA_LAUNCH(true, false); }
-    else            { if (paged) FA_LAUNCH(false, true); else FA_LAUNCH(false, false); }
+    const bool drop = a.p.p_dropout > 0.f;
+    if (drop) { if (a.has_bias) FA_LAUNCH(true, false, true); else FA_LAUNCH(false, false, true); }
+    else if (a.has_bias) { if (paged) FA_LAUNCH(true, true, false); else FA_LAUNCH(true, false, false); }
+    else            { if (paged) FA_LAUNCH(false, true, false); else FA_LAUNCH(false, false, false); }
 #undef FA_LAUNCH
     return 0;
 }

@@ -151,7 +151,7 @@ class FlashAttnFunc(torch.autograd.Function):
         rng = _philox(p, dropout_p, B, H_Q, q.device)
         dmask = torch.empty((0,), dtype=q.dtype, device=q.device)
         if return_softmax and dropout_p > 0.0:
-            dmask = torch.empty((B, H_Q, M, N), dtype=q.dtype, device=q.device)
+            dmask = torch.zeros((B, H_Q, M, N), dtype=q.dtype, device=q.device)
             p.dmask = _ptr(dmask)
         with torch.cuda.device(q.device):
             _lib.call("fa_fwd", p, _stream(q.device))
@@ -267,7 +267,7 @@ class FlashAttnVarlenFunc(torch.autograd.Function):
         rng = _philox(p, dropout_p, B, H_Q, q.device)
         dmask = torch.empty((0,), dtype=q.dtype, device=q.device)
         if return_attn_probs and dropout_p > 0.0:
-            dmask = torch.empty((T_Q, H_Q, max_seqlen_k), dtype=q.dtype, device=q.device)
+            dmask = torch.zeros((T_Q, H_Q, max_seqlen_k), dtype=q.dtype, device=q.device)
             p.dmask = _ptr(dmask)
         with torch.cuda.device(q.device):
             _lib.call("fa_varlen_fwd", p, _stream(q.device))
