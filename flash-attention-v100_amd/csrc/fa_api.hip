@@ -60,9 +60,10 @@ static int check_common(const fa_params& p, bool need_out) {
     FA_CHECK(p.nheads_k > 0 && p.nheads_q % p.nheads_k == 0, "H_Q must be divisible by H_K for GQA/MQA");
     FA_CHECK(p.p_dropout >= 0.f && p.p_dropout < 1.f, "p_dropout must be in [0, 1)");
     if (p.softcap > 0.f) FA_CHECK(p.p_dropout == 0.f, "Softcapping does not support dropout for now");
-    FA_CHECK((p.q_row_stride % 8) == 0 && (p.q_head_stride % 8) == 0 && (p.k_row_stride % 8) == 0 &&
-             (p.k_head_stride % 8) == 0 && (p.v_row_stride % 8) == 0 && (p.v_head_stride % 8) == 0,
-             "q/k/v strides must be multiples of 8 elements (16-byte rows)");
+    const int kv_al = p.kv_dtype == FA_FP8_E4M3 ? 16 : 8;
+    FA_CHECK((p.q_row_stride % 8) == 0 && (p.q_head_stride % 8) == 0 && (p.k_row_stride % kv_al) == 0 &&
+             (p.k_head_stride % kv_al) == 0 && (p.v_row_stride % kv_al) == 0 && (p.v_head_stride % kv_al) == 0,
+             "q/k/v strides must be multiples of 16 bytes");
     FA_CHECK((reinterpret_cast<uintptr_t>(p.q) & 15) == 0 && (reinterpret_cast<uintptr_t>(p.k) & 15) == 0 &&
              (reinterpret_cast<uintptr_t>(p.v) & 15) == 0, "q/k/v must be 16-byte aligned");
     if (!supported_head_dim(p.head_dim))
@@ -195,7 +196,8 @@ int fa_fwd_kvcache(const fa_params* pp, void* stream) {
     a.kv_batch_idx = p.cache_batch_idx;
     a.leftpad_k = p.cache_leftpad;
     rc = fa::launch_decode(a, s);
-    if (rc == -2) return fail(FA_ERR_UNSUPPORTED, "no kvcache kernel for this configuration");
+    if (rc == -2) return fail(FA_ERR_UNSUPPORTED, "no kvcache kernel for this configuration (fp8 caches need T_q * H_q/H_k <= 32, no ALiBi/softcap)");
+    if (rc == -1) return fail(FA_ERR_INVALID_ARGUMENT, "workspace too small: query fa_fwd_kvcache_workspace_bytes()");
     if (rc) return rc;
     return check_hip("fa_fwd_kvcache launch");
 }

@@ -1,0 +1,477 @@
+// fa_decode.hip - split-KV decode kernel for flash_attn_with_kvcache (small T_q).
+//
+// The reference runs decode as one 512-thread CTA per (batch, q-head) with a 32/64-row Q tile
+// holding ONE valid row, no GQA sharing and no split-KV (kernel/fused_mha_forward_kvcache.cu:344,462):
+// every q-head re-reads its kv-head.  On MI355X decode is HBM-bound (K+V read once),
+// so this kernel is organised around bytes, not FLOPs:
+//   * one workgroup per (batch, KV-head, split): the T_q x G query rows that share a kv-head are
+//     packed into ONE 32-row MFMA tile, so the KV stream is read once per kv-head (GQA packing);
+//   * the 4 waves of the workgroup take alternate 32-key tiles of the split's key range (no
+//     barrier in the loop: every wave stages ITS tiles through a private, double-buffered LDS
+//     region with fully coalesced 16-byte loads), then merge (m, l, O) through LDS once;
+//   * optional num_splits > 1 writes normalised partial O + LSE; decode_combine_kernel merges;
+//   * paged KV (block_table), cache_batch_idx, cache_leftpad, in-kernel RoPE on Q, causal /
+//     window masks, and fp8-e4m3 K/V (dequantised while staging; k_descale folds into the softmax
+//     scale, v_descale into the final normalisation).
+// ALiBi / softcap decode falls back to the general forward kernel (fa_fwd.hip).
+#include "fa_common.h"
+#include "fa_rope.h"
+
+namespace fa {
+
+constexpr int DEC_THREADS = 256;
+constexpr int DEC_BN = 32;                     // keys per wave tile
+
+template <int D> struct DecSmem {
+    static constexpr int TILE = DEC_BN * D * 2;            // one 16-bit K (or V) tile
+    static constexpr int WAVE = 4 * TILE;                  // 2 stages x (K + V), private per wave
+    static constexpr int TOTAL = 4 * WAVE;
+};
+
+struct DecArgs {
+    KArgs a;
+    int n_splits;
+    int rows;                  // T_q * G (<= 32)
+    int group;                 // G
+    int local;                 // RoPE position advances with the query row (causal / window)
+    int page_shift;            // log2(page_block_size) or -1
+    float* o_partial;          // [n_splits, B, Hq, T_q, D] fp32 (n_splits > 1)
+    float* lse_partial;        // [n_splits, B, Hq, T_q]
+};
+
+template <typename T>
+__device__ __forceinline__ void fp8x16_to_16bit(const u32x4& in, u32x4& lo, u32x4& hi) {
+    using E = Elem<T>;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const f32x2 a = __builtin_amdgcn_cvt_pk_f32_fp8(in[w], false);
+        const f32x2 b = __builtin_amdgcn_cvt_pk_f32_fp8(in[w], true);
+        const uint32_t p0 = E::pack2(a[0], a[1]), p1 = E::pack2(b[0], b[1]);
+        if (w < 2) { lo[2 * w] = p0; lo[2 * w + 1] = p1; }
+        else       { hi[2 * (w - 2)] = p0; hi[2 * (w - 2) + 1] = p1; }
+    }
+}
+
+template <typename T, int D, bool KV8, bool PAGED>
+__global__ void __launch_bounds__(DEC_THREADS, 1) fa_decode_kernel(const DecArgs da) {
+    using E = Elem<T>;
+    constexpr int KSTEPS = D / 16;
+    constexpr int DBLKS = D / 32;
+    constexpr int TILE = DecSmem<D>::TILE;
+    constexpr int EB = KV8 ? 1 : 2;                         // bytes per cache element
+    constexpr int CPR = D * EB / 16;                        // 16-byte chunks per cache row
+    constexpr int CH = DEC_BN * CPR / 64;                   // chunks per lane per tile
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const KArgs& a = da.a;
+    const fa_params& p = a.p;
+    const int unit = blockIdx.x;                            // (b, hk)
+    const int split = blockIdx.y;
+    const int b = unit / p.nheads_k, hk = unit - b * p.nheads_k;
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, g = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    char* wsm = smem + wave * DecSmem<D>::WAVE;
+
+    const int L = p.cache_seqlens ? p.cache_seqlens[b] : 0;
+    const int lp = p.cache_leftpad ? p.cache_leftpad[b] : 0;
+    const int cb = p.cache_batch_idx ? p.cache_batch_idx[b] : b;
+    const int seqlen_k = L + p.seqlen_new;
+    const int Tq = p.seqlen_q, G = da.group, R = da.rows;
+    const int off = seqlen_k - Tq;
+    const int wl = p.window_left;
+    const int wr = p.is_causal ? 0 : p.window_right;
+
+    // ---- my packed query row: r = t * G + gq ----
+    const int r = l31;
+    const int t_row = r / G, gq = r - t_row * G;
+    const int h = hk * G + gq;
+    const bool row_ok = r < R;
+    int lo = 0, hi = seqlen_k - 1;
+    if (wr >= 0) { const int h2 = t_row + off + wr; hi = h2 < hi ? h2 : hi; }
+    if (wl >= 0) { const int l2 = t_row + off - wl; lo = l2 > lo ? l2 : lo; }
+    if (!row_ok) { lo = 0x7fffffff; hi = -1; }
+
+    // ---- Q fragments (B operand), RoPE applied in registers ----
+    u32x4 qf[KSTEPS];
+    {
+        const uint16_t* qrow = reinterpret_cast<const uint16_t*>(p.q) + (int64_t)b * p.q_batch_stride +
+                               (int64_t)t_row * p.q_row_stride + (int64_t)h * p.q_head_stride;
+        const int half = p.rotary_dim >> 1;
+        const int pos = L + lp + (da.local ? t_row : 0);
+        const uint16_t* cosp = reinterpret_cast<const uint16_t*>(p.rotary_cos) + (int64_t)pos * half;
+        const uint16_t* sinp = reinterpret_cast<const uint16_t*>(p.rotary_sin) + (int64_t)pos * half;
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            const int d_base = 16 * ks + 8 * g;
+            u32x4 x = {0, 0, 0, 0};
+            if (row_ok) {
+                x = *reinterpret_cast<const u32x4*>(qrow + d_base);
+                if (p.rotary_dim > 0 && d_base < p.rotary_dim) {
+                    u32x4 xp = x;
+                    if (!p.rotary_interleaved) {
+                        const int pd = d_base < half ? d_base + half : d_base - half;
+                        xp = *reinterpret_cast<const u32x4*>(qrow + pd);
+                    }
+                    rope_chunk<T>(x, xp, cosp, sinp, d_base, p.rotary_dim, p.rotary_interleaved != 0);
+                }
+            }
+            qf[ks] = x;
+        }
+    }
+
+    // ---- key-tile range of this split / this wave ----
+    int tile_lo = 0;
+    if (wl >= 0) { const int kmin = off - wl; if (kmin > 0) tile_lo = kmin / DEC_BN; }
+    int tile_hi = (seqlen_k + DEC_BN - 1) / DEC_BN;
+    if (wr >= 0) { const int kmax = (Tq - 1) + off + wr; const int t2 = kmax < 0 ? 0 : kmax / DEC_BN + 1; tile_hi = t2 < tile_hi ? t2 : tile_hi; }
+    const int n_all = tile_hi > tile_lo ? tile_hi - tile_lo : 0;
+    const int per_split = ((n_all + da.n_splits - 1) / da.n_splits + 3) & ~3;     // multiple of 4 waves
+    const int s_lo = tile_lo + split * per_split;
+    int s_hi = s_lo + per_split; s_hi = s_hi < tile_hi ? s_hi : tile_hi;
+
+    // ---- staging (wave private) ----
+    const uint8_t* kbase = reinterpret_cast<const uint8_t*>(p.k) + (int64_t)hk * p.k_head_stride * EB;
+    const uint8_t* vbase = reinterpret_cast<const uint8_t*>(p.v) + (int64_t)hk * p.v_head_stride * EB;
+    const int32_t* btab = PAGED ? p.block_table + (int64_t)b * p.block_table_batch_stride : nullptr;
+    u32x4 kA[CH], vA[CH], kB[CH], vB[CH];                 // two register sets: two tiles in flight
+    // loop-invariant per-lane byte offsets inside a tile (row * row_stride + 16-byte column)
+    uint32_t k_voff[CH], v_voff[CH];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+        const int cidx = lane + 64 * i;
+        const int row = cidx / CPR, cc = cidx % CPR;
+        k_voff[i] = (uint32_t)(row * p.k_row_stride * EB + cc * 16);
+        v_voff[i] = (uint32_t)(row * p.v_row_stride * EB + cc * 16);
+    }
+    // a 32-key tile lies inside one page when the left pad keeps tiles 32-aligned (page % 64 == 0)
+    const bool tiles_aligned = !PAGED || ((lp & (DEC_BN - 1)) == 0);
+    auto load_tile = [&](int tile, u32x4 (&kreg)[CH], u32x4 (&vreg)[CH]) {
+        const int j0 = tile * DEC_BN;
+        if (tiles_aligned && j0 + DEC_BN <= seqlen_k) {
+            // fast path: ONE scalar base per tile, no predication
+            const int pos0 = lp + j0;
+            int64_t ko, vo;
+            if (PAGED) {
+                const int pg = da.page_shift >= 0 ? (pos0 >> da.page_shift) : pos0 / p.page_block_size;
+                const int pr = pos0 - pg * p.page_block_size;
+                const int64_t phys = btab[pg];
+                ko = phys * p.k_batch_stride + (int64_t)pr * p.k_row_stride;
+                vo = phys * p.v_batch_stride + (int64_t)pr * p.v_row_stride;
+            } else {
+                ko = (int64_t)cb * p.k_batch_stride + (int64_t)pos0 * p.k_row_stride;
+                vo = (int64_t)cb * p.v_batch_stride + (int64_t)pos0 * p.v_row_stride;
+            }
+            const uint8_t* kb = kbase + ko * EB;
+            const uint8_t* vb = vbase + vo * EB;
+#pragma unroll
+            for (int i = 0; i < CH; ++i) kreg[i] = *reinterpret_cast<const u32x4*>(kb + k_voff[i]);
+#pragma unroll
+            for (int i = 0; i < CH; ++i) vreg[i] = *reinterpret_cast<const u32x4*>(vb + v_voff[i]);
+            return;
+        }
+#pragma unroll 1
+        for (int i = 0; i < CH; ++i) {
+            const int cidx = lane + 64 * i;
+            const int row = cidx / CPR, cc = cidx % CPR;
+            const int j = j0 + row;
+            u32x4 z = {0, 0, 0, 0};
+            u32x4 kx = z, vx = z;
+            if (j < seqlen_k) {
+                const int pos = lp + j;
+                int64_t ko, vo;
+                if (PAGED) {
+                    const int pg = da.page_shift >= 0 ? (pos >> da.page_shift) : pos / p.page_block_size;
+                    const int pr = pos - pg * p.page_block_size;
+                    const int64_t phys = btab[pg];
+                    ko = phys * p.k_batch_stride + (int64_t)pr * p.k_row_stride;
+                    vo = phys * p.v_batch_stride + (int64_t)pr * p.v_row_stride;
+                } else {
+                    ko = (int64_t)cb * p.k_batch_stride + (int64_t)pos * p.k_row_stride;
+                    vo = (int64_t)cb * p.v_batch_stride + (int64_t)pos * p.v_row_stride;
+                }
+                kx = *reinterpret_cast<const u32x4*>(kbase + ko * EB + cc * 16);
+                vx = *reinterpret_cast<const u32x4*>(vbase + vo * EB + cc * 16);
+            }
+            // runtime-indexed store into the register arrays would spill: select with a static unroll
+#pragma unroll
+            for (int i2 = 0; i2 < CH; ++i2) if (i2 == i) { kreg[i2] = kx; vreg[i2] = vx; }
+        }
+    };
+    auto store_tile = [&](int stage, const u32x4 (&kreg)[CH], const u32x4 (&vreg)[CH]) {
+        char* ks = wsm + stage * 2 * TILE;
+        char* vs = ks + TILE;
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const int cidx = lane + 64 * i;
+            const int row = cidx / CPR, cc = cidx % CPR;
+            if (KV8) {
+                u32x4 l0, h0, l1, h1;
+                fp8x16_to_16bit<T>(kreg[i], l0, h0);
+                fp8x16_to_16bit<T>(vreg[i], l1, h1);
+                lds_write_b128(ks + swz_row_off<D>(row, cc * 32), l0);
+                lds_write_b128(ks + swz_row_off<D>(row, cc * 32 + 16), h0);
+                lds_write_b128(vs + swzt_row_off<D>(row, cc * 32), l1);
+                lds_write_b128(vs + swzt_row_off<D>(row, cc * 32 + 16), h1);
+            } else {
+                lds_write_b128(ks + swz_row_off<D>(row, cc * 16), kreg[i]);
+                lds_write_b128(vs + swzt_row_off<D>(row, cc * 16), vreg[i]);
+            }
+        }
+    };
+
+    f32x16 oacc[DBLKS];
+#pragma unroll
+    for (int d = 0; d < DBLKS; ++d)
+#pragma unroll
+        for (int rr2 = 0; rr2 < 16; ++rr2) oacc[d][rr2] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    const float c = a.scale_log2e * (KV8 ? p.k_descale : 1.0f);
+    const int v_rr = (lane & 15) >> 2;
+    const int v_cb = (((lane >> 4) & 1) << 5) + ((lane & 3) << 3);
+
+    auto compute_tile = [&](int tile, int stage) {
+        const char* ks = wsm + stage * 2 * TILE;
+        const char* vs = ks + TILE;
+        const int n0 = tile * DEC_BN;
+        // S^T[key][row] = K Q^T
+        f32x16 s;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s[i] = 0.f;
+#pragma unroll
+        for (int ksx = 0; ksx < KSTEPS; ++ksx) {
+            const u32x4 kf = lds_read_b128(ks + swz_row_off<D>(l31, 32 * ksx + 16 * g));
+            s = E::mfma(kf, qf[ksx], s);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int j = n0 + (i & 3) + 8 * (i >> 2) + 4 * g;
+            if (j < lo || j > hi) s[i] = -INFINITY;
+        }
+        float mx = s[0];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) mx = fmaxf(mx, s[i]);
+        mx = xhalf_max(mx) * c;
+        const float m_new = fmaxf(m_run, mx);
+        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+        const float alpha = fast_exp2(m_run - m_use);
+        m_run = m_new;
+        float psum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { s[i] = fast_exp2(fmaf(s[i], c, -m_use)); psum += s[i]; }
+        l_run = fmaf(l_run, alpha, psum);
+#pragma unroll
+        for (int d = 0; d < DBLKS; ++d)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) oacc[d][i] *= alpha;
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2) {
+            u32x4 pf;
+#pragma unroll
+            for (int w2 = 0; w2 < 4; ++w2) pf[w2] = E::pack2(s[8 * t2 + 2 * w2], s[8 * t2 + 2 * w2 + 1]);
+            const int row_a = 16 * t2 + 4 * g + v_rr;
+#pragma unroll
+            for (int d = 0; d < DBLKS; ++d) {
+                const u32x2 v0 = lds_read_tr16(vs + swzt_row_off<D>(row_a, d * 64 + v_cb));
+                const u32x2 v1 = lds_read_tr16(vs + swzt_row_off<D>(row_a + 8, d * 64 + v_cb));
+                u32x4 vf = {v0[0], v0[1], v1[0], v1[1]};
+                oacc[d] = E::mfma(vf, pf, oacc[d]);
+            }
+        }
+    };
+
+    // pipeline: LDS stage s holds tile t; register set X holds t+4 (landing), Y loads t+8.
+    const int t0 = s_lo + wave;
+    if (t0 < s_hi) {
+        load_tile(t0, kA, vA);
+        if (t0 + 4 < s_hi) load_tile(t0 + 4, kB, vB);
+        store_tile(0, kA, vA);
+        if (t0 + 8 < s_hi) load_tile(t0 + 8, kA, vA);
+    }
+    for (int tile = t0; tile < s_hi; tile += 8) {
+        // even step: stage 0 holds `tile`; B holds tile+4; A is loading tile+8
+        if (tile + 4 < s_hi) store_tile(1, kB, vB);
+        if (tile + 12 < s_hi) load_tile(tile + 12, kB, vB);
+        compute_tile(tile, 0);
+        if (tile + 4 >= s_hi) break;
+        // odd step: stage 1 holds tile+4; A holds tile+8; B is loading tile+12
+        if (tile + 8 < s_hi) store_tile(0, kA, vA);
+        if (tile + 16 < s_hi) load_tile(tile + 16, kA, vA);
+        compute_tile(tile + 4, 1);
+    }
+
+    // ---- merge the 4 waves through LDS ----
+    __syncthreads();                                        // everyone is done with its tiles
+    const float l_w = xhalf_sum(l_run);
+    float* red_m = reinterpret_cast<float*>(smem);                       // [4][32]
+    float* red_l = red_m + 4 * 32;                                       // [4][32]
+    float* red_o = red_l + 4 * 32;                                       // [4][32 rows][D]
+    if (g == 0) { red_m[wave * 32 + l31] = m_run; red_l[wave * 32 + l31] = l_w; }
+#pragma unroll
+    for (int d = 0; d < DBLKS; ++d)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+            f32x4 o4 = {oacc[d][4 * rq], oacc[d][4 * rq + 1], oacc[d][4 * rq + 2], oacc[d][4 * rq + 3]};
+            *reinterpret_cast<f32x4*>(red_o + ((wave * 32 + l31) * D + d * 32 + 8 * rq + 4 * g)) = o4;
+        }
+    __syncthreads();
+    // thread -> (row = tid / 8, 16-column slice)
+    {
+        const int row = tid >> 3;                           // 0..31
+        const int cs = (tid & 7) * (D / 8);                 // D/8 columns per thread
+        const int t3 = row / G, gq3 = row - t3 * G;
+        if (row < R) {
+            float mw[4], lw[4];
+            float m_all = -INFINITY;
+#pragma unroll
+            for (int w2 = 0; w2 < 4; ++w2) { mw[w2] = red_m[w2 * 32 + row]; lw[w2] = red_l[w2 * 32 + row]; m_all = fmaxf(m_all, mw[w2]); }
+            const float m_s = (m_all == -INFINITY) ? 0.f : m_all;
+            float l_all = 0.f, sc[4];
+#pragma unroll
+            for (int w2 = 0; w2 < 4; ++w2) { sc[w2] = fast_exp2(mw[w2] - m_s); l_all = fmaf(lw[w2], sc[w2], l_all); }
+            const float inv = l_all > 0.f ? (KV8 ? p.v_descale : 1.0f) / l_all : 0.f;
+            const float lse = l_all > 0.f ? (m_all + fast_log2(l_all)) * kLn2 : -INFINITY;
+            const int hq = hk * G + gq3;
+            if (da.n_splits == 1) {
+                uint16_t* op = reinterpret_cast<uint16_t*>(p.o) + (int64_t)b * p.o_batch_stride + (int64_t)t3 * p.o_row_stride +
+                               (int64_t)hq * p.o_head_stride + cs;
+#pragma unroll
+                for (int x = 0; x < D / 8; x += 2) {
+                    float v0 = 0.f, v1 = 0.f;
+#pragma unroll
+                    for (int w2 = 0; w2 < 4; ++w2) {
+                        v0 = fmaf(red_o[(w2 * 32 + row) * D + cs + x], sc[w2], v0);
+                        v1 = fmaf(red_o[(w2 * 32 + row) * D + cs + x + 1], sc[w2], v1);
+                    }
+                    *reinterpret_cast<uint32_t*>(op + x) = E::pack2(v0 * inv, v1 * inv);
+                }
+                if ((tid & 7) == 0)
+                    p.lse[(int64_t)b * p.lse_batch_stride + (int64_t)hq * p.lse_head_stride + t3] = lse;
+            } else {
+                const int64_t prow = (((int64_t)split * p.batch + b) * p.nheads_q + hq) * Tq + t3;
+                float* op = da.o_partial + prow * D + cs;
+#pragma unroll
+                for (int x = 0; x < D / 8; ++x) {
+                    float v0 = 0.f;
+#pragma unroll
+                    for (int w2 = 0; w2 < 4; ++w2) v0 = fmaf(red_o[(w2 * 32 + row) * D + cs + x], sc[w2], v0);
+                    op[x] = v0 * inv;
+                }
+                if ((tid & 7) == 0) da.lse_partial[prow] = lse;
+            }
+        }
+    }
+}
+
+// out[row] = sum_s w_s O_s,  w_s = exp(lse_s - LSE),  LSE = log sum_s exp(lse_s)
+template <typename T>
+__global__ void __launch_bounds__(256) decode_combine_kernel(const DecArgs da) {
+    using E = Elem<T>;
+    const fa_params& p = da.a.p;
+    const int D = p.head_dim;
+    const int cpr = D / 8;
+    const int64_t rows = (int64_t)p.batch * p.nheads_q * p.seqlen_q;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t row = idx / cpr;
+    const int cc = idx % cpr;
+    if (row >= rows) return;
+    float m = -INFINITY;
+    for (int s = 0; s < da.n_splits; ++s) m = fmaxf(m, da.lse_partial[(int64_t)s * rows + row]);
+    const float m_s = (m == -INFINITY) ? 0.f : m;
+    float den = 0.f;
+    for (int s = 0; s < da.n_splits; ++s) den += __expf(da.lse_partial[(int64_t)s * rows + row] - m_s);
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int s = 0; s < da.n_splits; ++s) {
+        const float wgt = den > 0.f ? __expf(da.lse_partial[(int64_t)s * rows + row] - m_s) / den : 0.f;
+        const float* op = da.o_partial + ((int64_t)s * rows + row) * D + cc * 8;
+#pragma unroll
+        for (int x = 0; x < 8; ++x) acc[x] = fmaf(op[x], wgt, acc[x]);
+    }
+    const int t = row % p.seqlen_q;
+    const int64_t bh = row / p.seqlen_q;
+    const int hq = bh % p.nheads_q;
+    const int64_t b = bh / p.nheads_q;
+    uint16_t* out = reinterpret_cast<uint16_t*>(p.o) + b * p.o_batch_stride + (int64_t)t * p.o_row_stride +
+                    (int64_t)hq * p.o_head_stride + cc * 8;
+    u32x4 o4;
+#pragma unroll
+    for (int x = 0; x < 4; ++x) o4[x] = E::pack2(acc[2 * x], acc[2 * x + 1]);
+    *reinterpret_cast<u32x4*>(out) = o4;
+    if (cc == 0) p.lse[b * p.lse_batch_stride + (int64_t)hq * p.lse_head_stride + t] = den > 0.f ? m + __logf(den) : -INFINITY;
+}
+
+// ---- host ---------------------------------------------------------------------------------------
+bool decode_applicable(const fa_params& p) {
+    if (p.alibi_slopes || p.softcap > 0.f) return false;
+    const int G = p.nheads_q / p.nheads_k;
+    return p.seqlen_q * G <= 32 && (p.head_dim == 64 || p.head_dim == 128);
+}
+
+int decode_num_splits(const fa_params& p) {
+    if (p.num_splits >= 1) return p.num_splits > 64 ? 64 : p.num_splits;
+    const int units = p.batch * p.nheads_k;
+    const int max_tiles = (p.seqlen_k + DEC_BN - 1) / DEC_BN;
+    int s = 1;
+    while (units * s < 512 && s < 32 && max_tiles / (s * 2) >= 8) s *= 2;       // >= 8 tiles (256 keys) per split
+    return s;
+}
+
+size_t decode_split_workspace_bytes(const fa_params& p) {
+    const int s = decode_num_splits(p);
+    if (s <= 1) return 0;
+    const size_t rows = (size_t)p.batch * p.nheads_q * p.seqlen_q;
+    return (size_t)s * rows * (p.head_dim + 1) * sizeof(float);
+}
+
+template <typename T, int D>
+static int launch_decode_td(DecArgs& da, hipStream_t stream) {
+    const fa_params& p = da.a.p;
+    const bool kv8 = p.kv_dtype == FA_FP8_E4M3;
+    const bool paged = p.block_table != nullptr;
+    dim3 grid(p.batch * p.nheads_k, da.n_splits);
+    const size_t smem = DecSmem<D>::TOTAL;
+#define FA_LAUNCH_DEC(KV8, PAGED)                                                                                   \
+    do {                                                                                                            \
+        auto kern = fa_decode_kernel<T, D, KV8, PAGED>;                                                             \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
+        hipLaunchKernelGGL(kern, grid, dim3(DEC_THREADS), smem, stream, da);                                        \
+    } while (0)
+    if (kv8) { if (paged) FA_LAUNCH_DEC(true, true); else FA_LAUNCH_DEC(true, false); }
+    else     { if (paged) FA_LAUNCH_DEC(false, true); else FA_LAUNCH_DEC(false, false); }
+#undef FA_LAUNCH_DEC
+    if (da.n_splits > 1) {
+        const int64_t total = (int64_t)p.batch * p.nheads_q * p.seqlen_q * (D / 8);
+        hipLaunchKernelGGL(decode_combine_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, da);
+    }
+    return 0;
+}
+
+// workspace layout: [o_partial | lse_partial] at `ws`
+int launch_decode_splitkv(const KArgs& a, void* ws, hipStream_t stream) {
+    const fa_params& p = a.p;
+    DecArgs da;
+    da.a = a;
+    da.group = p.nheads_q / p.nheads_k;
+    da.rows = p.seqlen_q * da.group;
+    da.local = (p.is_causal || p.window_left >= 0 || p.window_right >= 0) ? 1 : 0;
+    da.n_splits = decode_num_splits(p);
+    da.page_shift = -1;
+    if (p.block_table && (p.page_block_size & (p.page_block_size - 1)) == 0) {
+        int sft = 0; while ((1 << sft) < p.page_block_size) ++sft;
+        da.page_shift = sft;
+    }
+    da.o_partial = nullptr; da.lse_partial = nullptr;
+    if (da.n_splits > 1) {
+        if (!ws) return -1;
+        const size_t rows = (size_t)p.batch * p.nheads_q * p.seqlen_q;
+        da.o_partial = reinterpret_cast<float*>(ws);
+        da.lse_partial = da.o_partial + (size_t)da.n_splits * rows * p.head_dim;
+    }
+    const bool bf = p.dtype == FA_BF16;
+    switch (p.head_dim) {
+        case 64:  return bf ? launch_decode_td<bf16_tag, 64>(da, stream) : launch_decode_td<fp16_tag, 64>(da, stream);
+        case 128: return bf ? launch_decode_td<bf16_tag, 128>(da, stream) : launch_decode_td<fp16_tag, 128>(da, stream);
+        default:  return -2;
+    }
+}
+
+}  // namespace fa

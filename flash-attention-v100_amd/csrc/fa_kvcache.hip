@@ -10,50 +10,34 @@
 //   interleaved: (x[2t], x[2t+1]) -> (x0 c - x1 s, x0 s + x1 c)
 //   NeoX:        (x[t], x[t+rd/2]) -> (x0 c - x1 s, x0 s + x1 c)
 #include "fa_common.h"
+#include "fa_rope.h"
 
 namespace fa {
 
 int launch_fwd(const KArgs& a, hipStream_t stream);
+bool decode_applicable(const fa_params& p);
+size_t decode_split_workspace_bytes(const fa_params& p);
+int launch_decode_splitkv(const KArgs& a, void* ws, hipStream_t stream);
 
+// 8 x 16-bit -> 8 x fp8-e4m3 (OCP), value / descale, saturating at +-448
 template <typename T>
-__device__ __forceinline__ void rope_chunk(u32x4& x, const u32x4& xp, const uint16_t* cosp, const uint16_t* sinp,
-                                           int d_base, int rd, bool interleaved) {
-    // x: 8 elements at d_base..d_base+7; xp: partner chunk (NeoX only).
+__device__ __forceinline__ u32x2 to_fp8x8(const u32x4& x, float inv_descale) {
     using E = Elem<T>;
-    if (d_base >= rd) return;
-    const int half = rd >> 1;
-    if (interleaved) {
-        const u32x2 cw = *reinterpret_cast<const u32x2*>(cosp + d_base / 2);   // 4 cos values
-        const u32x2 sw = *reinterpret_cast<const u32x2*>(sinp + d_base / 2);
+    u32x2 r = {0, 0};
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float x0 = E::lo(x[i]), x1 = E::hi(x[i]);
-            const uint32_t cword = cw[i >> 1], sword = sw[i >> 1];
-            const float c = (i & 1) ? E::hi(cword) : E::lo(cword);
-            const float s = (i & 1) ? E::hi(sword) : E::lo(sword);
-            x[i] = E::pack2(fmaf(x0, c, -x1 * s), fmaf(x0, s, x1 * c));
-        }
-    } else {
-        const bool first = d_base < half;
-        const int t0 = first ? d_base : d_base - half;
-        const u32x4 cw = *reinterpret_cast<const u32x4*>(cosp + t0);           // 8 cos values
-        const u32x4 sw = *reinterpret_cast<const u32x4*>(sinp + t0);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float a0 = E::lo(x[i]), a1 = E::hi(x[i]);
-            const float b0 = E::lo(xp[i]), b1 = E::hi(xp[i]);
-            const float c0 = E::lo(cw[i]), c1 = E::hi(cw[i]);
-            const float s0 = E::lo(sw[i]), s1 = E::hi(sw[i]);
-            // first half: y = x0 c - x1 s (x0 = own, x1 = partner); second: y = x0 s + x1 c (x0 = partner, x1 = own)
-            const float y0 = first ? fmaf(a0, c0, -b0 * s0) : fmaf(b0, s0, a0 * c0);
-            const float y1 = first ? fmaf(a1, c1, -b1 * s1) : fmaf(b1, s1, a1 * c1);
-            x[i] = E::pack2(y0, y1);
-        }
+    for (int i = 0; i < 4; ++i) {
+        const float a0 = fminf(fmaxf(E::lo(x[i]) * inv_descale, -448.f), 448.f);
+        const float a1 = fminf(fmaxf(E::hi(x[i]) * inv_descale, -448.f), 448.f);
+        if (i == 0) r[0] = __builtin_amdgcn_cvt_pk_fp8_f32(a0, a1, r[0], false);
+        if (i == 1) r[0] = __builtin_amdgcn_cvt_pk_fp8_f32(a0, a1, r[0], true);
+        if (i == 2) r[1] = __builtin_amdgcn_cvt_pk_fp8_f32(a0, a1, r[1], false);
+        if (i == 3) r[1] = __builtin_amdgcn_cvt_pk_fp8_f32(a0, a1, r[1], true);
     }
+    return r;
 }
 
 // One thread per 16-byte chunk of one new (b, r, hk) row; K and V.
-template <typename T>
+template <typename T, bool KV8>
 __global__ void __launch_bounds__(256) kv_append_kernel(const KArgs a) {
     const fa_params& p = a.p;
     const int cpr = p.head_dim / 8;
@@ -99,8 +83,13 @@ __global__ void __launch_bounds__(256) kv_append_kernel(const KArgs a) {
     }
     koff += (int64_t)hk * p.k_head_stride + d_base;
     voff += (int64_t)hk * p.v_head_stride + d_base;
-    *reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(const_cast<void*>(p.k)) + koff) = kx;
-    *reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(const_cast<void*>(p.v)) + voff) = vx;
+    if (KV8) {
+        *reinterpret_cast<u32x2*>(reinterpret_cast<uint8_t*>(const_cast<void*>(p.k)) + koff) = to_fp8x8<T>(kx, 1.0f / p.k_descale);
+        *reinterpret_cast<u32x2*>(reinterpret_cast<uint8_t*>(const_cast<void*>(p.v)) + voff) = to_fp8x8<T>(vx, 1.0f / p.v_descale);
+    } else {
+        *reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(const_cast<void*>(p.k)) + koff) = kx;
+        *reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(const_cast<void*>(p.v)) + voff) = vx;
+    }
 }
 
 // Rotate q [B, Tq, Hq, D] into a contiguous workspace of the same shape.
@@ -138,6 +127,7 @@ __global__ void __launch_bounds__(256) q_rope_kernel(const KArgs a, uint16_t* ou
 }
 
 size_t decode_workspace_bytes(const fa_params& p) {
+    if (decode_applicable(p)) return decode_split_workspace_bytes(p);
     size_t bytes = 0;
     if (p.rotary_dim > 0) bytes += (size_t)p.batch * p.seqlen_q * p.nheads_q * p.head_dim * 2;
     return bytes;
@@ -146,13 +136,25 @@ size_t decode_workspace_bytes(const fa_params& p) {
 int launch_decode(const KArgs& a_in, hipStream_t stream) {
     KArgs a = a_in;
     fa_params& p = a.p;
-    if (p.kv_dtype == FA_FP8_E4M3) return -2;
     const bool bf = p.dtype == FA_BF16;
+    const bool kv8 = p.kv_dtype == FA_FP8_E4M3;
+    const bool fast = decode_applicable(p);
+    if (kv8 && !fast) return -2;                         // fp8 cache is served by the decode kernel only
     if (p.k_new) {
         const int64_t total = (int64_t)p.batch * p.seqlen_new * p.nheads_k * (p.head_dim / 8);
         const int grid = (int)((total + 255) / 256);
-        if (bf) hipLaunchKernelGGL(kv_append_kernel<bf16_tag>, dim3(grid), dim3(256), 0, stream, a);
-        else    hipLaunchKernelGGL(kv_append_kernel<fp16_tag>, dim3(grid), dim3(256), 0, stream, a);
+        if (kv8) {
+            if (bf) hipLaunchKernelGGL((kv_append_kernel<bf16_tag, true>), dim3(grid), dim3(256), 0, stream, a);
+            else    hipLaunchKernelGGL((kv_append_kernel<fp16_tag, true>), dim3(grid), dim3(256), 0, stream, a);
+        } else {
+            if (bf) hipLaunchKernelGGL((kv_append_kernel<bf16_tag, false>), dim3(grid), dim3(256), 0, stream, a);
+            else    hipLaunchKernelGGL((kv_append_kernel<fp16_tag, false>), dim3(grid), dim3(256), 0, stream, a);
+        }
+    }
+    if (fast) {
+        const size_t need = decode_split_workspace_bytes(p);
+        if (need > 0 && (!p.workspace || p.workspace_bytes < need)) return -1;
+        return launch_decode_splitkv(a, p.workspace, stream);
     }
     if (p.rotary_dim > 0) {
         const size_t need = decode_workspace_bytes(p);

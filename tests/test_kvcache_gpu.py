@@ -104,3 +104,67 @@ def test_kvcache_argument_errors():
     with pytest.raises(RuntimeError):          # rotary without k
         cos = torch.zeros(256, 32, dtype=torch.float16, device="cuda")
         _fa().flash_attn_with_kvcache(q, kc, kc.clone(), rotary_cos=cos, rotary_sin=cos, cache_seqlens=5)
+
+
+@pytest.mark.parametrize("case", [
+    # B, Tq, Hq, Hk, D, L, page, dtype, num_splits
+    (2, 1, 8, 2, 128, 3000, 256, "fp16", 0),      # small batch -> heuristic split-KV, GQA packed (4 rows)
+    (3, 4, 16, 2, 64, 1000, 64, "bf16", 4),       # 32 packed rows, explicit 4 splits
+    (2, 2, 4, 4, 128, 517, 0, "fp16", 3),         # non-paged, odd split count, Tq = 2 causal
+    (130, 1, 4, 4, 128, 300, 0, "fp16", 1),       # many units, no split
+])
+def test_decode_splitkv_gqa_packing(case):
+    B, Tq, Hq, Hk, D, L, page, dt, nsplit = case
+    g = torch.Generator().manual_seed(11)
+    seqlens = torch.randint(max(1, L // 2), L, (B,), generator=g, dtype=torch.int32)
+    q = rand16((B, Tq, Hq, D), dt, 1)
+    knew = rand16((B, Tq, Hk, D), dt, 4); vnew = rand16((B, Tq, Hk, D), dt, 5)
+    if page:
+        pps = (L + Tq + page - 1) // page
+        nblk = B * pps + 2
+        kc = rand16((nblk, page, Hk, D), dt, 2); vc = rand16((nblk, page, Hk, D), dt, 3)
+        bt = torch.randperm(nblk, generator=g)[: B * pps].reshape(B, pps).to(torch.int32)
+    else:
+        kc = rand16((B, L + Tq + 3, Hk, D), dt, 2); vc = rand16((B, L + Tq + 3, Hk, D), dt, 3)
+        bt = None
+    kc_ref, vc_ref = f64(kc).copy(), f64(vc).copy()
+    out, lse = _fa().flash_attn_with_kvcache(q, kc, vc, k=knew, v=vnew, cache_seqlens=seqlens.cuda(),
+                                             block_table=None if bt is None else bt.cuda(), causal=True,
+                                             num_splits=nsplit, return_softmax_lse=True)
+    o_ref, lse_ref = oracle.kvcache_fwd(f64(q), kc_ref, vc_ref, k=f64(knew), v=f64(vnew),
+                                        cache_seqlens=seqlens.numpy(), block_table=None if bt is None else bt.numpy(),
+                                        causal=True, io_dtype=dt)
+    assert np.array_equal(f64(kc), kc_ref) and np.array_equal(f64(vc), vc_ref)
+    assert_close(f64(out), o_ref, dt, "out")
+    assert_lse_close(f64(lse), lse_ref, "lse")
+
+
+@pytest.mark.parametrize("Hk", [8, 2])
+def test_decode_fp8_kv_cache(Hk):
+    """fp8-e4m3 KV cache (extension of this build): stored code * descale, new rows quantised on append."""
+    B, Hq, D, L, page, dt = 4, 8, 128, 700, 256, "bf16"
+    kd, vd = 0.05, 0.04
+    pps = (L + 1 + page - 1) // page
+    nblk = B * pps
+    kc16 = rand16((nblk, page, Hk, D), dt, 2, scale=1.5); vc16 = rand16((nblk, page, Hk, D), dt, 3, scale=1.5)
+    kc = (kc16.float() / kd).to(torch.float8_e4m3fn); vc = (vc16.float() / vd).to(torch.float8_e4m3fn)
+    bt = torch.randperm(nblk, generator=torch.Generator().manual_seed(2)).reshape(B, pps).to(torch.int32)
+    q = rand16((B, 1, Hq, D), dt, 1)
+    knew = rand16((B, 1, Hk, D), dt, 4); vnew = rand16((B, 1, Hk, D), dt, 5)
+    seqlens = torch.tensor([L - 1, 17, 256, 511], dtype=torch.int32)
+    cos, sin = _rotary(pps * page + 8, D, dt)
+    kc_ref = kc.float().double().cpu().numpy().copy(); vc_ref = vc.float().double().cpu().numpy().copy()
+    out, lse = _fa().flash_attn_with_kvcache(q, kc, vc, k=knew, v=vnew, rotary_cos=cos, rotary_sin=sin,
+                                             cache_seqlens=seqlens.cuda(), block_table=bt.cuda(), causal=True,
+                                             rotary_interleaved=False, return_softmax_lse=True,
+                                             k_descale=kd, v_descale=vd)
+    o_ref, lse_ref = oracle.kvcache_fwd(f64(q), kc_ref, vc_ref, k=f64(knew), v=f64(vnew), rotary_cos=f64(cos),
+                                        rotary_sin=f64(sin), cache_seqlens=seqlens.numpy(), block_table=bt.numpy(),
+                                        causal=True, rotary_interleaved=False, io_dtype=dt, k_descale=kd, v_descale=vd)
+    # appended rows: identical fp8 codes except for fp32-vs-fp64 rounding ties (<= 1 code step)
+    got_k = kc.float().double().cpu().numpy(); got_v = vc.float().double().cpu().numpy()
+    assert (np.abs(got_k - kc_ref) <= 0.13 * np.maximum(np.abs(kc_ref), 2.0 ** -6)).all()
+    assert (got_k != kc_ref).mean() < 1e-3
+    assert np.array_equal(got_v, vc_ref)
+    assert_close(f64(out), o_ref, dt, "out", mult=1.5)
+    assert_lse_close(f64(lse), lse_ref, "lse", atol=3e-2)
