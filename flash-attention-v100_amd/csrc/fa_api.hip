@@ -46,7 +46,7 @@ static int check_hip(const char* what) {
     return FA_OK;
 }
 
-static bool supported_head_dim(int d) { return d == 64 || d == 128; }
+static bool supported_head_dim(int d) { return d == 64 || d == 128 || d == 256; }
 
 // Checks shared by every op (reference: fused_mha_forward.cu:324-340).
 static int check_common(const fa_params& p, bool need_out) {
@@ -67,7 +67,7 @@ static int check_common(const fa_params& p, bool need_out) {
     FA_CHECK((reinterpret_cast<uintptr_t>(p.q) & 15) == 0 && (reinterpret_cast<uintptr_t>(p.k) & 15) == 0 &&
              (reinterpret_cast<uintptr_t>(p.v) & 15) == 0, "q/k/v must be 16-byte aligned");
     if (!supported_head_dim(p.head_dim))
-        return fail(FA_ERR_UNSUPPORTED, "head dimension %d has no gfx950 kernel in this build (64, 128)", p.head_dim);
+        return fail(FA_ERR_UNSUPPORTED, "head dimension %d has no gfx950 kernel in this build (64, 128, 256)", p.head_dim);
     return FA_OK;
 }
 
@@ -105,7 +105,7 @@ int fa_abi_version(void) { return FA_ABI_VERSION; }
 size_t fa_params_size(void) { return sizeof(fa_params); }
 const char* fa_last_error(void) { return g_last_error.c_str(); }
 const char* fa_build_info(void) {
-    return "libfa_mi355: gfx950 (CDNA4) hand-written HIP; mfma_f32_32x32x16_{bf16,f16}; head_dim {64,128}; "
+    return "libfa_mi355: gfx950 (CDNA4) hand-written HIP; mfma_f32_32x32x16_{bf16,f16}; head_dim {64,128,256}; "
            "ops fwd/bwd/varlen_fwd/varlen_bwd/fwd_kvcache";
 }
 

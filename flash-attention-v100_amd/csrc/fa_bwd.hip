@@ -756,6 +756,7 @@ int launch_bwd(const KArgs& a, hipStream_t stream) {
     switch (a.p.head_dim) {
         case 64:  return bf ? launch_bwd_td<bf16_tag, 64>(a, stream) : launch_bwd_td<fp16_tag, 64>(a, stream);
         case 128: return bf ? launch_bwd_td<bf16_tag, 128>(a, stream) : launch_bwd_td<fp16_tag, 128>(a, stream);
+        case 256: return bf ? launch_bwd_td<bf16_tag, 256>(a, stream) : launch_bwd_td<fp16_tag, 256>(a, stream);
         default:  return -2;
     }
 }

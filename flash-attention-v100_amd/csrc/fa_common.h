@@ -100,8 +100,8 @@ __device__ __forceinline__ int swz_row_off(int row, int col_byte) {
 template <int D>
 __device__ __forceinline__ int swzt_row_off(int row, int col_byte) {
     constexpr int ROWB = D * 2;
-    static_assert(D == 64 || D == 128, "swzt layout defined for D = 64, 128");
-    const int f = (D == 128) ? (((row & 3) << 2) | ((row >> 2) & 3))
+    static_assert(D == 64 || D == 128 || D == 256, "swzt layout defined for D = 64, 128, 256");
+    const int f = (D >= 128) ? (((row & 3) << 2) | ((row >> 2) & 3))
                              : ((((row >> 1) & 1) << 2) | ((row >> 2) & 3));
     return row * ROWB + (col_byte ^ (f << 4));
 }

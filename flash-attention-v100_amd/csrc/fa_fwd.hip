@@ -34,7 +34,7 @@ template <int D> struct FwdSmem {
 };
 
 template <typename T, int D, bool BIAS, bool PAGED, bool DROPOUT>
-__global__ void __launch_bounds__(FWD_THREADS, 2) fa_fwd_kernel(const KArgs a) {
+__global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : 2)) fa_fwd_kernel(const KArgs a) {
     using E = Elem<T>;
     constexpr int KSTEPS = D / 16;
     constexpr int DBLKS = D / 32;
@@ -421,6 +421,7 @@ int launch_fwd(const KArgs& a, hipStream_t stream) {
     switch (a.p.head_dim) {
         case 64:  return bf ? launch_fwd_td<bf16_tag, 64>(a, paged, stream) : launch_fwd_td<fp16_tag, 64>(a, paged, stream);
         case 128: return bf ? launch_fwd_td<bf16_tag, 128>(a, paged, stream) : launch_fwd_td<fp16_tag, 128>(a, paged, stream);
+        case 256: return bf ? launch_fwd_td<bf16_tag, 256>(a, paged, stream) : launch_fwd_td<fp16_tag, 256>(a, paged, stream);
         default:  return -2;
     }
 }

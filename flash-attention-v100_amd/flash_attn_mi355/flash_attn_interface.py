@@ -7,7 +7,7 @@ same positional/keyword arguments, defaults and return conventions.  Differences
 deliberate (DESIGN.md "divergences"):
   * tensors are handed to the C ABI (include/fa_mi355.h) with their strides - none of the
     reference's permute().contiguous() copies (flash_attn_interface.py:36-53,67);
-  * fp16 AND bf16; any head_dim <= 128 (zero-padded to 64/128 on the host);
+  * fp16 AND bf16; any head_dim <= 256 (zero-padded to 64/128/256 on the host);
   * `return_attn_probs=True` works with dropout_p == 0 (returns an empty dmask) instead of
     raising (kernel/fused_mha_forward.cu:371);
   * `flash_attn_with_kvcache` accepts fp8-e4m3 caches with `k_descale` / `v_descale`.
@@ -35,7 +35,9 @@ def _padded_head_dim(d: int) -> int:
         return 64
     if d <= 128:
         return 128
-    raise RuntimeError(f"head dimension {d} > 128 has no gfx950 kernel in this build")
+    if d <= 256:
+        return 256          # functional, not yet tuned (register spills): DESIGN.md section 8
+    raise RuntimeError(f"head dimension {d} > 256 is not supported (reference limit, fused_mha_forward.cu:337)")
 
 
 def _prep(x: torch.Tensor, dpad: int) -> torch.Tensor:
@@ -380,8 +382,8 @@ def flash_attn_with_kvcache(q, k_cache, v_cache, k=None, v=None, rotary_cos=None
                     ("cache_leftpad", cache_leftpad), ("block_table", block_table)):
         if t is not None and t.dtype != torch.int32:
             raise RuntimeError(f"{name} must have dtype int32")
-    if D not in (64, 128):
-        raise RuntimeError(f"kvcache head dimension {D} has no gfx950 kernel in this build (64, 128)")
+    if D not in (64, 128, 256):
+        raise RuntimeError(f"kvcache head dimension {D} has no gfx950 kernel in this build (64, 128, 256)")
     fp8 = k_cache.dtype == torch.float8_e4m3fn
     if not fp8 and (k_cache.dtype != q.dtype or v_cache.dtype != q.dtype):
         raise RuntimeError("kcache/vcache must have the same dtype as q (or float8_e4m3fn)")

@@ -108,3 +108,22 @@ def test_bwd_deterministic_and_linear():
         assert torch.isfinite(a_).all()
         rel = ((b_.float() - 2 * a_.float()).abs().max() / (2 * a_.float()).abs().max()).item()
         assert rel < 2e-2, rel
+
+
+@pytest.mark.parametrize("D,dt", [(256, "bf16"), (192, "fp16"), (32, "fp16"), (16, "bf16")])
+def test_head_dims_of_the_reference(D, dt):
+    """Reference head dims {16, 32, 64, 128, 256} (fused_mha_forward.cu:421-428) + a padded one."""
+    B, S, Hq, Hk = 1, 160, 4, 2
+    q = rand16((B, S, Hq, D), dt, 1).requires_grad_(True)
+    k = rand16((B, S, Hk, D), dt, 2).requires_grad_(True)
+    v = rand16((B, S, Hk, D), dt, 3).requires_grad_(True)
+    do = rand16((B, S, Hq, D), dt, 4)
+    out = _fa().flash_attn_func(q, k, v, causal=True)
+    dq, dk, dv = torch.autograd.grad(out, (q, k, v), do)
+    t = lambda x: f64(x).transpose(0, 2, 1, 3)
+    o_ref, lse_ref, _ = oracle.attn_fwd(t(q), t(k), t(v), D ** -0.5, causal=True)
+    g = oracle.attn_bwd(t(do), t(q), t(k), t(v), o_ref, lse_ref.astype(np.float64), D ** -0.5, causal=True)
+    assert_close(t(out), o_ref, dt, "out")
+    assert_close(t(dq), g[0], dt, "dq", mult=2.0)
+    assert_close(t(dk), g[1], dt, "dk", mult=2.0)
+    assert_close(t(dv), g[2], dt, "dv", mult=2.0)
