@@ -128,6 +128,9 @@ __global__ void __launch_bounds__(BWD_THREADS, 1) fa_bwd_dkdv_kernel(const KArgs
     const uint64_t drop_n_glob = (uint64_t)p.seqlen_k;
 
     // loop-invariant staging geometry
+    // Q / dO tiles are staged through registers here (buffer_load -> ds_write after the MFMAs):
+    // measured 4 % faster than LDS-DMA for this one-wave-per-SIMD kernel (the DMA's vmcnt(0) in
+    // front of the barrier is exposed), while LDS-DMA wins in the two-wave kernels (fwd, dQ).
     uint32_t q_voff[CHUNKS], do_voff[CHUNKS];
     int t_lds[CHUNKS];
 #pragma unroll
@@ -211,7 +214,7 @@ __global__ void __launch_bounds__(BWD_THREADS, 1) fa_bwd_dkdv_kernel(const KArgs
     // ---- staging of Q / dO / lse / D tiles (rows past seqlen_q read as zero) ----
     u32x4 qreg[CHUNKS], doreg[CHUNKS];
     float statreg = 0.f;
-    auto load_tile = [&](int it) {
+    auto load_tile = [&](int it, auto) {
         const int gq = it / n_tiles;
         const int m0 = (mt0 + it - gq * n_tiles) * DKV_BQ;
         const int h = hk * group + gq;
@@ -392,13 +395,13 @@ __global__ void __launch_bounds__(BWD_THREADS, 1) fa_bwd_dkdv_kernel(const KArgs
     auto step = [&](auto stage_c, int it) {
         constexpr int stage = decltype(stage_c)::value;
         const bool has_next = it + 1 < n_iter;
-        if (has_next) load_tile(it + 1);
+        if (has_next) load_tile(it + 1, std::integral_constant<int, stage ^ 1>{});
         compute(stage_c, it);
         if (has_next) store_tile(std::integral_constant<int, stage ^ 1>{});
         __syncthreads();
     };
 
-    if (n_iter > 0) { load_tile(0); store_tile(std::integral_constant<int, 0>{}); }
+    if (n_iter > 0) { load_tile(0, std::integral_constant<int, 0>{}); store_tile(std::integral_constant<int, 0>{}); }
     __syncthreads();
     for (int it = 0; it < n_iter; it += 2) {
         step(std::integral_constant<int, 0>{}, it);
@@ -471,16 +474,22 @@ __global__ void __launch_bounds__(BWD_THREADS, OCC) fa_bwd_dq_kernel(const KArgs
     const __amdgpu_buffer_rsrc_t v_rsrc = make_rsrc(vp, p.v_row_stride, sg.seqlen_k, D);
     const uint32_t k_tile_bytes = (uint32_t)(DQ_BN * p.k_row_stride * 2);
     const uint32_t v_tile_bytes = (uint32_t)(DQ_BN * p.v_row_stride * 2);
+    // LDS-DMA staging (see fa_fwd.hip): instruction `inst` = wave*CHUNKS + i covers ROWS_PI rows,
+    // lane -> (row, physical slot); the source offset carries the swizzle.
+    constexpr int ROWS_PI = 64 / CPR;
     uint32_t k_voff[CHUNKS], v_voff[CHUNKS];
     int k_lds[CHUNKS], v_lds[CHUNKS];
 #pragma unroll
     for (int i = 0; i < CHUNKS; ++i) {
-        const int cidx = tid + i * BWD_THREADS;
-        const int row = cidx / CPR, cc = cidx % CPR;
-        k_voff[i] = (uint32_t)(row * p.k_row_stride + cc * 8) * 2u;
-        v_voff[i] = (uint32_t)(row * p.v_row_stride + cc * 8) * 2u;
-        k_lds[i] = swzt_row_off<D>(row, cc * 16);
-        v_lds[i] = TILE + swz_row_off<D>(row, cc * 16);
+        const int inst = wave * CHUNKS + i;
+        const int row = inst * ROWS_PI + lane / CPR;
+        const int slot = lane % CPR;
+        const int k_cb = swzt_row_off<D>(row, slot * 16) - row * D * 2;
+        const int v_cb = swz_row_off<D>(row, slot * 16) - row * D * 2;
+        k_voff[i] = (uint32_t)(row * p.k_row_stride * 2 + k_cb);
+        v_voff[i] = (uint32_t)(row * p.v_row_stride * 2 + v_cb);
+        k_lds[i] = inst * 1024;
+        v_lds[i] = TILE + inst * 1024;
     }
     int k_rd[KSTEPS], v_rd[KSTEPS];
 #pragma unroll
@@ -554,23 +563,15 @@ __global__ void __launch_bounds__(BWD_THREADS, OCC) fa_bwd_dq_kernel(const KArgs
         }
     }
 
-    u32x4 kreg[CHUNKS], vreg[CHUNKS];
-    auto load_tile = [&](int nb) {
+    auto load_tile = [&](int nb, auto stage_c) {
+        constexpr int stage = decltype(stage_c)::value;
+        char* base = smem + stage * STAGE;
         const uint32_t ks_off = (uint32_t)nb * k_tile_bytes;
         const uint32_t vs_off = (uint32_t)nb * v_tile_bytes;
 #pragma unroll
-        for (int i = 0; i < CHUNKS; ++i) kreg[i] = buf_load_b128(k_rsrc, k_voff[i], ks_off);
+        for (int i = 0; i < CHUNKS; ++i) buf_load_lds_b128(k_rsrc, base + k_lds[i], k_voff[i], ks_off);
 #pragma unroll
-        for (int i = 0; i < CHUNKS; ++i) vreg[i] = buf_load_b128(v_rsrc, v_voff[i], vs_off);
-    };
-    auto store_tile = [&](auto stage_c) {
-        constexpr int stage = decltype(stage_c)::value;
-        char* base = smem + stage * STAGE;
-#pragma unroll
-        for (int i = 0; i < CHUNKS; ++i) {
-            lds_write_b128(base + k_lds[i], kreg[i]);
-            lds_write_b128(base + v_lds[i], vreg[i]);
-        }
+        for (int i = 0; i < CHUNKS; ++i) buf_load_lds_b128(v_rsrc, base + v_lds[i], v_voff[i], vs_off);
     };
 
     f32x16 dq_acc[DBLKS];
@@ -661,15 +662,14 @@ __global__ void __launch_bounds__(BWD_THREADS, OCC) fa_bwd_dq_kernel(const KArgs
     auto step = [&](auto stage_c, int nb) {
         constexpr int stage = decltype(stage_c)::value;
         const bool has_next = nb + 1 < n_max;
-        if (has_next) load_tile(nb + 1);
+        if (has_next) load_tile(nb + 1, std::integral_constant<int, stage ^ 1>{});
         const int n0 = nb * DQ_BN;
         const bool wave_active = (n0 <= w_hi_max) && (n0 + DQ_BN - 1 >= w_lo_min) && (wave_row0 < sg.seqlen_q);
         if (wave_active) compute(stage_c, nb);
-        if (has_next) store_tile(std::integral_constant<int, stage ^ 1>{});
         __syncthreads();
     };
 
-    if (n_min < n_max) { load_tile(n_min); store_tile(std::integral_constant<int, 0>{}); }
+    if (n_min < n_max) load_tile(n_min, std::integral_constant<int, 0>{});
     __syncthreads();
     for (int nb = n_min; nb < n_max; nb += 2) {
         step(std::integral_constant<int, 0>{}, nb);
@@ -735,7 +735,8 @@ static int launch_bwd_td(const KArgs& a, hipStream_t stream) {
     if (g_bwd_phase_mask & 4) {
         const int grid = work_grid(p.batch, p.nheads_q, p.nheads_k, a.n_qblocks);
         const size_t smem = DqSmem<D>::TOTAL;
-        constexpr int OCC = (D >= 128) ? 1 : 2;
+        // D = 128: two waves per SIMD spill ~10 registers but measure 11 % faster than one wave
+        constexpr int OCC = (D > 128) ? 1 : 2;
 #define FA_LAUNCH_DQ(BIAS, DROP)                                                                                  \
         do {                                                                                                      \
             auto kern = fa_bwd_dq_kernel<T, D, BIAS, OCC, DROP>;                                                  \

@@ -160,6 +160,13 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, in
 __device__ __forceinline__ u32x4 buf_load_b128(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
     return __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
 }
+// LDS-DMA: buffer_load_dwordx4 ... lds.  The 64 lanes write 1 KiB at `lds_dst` + lane * 16
+// (destination is lane-linear; a swizzled LDS image is obtained by permuting the per-lane SOURCE
+// offset `voff`), out-of-range lanes write zeros (probed: tools/probes/probe_lds_dma_oob.hip).
+// No VGPR staging, no ds_write; completion is tracked by vmcnt (hipcc waits before the barrier).
+__device__ __forceinline__ void buf_load_lds_b128(__amdgpu_buffer_rsrc_t r, char* lds_dst, uint32_t voff, uint32_t soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_dst, 16, voff, soff, 0, 0);
+}
 
 // ---- dropout: Philox-4x32-10, the reference's stream (include/philox.h:13-73) -----------------
 // element (i_glob, j): flat = i_glob * N_glob + j; counter = offset + (flat >> 2); word = flat & 3;

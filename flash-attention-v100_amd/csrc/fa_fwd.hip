@@ -150,26 +150,44 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : 2)) fa_fwd_kernel(
         }
     }
 
-    // ---- staging: global -> registers -> LDS ------------------------------------------------
-    // per-thread chunk c = tid + 256 i : row = c / CPR, 16-byte column cc = c % CPR
-    u32x4 kreg[CHUNKS], vreg[CHUNKS];
+    // ---- staging ---------------------------------------------------------------------------
+    // Dense / varlen: LDS-DMA (buffer_load ... lds).  Wave w issues instructions w*CHUNKS ..+CHUNKS-1
+    // of each tile; instruction i covers ROWS_PI consecutive rows (64 lanes x 16 B = 1 KiB), lane l ->
+    // row i*ROWS_PI + l / CPR, PHYSICAL 16-byte slot l % CPR, and fetches the logical chunk that the
+    // XOR swizzle places there (the swizzle is an involution).
+    // Paged K/V: one page lookup per row -> global_load to registers, ds_write after the MFMAs.
+    constexpr int ROWS_PI = 64 / CPR;
+    u32x4 kreg[PAGED ? CHUNKS : 1], vreg[PAGED ? CHUNKS : 1];
     uint32_t k_voff[CHUNKS], v_voff[CHUNKS];
     int k_lds[CHUNKS], v_lds[CHUNKS];
 #pragma unroll
     for (int i = 0; i < CHUNKS; ++i) {
-        const int c = tid + i * FWD_THREADS;
-        const int row = c / CPR, cc = c % CPR;
-        k_voff[i] = (uint32_t)(row * p.k_row_stride + cc * 8) * 2u;
-        v_voff[i] = (uint32_t)(row * p.v_row_stride + cc * 8) * 2u;
-        k_lds[i] = swz_row_off<D>(row, cc * 16);
-        v_lds[i] = TILE + swzt_row_off<D>(row, cc * 16);
+        if (PAGED) {
+            const int c = tid + i * FWD_THREADS;
+            const int row = c / CPR, cc = c % CPR;
+            k_voff[i] = 0; v_voff[i] = 0;
+            k_lds[i] = swz_row_off<D>(row, cc * 16);
+            v_lds[i] = TILE + swzt_row_off<D>(row, cc * 16);
+        } else {
+            const int inst = wave * CHUNKS + i;
+            const int row = inst * ROWS_PI + lane / CPR;
+            const int slot = lane % CPR;
+            const int k_cb = swz_row_off<D>(row, slot * 16) - row * D * 2;      // logical byte column
+            const int v_cb = swzt_row_off<D>(row, slot * 16) - row * D * 2;
+            k_voff[i] = (uint32_t)(row * p.k_row_stride * 2 + k_cb);
+            v_voff[i] = (uint32_t)(row * p.v_row_stride * 2 + v_cb);
+            k_lds[i] = inst * 1024;                                             // wave-uniform destination
+            v_lds[i] = TILE + inst * 1024;
+        }
     }
     const __amdgpu_buffer_rsrc_t k_rsrc = make_rsrc(kp, p.k_row_stride, PAGED ? 0 : seqlen_k, D);
     const __amdgpu_buffer_rsrc_t v_rsrc = make_rsrc(vp, p.v_row_stride, PAGED ? 0 : seqlen_k, D);
     const uint32_t k_tile_bytes = (uint32_t)(FWD_BN * p.k_row_stride * 2);
     const uint32_t v_tile_bytes = (uint32_t)(FWD_BN * p.v_row_stride * 2);
 
-    auto load_tile = [&](int nb) {
+    // issue the loads of tile nb; for the DMA path they land directly in LDS stage `stage`
+    auto load_tile = [&](int nb, auto stage_c) {
+        constexpr int stage = decltype(stage_c)::value;
         if (PAGED) {
             const int n0 = nb * FWD_BN;
 #pragma unroll
@@ -189,21 +207,24 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : 2)) fa_fwd_kernel(
                 }
             }
         } else {
+            char* base = smem + stage * STAGE;
             const uint32_t ks_off = (uint32_t)nb * k_tile_bytes;
             const uint32_t vs_off = (uint32_t)nb * v_tile_bytes;
 #pragma unroll
-            for (int i = 0; i < CHUNKS; ++i) kreg[i] = buf_load_b128(k_rsrc, k_voff[i], ks_off);
+            for (int i = 0; i < CHUNKS; ++i) buf_load_lds_b128(k_rsrc, base + k_lds[i], k_voff[i], ks_off);
 #pragma unroll
-            for (int i = 0; i < CHUNKS; ++i) vreg[i] = buf_load_b128(v_rsrc, v_voff[i], vs_off);
+            for (int i = 0; i < CHUNKS; ++i) buf_load_lds_b128(v_rsrc, base + v_lds[i], v_voff[i], vs_off);
         }
     };
     auto store_tile = [&](auto stage_c) {
         constexpr int stage = decltype(stage_c)::value;
-        char* base = smem + stage * STAGE;
+        if (PAGED) {
+            char* base = smem + stage * STAGE;
 #pragma unroll
-        for (int i = 0; i < CHUNKS; ++i) {
-            lds_write_b128(base + k_lds[i], kreg[i]);
-            lds_write_b128(base + v_lds[i], vreg[i]);
+            for (int i = 0; i < CHUNKS; ++i) {
+                lds_write_b128(base + k_lds[i], kreg[i]);
+                lds_write_b128(base + v_lds[i], vreg[i]);
+            }
         }
     };
 
@@ -236,6 +257,49 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : 2)) fa_fwd_kernel(
 #ifndef FA_NO_SETPRIO
         __builtin_amdgcn_s_setprio(1);
 #endif
+#ifdef FA_CHAIN
+        // one accumulator chain at a time: 8 fragment reads, then 8 back-to-back dependent MFMAs
+        {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                u32x4 kq[KSTEPS];
+#pragma unroll
+                for (int ks = 0; ks < KSTEPS; ++ks) kq[ks] = lds_read_b128(sbase + k_rd[ks] + kb * 32 * D * 2);
+#pragma unroll
+                for (int ks = 0; ks < KSTEPS; ++ks) sacc[kb] = E::mfma(kq[ks], qf[ks], sacc[kb]);
+                __builtin_amdgcn_sched_group_barrier(0x100, KSTEPS, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, KSTEPS, 0);
+            }
+        }
+#elif defined(FA_LDS_PIPE)
+        // LDS latency (~200+ cycles under load) is not hidden by the partner wave: keep FA_LDS_PIPE
+        // k-steps of K fragments in flight ahead of the MFMAs that consume them.
+        {
+            constexpr int PD = FA_LDS_PIPE;
+            u32x4 kq0[KSTEPS], kq1[KSTEPS];
+#pragma unroll
+            for (int ks = 0; ks < PD && ks < KSTEPS; ++ks) {
+                kq0[ks] = lds_read_b128(sbase + k_rd[ks]);
+                kq1[ks] = lds_read_b128(sbase + k_rd[ks] + 32 * D * 2);
+            }
+#pragma unroll
+            for (int ks = 0; ks < KSTEPS; ++ks) {
+                if (ks + PD < KSTEPS) {
+                    kq0[ks + PD] = lds_read_b128(sbase + k_rd[ks + PD]);
+                    kq1[ks + PD] = lds_read_b128(sbase + k_rd[ks + PD] + 32 * D * 2);
+                }
+                sacc[0] = E::mfma(kq0[ks], qf[ks], sacc[0]);
+                sacc[1] = E::mfma(kq1[ks], qf[ks], sacc[1]);
+            }
+            // pin the order: PD k-steps of reads first, then {2 reads, 2 MFMAs} per k-step
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * (PD < KSTEPS ? PD : KSTEPS), 0);
+#pragma unroll
+            for (int ks = 0; ks < KSTEPS; ++ks) {
+                if (ks + PD < KSTEPS) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            }
+        }
+#else
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks) {
             const u32x4 k0 = lds_read_b128(sbase + k_rd[ks]);
@@ -243,6 +307,7 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : 2)) fa_fwd_kernel(
             sacc[0] = E::mfma(k0, qf[ks], sacc[0]);
             sacc[1] = E::mfma(k1, qf[ks], sacc[1]);
         }
+#endif
 #ifndef FA_NO_SETPRIO
         __builtin_amdgcn_s_setprio(0);
 #endif
@@ -336,6 +401,21 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : 2)) fa_fwd_kernel(
             pf[1] = E::pack2(sacc[kb][8 * ks2 + 2], sacc[kb][8 * ks2 + 3]);
             pf[2] = E::pack2(sacc[kb][8 * ks2 + 4], sacc[kb][8 * ks2 + 5]);
             pf[3] = E::pack2(sacc[kb][8 * ks2 + 6], sacc[kb][8 * ks2 + 7]);
+#ifdef FA_LDS_PIPE
+            {
+                // all V^T fragments of this k-step first (2 x DBLKS transpose reads), then the MFMAs
+                const int row_a = kb * 32 + 16 * ks2 + 4 * g + v_rr;
+                u32x4 vfr[DBLKS];
+#pragma unroll
+                for (int d = 0; d < DBLKS; ++d) {
+                    const u32x2 v0 = lds_read_tr16(sbase + TILE + swzt_row_off<D>(row_a, d * 64 + v_cb));
+                    const u32x2 v1 = lds_read_tr16(sbase + TILE + swzt_row_off<D>(row_a + 8, d * 64 + v_cb));
+                    vfr[d] = u32x4{v0[0], v0[1], v1[0], v1[1]};
+                }
+#pragma unroll
+                for (int d = 0; d < DBLKS; ++d) oacc[d] = E::mfma(vfr[d], pf, oacc[d]);
+            }
+#else
 #pragma unroll
             for (int d = 0; d < DBLKS; ++d) {
                 // rows kb*32 + 16 ks2 + 8 hf + 4 g + (0..3), 64-byte column block d
@@ -345,13 +425,14 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : 2)) fa_fwd_kernel(
                 u32x4 vf = {v0[0], v0[1], v1[0], v1[1]};
                 oacc[d] = E::mfma(vf, pf, oacc[d]);
             }
+#endif
         }
     };
 
     auto tile_step = [&](auto stage_c, int nb) {
         constexpr int stage = decltype(stage_c)::value;
         const bool has_next = nb + 1 < n_max;
-        if (has_next) load_tile(nb + 1);
+        if (has_next) load_tile(nb + 1, std::integral_constant<int, stage ^ 1>{});
         const int n0 = nb * FWD_BN;
         // wave-uniform: does this wave see anything in this tile?
         const bool wave_active = (n0 <= w_hi_max) && (n0 + FWD_BN - 1 >= w_lo_min);
@@ -361,7 +442,7 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : 2)) fa_fwd_kernel(
     };
 
     if (n_min < n_max) {
-        load_tile(n_min);
+        load_tile(n_min, std::integral_constant<int, 0>{});
         store_tile(std::integral_constant<int, 0>{});
     }
     __syncthreads();

@@ -1,0 +1,9 @@
+import os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "flash-attention-v100_amd"))
+import torch, flash_attn
+torch.manual_seed(0)
+causal = "--nc" not in sys.argv
+q, k, v = (torch.randn(8, 4096, 16, 128, device="cuda", dtype=torch.bfloat16) for _ in range(3))
+for _ in range(2):
+    o = flash_attn.flash_attn_func(q, k, v, causal=causal)
+torch.cuda.synchronize()
