@@ -257,49 +257,6 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : 2)) fa_fwd_kernel(
 #ifndef FA_NO_SETPRIO
         __builtin_amdgcn_s_setprio(1);
 #endif
-#ifdef FA_CHAIN
-        // one accumulator chain at a time: 8 fragment reads, then 8 back-to-back dependent MFMAs
-        {
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
-                u32x4 kq[KSTEPS];
-#pragma unroll
-                for (int ks = 0; ks < KSTEPS; ++ks) kq[ks] = lds_read_b128(sbase + k_rd[ks] + kb * 32 * D * 2);
-#pragma unroll
-                for (int ks = 0; ks < KSTEPS; ++ks) sacc[kb] = E::mfma(kq[ks], qf[ks], sacc[kb]);
-                __builtin_amdgcn_sched_group_barrier(0x100, KSTEPS, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, KSTEPS, 0);
-            }
-        }
-#elif defined(FA_LDS_PIPE)
-        // LDS latency (~200+ cycles under load) is not hidden by the partner wave: keep FA_LDS_PIPE
-        // k-steps of K fragments in flight ahead of the MFMAs that consume them.
-        {
-            constexpr int PD = FA_LDS_PIPE;
-            u32x4 kq0[KSTEPS], kq1[KSTEPS];
-#pragma unroll
-            for (int ks = 0; ks < PD && ks < KSTEPS; ++ks) {
-                kq0[ks] = lds_read_b128(sbase + k_rd[ks]);
-                kq1[ks] = lds_read_b128(sbase + k_rd[ks] + 32 * D * 2);
-            }
-#pragma unroll
-            for (int ks = 0; ks < KSTEPS; ++ks) {
-                if (ks + PD < KSTEPS) {
-                    kq0[ks + PD] = lds_read_b128(sbase + k_rd[ks + PD]);
-                    kq1[ks + PD] = lds_read_b128(sbase + k_rd[ks + PD] + 32 * D * 2);
-                }
-                sacc[0] = E::mfma(kq0[ks], qf[ks], sacc[0]);
-                sacc[1] = E::mfma(kq1[ks], qf[ks], sacc[1]);
-            }
-            // pin the order: PD k-steps of reads first, then {2 reads, 2 MFMAs} per k-step
-            __builtin_amdgcn_sched_group_barrier(0x100, 2 * (PD < KSTEPS ? PD : KSTEPS), 0);
-#pragma unroll
-            for (int ks = 0; ks < KSTEPS; ++ks) {
-                if (ks + PD < KSTEPS) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-            }
-        }
-#else
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks) {
             const u32x4 k0 = lds_read_b128(sbase + k_rd[ks]);
@@ -307,7 +264,6 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : 2)) fa_fwd_kernel(
             sacc[0] = E::mfma(k0, qf[ks], sacc[0]);
             sacc[1] = E::mfma(k1, qf[ks], sacc[1]);
         }
-#endif
 #ifndef FA_NO_SETPRIO
         __builtin_amdgcn_s_setprio(0);
 #endif
@@ -401,21 +357,6 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : 2)) fa_fwd_kernel(
             pf[1] = E::pack2(sacc[kb][8 * ks2 + 2], sacc[kb][8 * ks2 + 3]);
             pf[2] = E::pack2(sacc[kb][8 * ks2 + 4], sacc[kb][8 * ks2 + 5]);
             pf[3] = E::pack2(sacc[kb][8 * ks2 + 6], sacc[kb][8 * ks2 + 7]);
-#ifdef FA_LDS_PIPE
-            {
-                // all V^T fragments of this k-step first (2 x DBLKS transpose reads), then the MFMAs
-                const int row_a = kb * 32 + 16 * ks2 + 4 * g + v_rr;
-                u32x4 vfr[DBLKS];
-#pragma unroll
-                for (int d = 0; d < DBLKS; ++d) {
-                    const u32x2 v0 = lds_read_tr16(sbase + TILE + swzt_row_off<D>(row_a, d * 64 + v_cb));
-                    const u32x2 v1 = lds_read_tr16(sbase + TILE + swzt_row_off<D>(row_a + 8, d * 64 + v_cb));
-                    vfr[d] = u32x4{v0[0], v0[1], v1[0], v1[1]};
-                }
-#pragma unroll
-                for (int d = 0; d < DBLKS; ++d) oacc[d] = E::mfma(vfr[d], pf, oacc[d]);
-            }
-#else
 #pragma unroll
             for (int d = 0; d < DBLKS; ++d) {
                 // rows kb*32 + 16 ks2 + 8 hf + 4 g + (0..3), 64-byte column block d
@@ -425,7 +366,6 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : 2)) fa_fwd_kernel(
                 u32x4 vf = {v0[0], v0[1], v1[0], v1[1]};
                 oacc[d] = E::mfma(vf, pf, oacc[d]);
             }
-#endif
         }
     };
 
