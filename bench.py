@@ -19,8 +19,8 @@ Besides the contract fields the JSON line carries
                   bf16 MFMA peak; durations measured here with HIP events on the stream the
                   kernels run on (torch's current stream);
   kernels       - the same for every kernel of the step (fwd, bwd dK/dV, bwd dQ, preprocess);
-  cpu_baseline  - torch scaled_dot_product_attention on the host cores (rank 0, N = 1 only),
-                  bounded sample of the same workload.
+  cpu_baseline  - the oracle (numpy fp64 restatement of the reference algorithm) on the host
+                  cores (rank 0, N = 1 only), bounded sample of the same workload.
 """
 import argparse
 import json
@@ -59,32 +59,78 @@ def event_time_ms(fn, iters):
 
 
 def cpu_baseline(c, budget_s=15.0):
-    """The PyTorch-SDPA CPU path on a bounded sample: 1 batch x 2 heads of the workload,
-    bf16, causal, fwd+bwd, repeated for ~budget_s seconds."""
-    B, H, S, D = 1, 2, c["seqlen"], c["head_dim"]
-    g = torch.Generator().manual_seed(421)
-    q, k, v, do = (torch.randn(B, H, S, D, generator=g).to(torch.bfloat16) for _ in range(4))
-    q.requires_grad_(True); k.requires_grad_(True); v.requires_grad_(True)
-    threads = torch.get_num_threads()
+    """The oracle (oracle/attention.py: the numpy fp64 restatement of the reference algorithm,
+    fwd + bwd) timed on the host cores on a bounded sample of the workload: 1 batch x 1 head
+    of S4096 D128 causal per repetition, for ~budget_s seconds.  numpy's BLAS supplies the
+    threading.  The torch-SDPA CPU path (bf16) is timed next to it for orientation."""
+    import numpy as np
+    from oracle import attention as oa
+    B, H, S, D = 1, 1, c["seqlen"], c["head_dim"]
+    rng = np.random.default_rng(421)
+    q, k, v, do = (rng.standard_normal((B, H, S, D)) for _ in range(4))
+    scale = D ** -0.5
+    try:
+        from threadpoolctl import threadpool_info
+        cores = max([i.get("num_threads", 1) for i in threadpool_info()] or [1])
+    except Exception:
+        cores = os.cpu_count() or 1
 
-    def step():
-        o = torch.nn.functional.scaled_dot_product_attention(q, k, v, is_causal=True)
-        o.backward(do)
-        q.grad = k.grad = v.grad = None
+    def ostep():
+        o, lse, _ = oa.attn_fwd(q, k, v, scale, causal=True)
+        oa.attn_bwd(do, q, k, v, o, lse, scale, causal=True)
 
-    step()
+    ostep()
     t0 = time.perf_counter()
     n = 0
     while True:
-        step()
+        ostep()
         n += 1
         el = time.perf_counter() - t0
-        if el > budget_s or n >= 200:
+        if el > budget_s or n >= 50:
             break
     flops = 3.5 * 4.0 * B * H * S * S * D * 0.5
-    return {"value": round(flops * n / el / 1e12, 4), "unit": "TFLOP/s", "cores": threads,
-            "kind": "port",
-            "sample": f"torch SDPA (CPU) fwd+bwd bf16 causal B{B} H{H} S{S} D{D}, {n} reps in {el:.1f}s"}
+    res = {"value": round(flops * n / el / 1e12, 5), "unit": "TFLOP/s", "cores": cores, "kind": "port",
+           "sample": f"oracle (numpy fp64) fwd+bwd causal B{B} H{H} S{S} D{D}, {n} reps in {el:.1f}s"}
+
+    # orientation only: PyTorch's own CPU attention in bf16 on the same shape family
+    Bt, Ht = 1, 2
+    g = torch.Generator().manual_seed(421)
+    tq, tk, tv, tdo = (torch.randn(Bt, Ht, S, D, generator=g).to(torch.bfloat16) for _ in range(4))
+    tq.requires_grad_(True); tk.requires_grad_(True); tv.requires_grad_(True)
+
+    def tstep():
+        o = torch.nn.functional.scaled_dot_product_attention(tq, tk, tv, is_causal=True)
+        o.backward(tdo)
+        tq.grad = tk.grad = tv.grad = None
+
+    tstep()
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        tstep()
+        n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s / 3 or n >= 100:
+            break
+    res["torch_sdpa_cpu_tflops"] = round(3.5 * 4.0 * Bt * Ht * S * S * D * 0.5 * n / el / 1e12, 4)
+    res["torch_sdpa_cpu_threads"] = torch.get_num_threads()
+    return res
+
+
+def measured_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes
+    (profiles/*_traffic.json, written by tools/collect_profiles.sh on the same workload)."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic.json"))):
+        try:
+            d = json.load(open(path))
+        except Exception:
+            continue
+        for name, v in d.get("kernels", {}).items():
+            if name.startswith(kernel + "<") and "bf16" in name:
+                best = (v["total_bytes"], os.path.relpath(path, ROOT))
+    return best
 
 
 def main():
@@ -181,6 +227,11 @@ def main():
                                                   "bwd_dq": "fa_bwd_dq_kernel"}[dom],
                     "achieved": kernels[dom]["achieved"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                     "frac": kernels[dom]["frac"], "traffic": None}
+        tr = measured_traffic(roofline["kernel"])
+        if tr:
+            roofline["traffic"] = tr[0]
+            roofline["traffic_unit"] = "bytes of HBM per launch (FETCH_SIZE x2 + WRITE_SIZE)"
+            roofline["traffic_source"] = tr[1]
         out = {
             "metric": "attention TFLOPS fwd+bwd (seqlen 4096, hd128, causal)",
             "value": round(value, 2), "unit": "TFLOP/s", "n_gpus": world, "steps": args.steps,

@@ -82,7 +82,7 @@ def _build_variant(defines, out, verbose):
     for src in SOURCES:
         obj = os.path.join(bdir, src.replace(".hip", ".o"))
         objs.append(obj)
-        cmd = [hipcc] + FLAGS + ["-D" + d for d in defines] + ["-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc] + FLAGS + [d if d.startswith("-") else "-D" + d for d in defines] + ["-c", os.path.join(CSRC, src), "-o", obj]
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
     for src, pr in procs:
         o, _ = pr.communicate()

@@ -77,6 +77,15 @@ __device__ __forceinline__ SeqGeom seq_geom(const fa_params& p, int b) {
 // ---------------------------------------------------------------------------------------------
 // 2. dK / dV
 // ---------------------------------------------------------------------------------------------
+#ifdef FA_TIMERS
+// development aid (variant builds only): per-phase s_memtime sums of wave 0 of workgroup FA_TIMERS
+__device__ unsigned long long g_timers[16];
+#define TMR_NOW() __builtin_readcyclecounter()
+#define TMR_ADD(i, t0) do { const unsigned long long t1_ = TMR_NOW(); tmr[i] += t1_ - (t0); (t0) = t1_; } while (0)
+#else
+#define TMR_NOW() 0ull
+#define TMR_ADD(i, t0) do { } while (0)
+#endif
 constexpr int DKV_BN = 128;     // keys per workgroup (32 per wave)
 #ifndef FA_DKV_BQ
 #define FA_DKV_BQ 64
@@ -102,6 +111,8 @@ __global__ void __launch_bounds__(BWD_THREADS, 1) fa_bwd_dkdv_kernel(const KArgs
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const fa_params& p = a.p;
+    unsigned long long tmr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    (void)tmr;
     const int n_kblocks = (p.seqlen_k + DKV_BN - 1) / DKV_BN;
     // causal load balance: key block i is paired with its mirror (heavy + light = constant)
     const bool pair = a.pair_qblocks && n_kblocks >= 2;
@@ -131,18 +142,35 @@ __global__ void __launch_bounds__(BWD_THREADS, 1) fa_bwd_dkdv_kernel(const KArgs
     const uint64_t drop_n_glob = (uint64_t)p.seqlen_k;
 
     // loop-invariant staging geometry
-    // Q / dO tiles are staged through registers here (buffer_load -> ds_write after the MFMAs):
-    // measured 4 % faster than LDS-DMA for this one-wave-per-SIMD kernel (the DMA's vmcnt(0) in
-    // front of the barrier is exposed), while LDS-DMA wins in the two-wave kernels (fwd, dQ).
+#ifndef FA_DKV_DMA
+    // Q / dO tiles staged through registers (buffer_load -> ds_write after the MFMAs): measured
+    // 13 % faster than LDS-DMA for this one-wave-per-SIMD kernel (1.54 vs 1.74 ms), while
+    // LDS-DMA wins in the two-wave kernels (fwd, dQ).
+    constexpr bool DMA = false;
+#else
+    // Q / dO tiles by LDS-DMA (see fa_fwd.hip): instruction `inst` = wave*CHUNKS + i covers
+    // ROWS_PI rows, lane -> (row, physical slot); the source offset carries the swizzle.
+    constexpr bool DMA = true;
+#endif
     uint32_t q_voff[CHUNKS], do_voff[CHUNKS];
     int t_lds[CHUNKS];
 #pragma unroll
     for (int i = 0; i < CHUNKS; ++i) {
-        const int cidx = tid + i * BWD_THREADS;
-        const int row = cidx / CPR, cc = cidx % CPR;
-        q_voff[i] = (uint32_t)(row * p.q_row_stride + cc * 8) * 2u;
-        do_voff[i] = (uint32_t)(row * p.do_row_stride + cc * 8) * 2u;
-        t_lds[i] = swzt_row_off<D>(row, cc * 16);
+        if (DMA) {
+            constexpr int ROWS_PI = 64 / CPR;
+            const int inst = wave * CHUNKS + i;
+            const int row = inst * ROWS_PI + lane / CPR;
+            const int cbs = swzt_row_off<D>(row, (lane % CPR) * 16) - row * D * 2;
+            q_voff[i] = (uint32_t)(row * p.q_row_stride * 2 + cbs);
+            do_voff[i] = (uint32_t)(row * p.do_row_stride * 2 + cbs);
+            t_lds[i] = inst * 1024;
+        } else {
+            const int cidx = tid + i * BWD_THREADS;
+            const int row = cidx / CPR, cc = cidx % CPR;
+            q_voff[i] = (uint32_t)(row * p.q_row_stride + cc * 8) * 2u;
+            do_voff[i] = (uint32_t)(row * p.do_row_stride + cc * 8) * 2u;
+            t_lds[i] = swzt_row_off<D>(row, cc * 16);
+        }
     }
     const int64_t qb_off = p.cu_seqlens_q ? 0 : (int64_t)b * p.q_batch_stride;
     const int64_t dob_off = p.cu_seqlens_q ? 0 : (int64_t)b * p.do_batch_stride;
@@ -217,7 +245,12 @@ __global__ void __launch_bounds__(BWD_THREADS, 1) fa_bwd_dkdv_kernel(const KArgs
     // ---- staging of Q / dO / lse / D tiles (rows past seqlen_q read as zero) ----
     u32x4 qreg[CHUNKS], doreg[CHUNKS];
     float statreg = 0.f;
-    auto load_tile = [&](int it, auto) {
+    // (measured with s_memtime, tools/read_timers.py: the 8 buffer_loads cost the wave ~900 issue
+    //  cycles per step; spreading them in slices between the MFMA phases made the kernel 25 %
+    //  SLOWER - the extra control flow costs more registers than this kernel has - so they stay
+    //  one burst at the top of the step.)
+    auto load_tile = [&](int it, auto stage_c) {
+        constexpr int stage = decltype(stage_c)::value;
         const int gq = it / n_tiles;
         const int m0 = (mt0 + it - gq * n_tiles) * DKV_BQ;
         const int h = hk * group + gq;
@@ -225,10 +258,18 @@ __global__ void __launch_bounds__(BWD_THREADS, 1) fa_bwd_dkdv_kernel(const KArgs
         const __amdgpu_buffer_rsrc_t do_rsrc = make_rsrc(do_base + (int64_t)h * p.do_head_stride, p.do_row_stride, sg.seqlen_q, D);
         const uint32_t q_soff = (uint32_t)(m0 * p.q_row_stride * 2);
         const uint32_t do_soff = (uint32_t)(m0 * p.do_row_stride * 2);
+        if (DMA) {
+            char* qs = smem + stage * STAGE;
 #pragma unroll
-        for (int i = 0; i < CHUNKS; ++i) qreg[i] = buf_load_b128(q_rsrc, q_voff[i], q_soff);
+            for (int i = 0; i < CHUNKS; ++i) buf_load_lds_b128(q_rsrc, qs + t_lds[i], q_voff[i], q_soff);
 #pragma unroll
-        for (int i = 0; i < CHUNKS; ++i) doreg[i] = buf_load_b128(do_rsrc, do_voff[i], do_soff);
+            for (int i = 0; i < CHUNKS; ++i) buf_load_lds_b128(do_rsrc, qs + TILE + t_lds[i], do_voff[i], do_soff);
+        } else {
+#pragma unroll
+            for (int i = 0; i < CHUNKS; ++i) qreg[i] = buf_load_b128(q_rsrc, q_voff[i], q_soff);
+#pragma unroll
+            for (int i = 0; i < CHUNKS; ++i) doreg[i] = buf_load_b128(do_rsrc, do_voff[i], do_soff);
+        }
         if (tid < 2 * DKV_BQ) {
             const int r = tid & (DKV_BQ - 1);
             const int qi = m0 + r;
@@ -244,10 +285,12 @@ __global__ void __launch_bounds__(BWD_THREADS, 1) fa_bwd_dkdv_kernel(const KArgs
         char* qs = smem + stage * STAGE;
         char* dos = qs + TILE;
         float* st = reinterpret_cast<float*>(dos + TILE);
+        if (!DMA) {
 #pragma unroll
-        for (int i = 0; i < CHUNKS; ++i) {
-            lds_write_b128(qs + t_lds[i], qreg[i]);
-            lds_write_b128(dos + t_lds[i], doreg[i]);
+            for (int i = 0; i < CHUNKS; ++i) {
+                lds_write_b128(qs + t_lds[i], qreg[i]);
+                lds_write_b128(dos + t_lds[i], doreg[i]);
+            }
         }
         if (tid < 2 * DKV_BQ) st[tid] = statreg;          // [0,64): lse2, [64,128): D
     };
@@ -260,150 +303,203 @@ __global__ void __launch_bounds__(BWD_THREADS, 1) fa_bwd_dkdv_kernel(const KArgs
 
     float slope = 0.f;
 
+    // ---- the three phases of one 32-query x 32-key sub-tile of this wave ----
+    // sd: S = Q K^T, dP = dO V^T : acc[r] = X[q0 + row(r,g)][my_key]
+    auto sd = [&](const char* qs, const char* dos, int sub, f32x16& s_acc, f32x16& dp_acc) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s_acc[r] = 0.f; dp_acc[r] = 0.f; }
+        // (measured: alternating the S and dP chains is 6 % SLOWER here - one wave per SIMD -
+        //  while it is 10 % faster in the two-wave dQ kernel)
+#ifndef FA_DKV_NO_PREFETCH
+        // one wave per SIMD: nothing else hides the LDS latency, so all Q fragments are fetched
+        // up front and the dO fragments stream in behind the S MFMAs
+        u32x4 qa[KSTEPS], da[KSTEPS];
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) qa[ks] = lds_read_b128(qs + a_rd[ks] + sub * 32 * D * 2);
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            da[ks] = lds_read_b128(dos + a_rd[ks] + sub * 32 * D * 2);
+            s_acc = E::mfma(qa[ks], kf[ks], s_acc);
+        }
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) dp_acc = E::mfma(da[ks], vf[ks], dp_acc);
+        __builtin_amdgcn_sched_group_barrier(0x100, KSTEPS, 0);
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, KSTEPS, 0);
+#else
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            const u32x4 qa = lds_read_b128(qs + a_rd[ks] + sub * 32 * D * 2);
+            s_acc = E::mfma(qa, kf[ks], s_acc);
+        }
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            const u32x4 da = lds_read_b128(dos + a_rd[ks] + sub * 32 * D * 2);
+            dp_acc = E::mfma(da, vf[ks], dp_acc);
+        }
+#endif
+    };
+    // row statistics for q = q0 + 8 i + 4 g + (0..3)
+    auto sm_stats = [&](const float* st, int sub, f32x4 (&lse2)[4], f32x4 (&dsum)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            lse2[i] = *reinterpret_cast<const f32x4*>(st + sub * 32 + 8 * i + 4 * g);
+            dsum[i] = *reinterpret_cast<const f32x4*>(st + DKV_BQ + sub * 32 + 8 * i + 4 * g);
+        }
+    };
+    // sm: P = exp2(S c - lse2), dS = P (dP - D), rounded to 16 bit as the B operands of phase bk
+    auto sm = [&](int q0, bool need_mask, const f32x4 (&lse2)[4], const f32x4 (&dsum)[4],
+                  const f32x16& s_acc, const f32x16& dp_acc, u32x4 (&pf)[2], u32x4 (&dsf)[2]) {
+        float pv[16], dsv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float l2 = lse2[r >> 2][r & 3];
+            const int qi = q0 + (r & 3) + 8 * (r >> 2) + 4 * g;
+            float dpe = dp_acc[r];
+            bool keep = true;
+            if (DROPOUT) {
+                // dS = P (keep rp dP - D); dV accumulates keep P (rp applied in the epilogue)
+                keep = dropout_keep1(dc, (uint64_t)(sg.q_row0 + qi) * drop_n_glob + (uint64_t)my_key);
+                dpe = keep ? dpe * a.rp_dropout : 0.f;
+            }
+            float pr, dsr;
+            if (BIAS) {
+                float sv = s_acc[r] * p.softmax_scale;
+                sv = fmaf(-slope, fabsf((float)(qi + off - my_key)), sv);
+                float chain = 1.f;
+                if (p.softcap > 0.f) {
+                    const float t = fast_tanh(sv / p.softcap);
+                    sv = p.softcap * t;
+                    chain = 1.f - t * t;
+                }
+                pr = fast_exp2(fmaf(sv, kLog2e, -l2));
+                dsr = pr * (dpe - dsum[r >> 2][r & 3]) * chain;
+            } else {
+                pr = fast_exp2(fmaf(s_acc[r], c, -l2));
+                dsr = pr * (dpe - dsum[r >> 2][r & 3]);
+            }
+            pv[r] = (DROPOUT && !keep) ? 0.f : pr;
+            dsv[r] = dsr;
+        }
+        if (need_mask) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int qi = q0 + (r & 3) + 8 * (r >> 2) + 4 * g;
+                if (qi < qlo || qi > qhi) { pv[r] = 0.f; dsv[r] = 0.f; }
+            }
+        }
+        // k-step t of phase bk covers regs 8t .. 8t+7
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int w2 = 0; w2 < 4; ++w2) {
+                pf[t][w2] = E::pack2(pv[8 * t + 2 * w2], pv[8 * t + 2 * w2 + 1]);
+                dsf[t][w2] = E::pack2(dsv[8 * t + 2 * w2], dsv[8 * t + 2 * w2 + 1]);
+            }
+    };
+    // bk: dV^T += dO^T P,  dK^T += Q^T dS
+    auto bk = [&](const char* qs, const char* dos, int sub, const u32x4 (&pf)[2], const u32x4 (&dsf)[2]) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            // rows sub*32 + 16 t + 8 hf + 4 g + rr ; cols 32 d + 16 ((lane>>4)&1) + 4 (lane&3)
+            const int row_a = sub * 32 + 16 * t + 4 * g + rr;
+#ifndef FA_DKV_NO_PREFETCH
+            u32x4 af[DBLKS], bfr[DBLKS];
+#pragma unroll
+            for (int d = 0; d < DBLKS; ++d) {
+                const u32x2 a0 = lds_read_tr16(dos + swzt_row_off<D>(row_a, d * 64 + cb));
+                const u32x2 a1 = lds_read_tr16(dos + swzt_row_off<D>(row_a + 8, d * 64 + cb));
+                af[d] = u32x4{a0[0], a0[1], a1[0], a1[1]};
+            }
+#pragma unroll
+            for (int d = 0; d < DBLKS; ++d) {
+                const u32x2 b0 = lds_read_tr16(qs + swzt_row_off<D>(row_a, d * 64 + cb));
+                const u32x2 b1 = lds_read_tr16(qs + swzt_row_off<D>(row_a + 8, d * 64 + cb));
+                bfr[d] = u32x4{b0[0], b0[1], b1[0], b1[1]};
+                dv_acc[d] = E::mfma(af[d], pf[t], dv_acc[d]);
+            }
+#pragma unroll
+            for (int d = 0; d < DBLKS; ++d) dk_acc[d] = E::mfma(bfr[d], dsf[t], dk_acc[d]);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * DBLKS, 0);
+#pragma unroll
+            for (int d = 0; d < DBLKS; ++d) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, DBLKS, 0);
+#else
+#pragma unroll
+            for (int d = 0; d < DBLKS; ++d) {
+                const u32x2 a0 = lds_read_tr16(dos + swzt_row_off<D>(row_a, d * 64 + cb));
+                const u32x2 a1 = lds_read_tr16(dos + swzt_row_off<D>(row_a + 8, d * 64 + cb));
+                u32x4 af = {a0[0], a0[1], a1[0], a1[1]};
+                dv_acc[d] = E::mfma(af, pf[t], dv_acc[d]);
+                const u32x2 b0 = lds_read_tr16(qs + swzt_row_off<D>(row_a, d * 64 + cb));
+                const u32x2 b1 = lds_read_tr16(qs + swzt_row_off<D>(row_a + 8, d * 64 + cb));
+                u32x4 bfr = {b0[0], b0[1], b1[0], b1[1]};
+                dk_acc[d] = E::mfma(bfr, dsf[t], dk_acc[d]);
+            }
+#endif
+        }
+    };
+
     auto compute = [&](auto stage_c, int it) {
         constexpr int stage = decltype(stage_c)::value;
+        constexpr int NSUB = DKV_BQ / 32;
         const int gq = it / n_tiles;
         const int m0 = (mt0 + it - gq * n_tiles) * DKV_BQ;
         if (BIAS && p.alibi_slopes) slope = p.alibi_slopes[b * p.alibi_batch_stride + hk * group + gq];
         const char* qs = smem + stage * STAGE;
         const char* dos = qs + TILE;
         const float* st = reinterpret_cast<const float*>(dos + TILE);
+        // any visible (query, key) pair for this wave in rows [q0, q0+31]?
+        auto is_active = [&](int q0) { return wave_has_keys && (q0 <= w_qhi_max) && (q0 + 31 >= w_qlo_min); };
+        auto needs_mask = [&](int q0) { return key_tail || (q0 < w_qlo_max) || (q0 + 31 > w_qhi_min); };
 #pragma unroll
-        for (int sub = 0; sub < DKV_BQ / 32; ++sub) {
+        for (int sub = 0; sub < NSUB; ++sub) {
             const int q0 = m0 + sub * 32;
-            // any visible (query, key) pair for this wave in rows [q0, q0+31]?
-            const bool active = wave_has_keys && (q0 <= w_qhi_max) && (q0 + 31 >= w_qlo_min);
-            if (!active) continue;
-            // ---- S = Q K^T, dP = dO V^T : acc[r] = X[q0 + row(r,g)][my_key] ----
+            if (!is_active(q0)) continue;
             f32x16 s_acc, dp_acc;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { s_acc[r] = 0.f; dp_acc[r] = 0.f; }
-#ifdef FA_PREFETCH
-            // one wave per SIMD: nothing else hides LDS latency, so fetch ALL row fragments of
-            // the sub-tile first and let the MFMAs stream behind counted lgkmcnt waits
-            u32x4 qa[KSTEPS], da[KSTEPS];
-#pragma unroll
-            for (int ks = 0; ks < KSTEPS; ++ks) qa[ks] = lds_read_b128(qs + a_rd[ks] + sub * 32 * D * 2);
-#pragma unroll
-            for (int ks = 0; ks < KSTEPS; ++ks) da[ks] = lds_read_b128(dos + a_rd[ks] + sub * 32 * D * 2);
-            __builtin_amdgcn_sched_group_barrier(0x100, 2 * KSTEPS, 0);
-#pragma unroll
-            for (int ks = 0; ks < KSTEPS; ++ks) s_acc = E::mfma(qa[ks], kf[ks], s_acc);
-#pragma unroll
-            for (int ks = 0; ks < KSTEPS; ++ks) dp_acc = E::mfma(da[ks], vf[ks], dp_acc);
-            __builtin_amdgcn_sched_group_barrier(0x008, 2 * KSTEPS, 0);
-#else
-            // (measured: alternating the S and dP chains is 6 % SLOWER here - one wave per SIMD -
-            //  while it is 10 % faster in the two-wave dQ kernel)
-#pragma unroll
-            for (int ks = 0; ks < KSTEPS; ++ks) {
-                const u32x4 qa = lds_read_b128(qs + a_rd[ks] + sub * 32 * D * 2);
-                s_acc = E::mfma(qa, kf[ks], s_acc);
-            }
-#pragma unroll
-            for (int ks = 0; ks < KSTEPS; ++ks) {
-                const u32x4 da = lds_read_b128(dos + a_rd[ks] + sub * 32 * D * 2);
-                dp_acc = E::mfma(da, vf[ks], dp_acc);
-            }
-#endif
-            // row statistics for q = q0 + 8 i + 4 g + (0..3)
+            u32x4 pf[2], dsf[2];
             f32x4 lse2[4], dsum[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                lse2[i] = *reinterpret_cast<const f32x4*>(st + sub * 32 + 8 * i + 4 * g);
-                dsum[i] = *reinterpret_cast<const f32x4*>(st + DKV_BQ + sub * 32 + 8 * i + 4 * g);
-            }
-            float pv[16], dsv[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float l2 = lse2[r >> 2][r & 3];
-                const int qi = q0 + (r & 3) + 8 * (r >> 2) + 4 * g;
-                float dpe = dp_acc[r];
-                bool keep = true;
-                if (DROPOUT) {
-                    // dS = P (keep rp dP - D); dV accumulates keep P (rp applied in the epilogue)
-                    keep = dropout_keep1(dc, (uint64_t)(sg.q_row0 + qi) * drop_n_glob + (uint64_t)my_key);
-                    dpe = keep ? dpe * a.rp_dropout : 0.f;
-                }
-                float pr, dsr;
-                if (BIAS) {
-                    float s = s_acc[r] * p.softmax_scale;
-                    s = fmaf(-slope, fabsf((float)(qi + off - my_key)), s);
-                    float chain = 1.f;
-                    if (p.softcap > 0.f) {
-                        const float t = fast_tanh(s / p.softcap);
-                        s = p.softcap * t;
-                        chain = 1.f - t * t;
-                    }
-                    pr = fast_exp2(fmaf(s, kLog2e, -l2));
-                    dsr = pr * (dpe - dsum[r >> 2][r & 3]) * chain;
-                } else {
-                    pr = fast_exp2(fmaf(s_acc[r], c, -l2));
-                    dsr = pr * (dpe - dsum[r >> 2][r & 3]);
-                }
-                pv[r] = (DROPOUT && !keep) ? 0.f : pr;
-                dsv[r] = dsr;
-            }
-            const bool need_mask = key_tail || (q0 < w_qlo_max) || (q0 + 31 > w_qhi_min);
-            if (need_mask) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int qi = q0 + (r & 3) + 8 * (r >> 2) + 4 * g;
-                    if (qi < qlo || qi > qhi) { pv[r] = 0.f; dsv[r] = 0.f; }
-                }
-            }
-            // ---- dV^T += dO^T P,  dK^T += Q^T dS : k-step t covers regs 8t .. 8t+7 ----
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                u32x4 pf, dsf;
-#pragma unroll
-                for (int w2 = 0; w2 < 4; ++w2) {
-                    pf[w2] = E::pack2(pv[8 * t + 2 * w2], pv[8 * t + 2 * w2 + 1]);
-                    dsf[w2] = E::pack2(dsv[8 * t + 2 * w2], dsv[8 * t + 2 * w2 + 1]);
-                }
-                // rows sub*32 + 16 t + 8 hf + 4 g + rr ; cols 32 d + 16 ((lane>>4)&1) + 4 (lane&3)
-                const int row_a = sub * 32 + 16 * t + 4 * g + rr;
-#ifdef FA_PREFETCH
-                u32x4 af[DBLKS], bfr[DBLKS];
-#pragma unroll
-                for (int d = 0; d < DBLKS; ++d) {
-                    const u32x2 a0 = lds_read_tr16(dos + swzt_row_off<D>(row_a, d * 64 + cb));
-                    const u32x2 a1 = lds_read_tr16(dos + swzt_row_off<D>(row_a + 8, d * 64 + cb));
-                    const u32x2 b0 = lds_read_tr16(qs + swzt_row_off<D>(row_a, d * 64 + cb));
-                    const u32x2 b1 = lds_read_tr16(qs + swzt_row_off<D>(row_a + 8, d * 64 + cb));
-                    af[d] = u32x4{a0[0], a0[1], a1[0], a1[1]};
-                    bfr[d] = u32x4{b0[0], b0[1], b1[0], b1[1]};
-                }
-                __builtin_amdgcn_sched_group_barrier(0x100, 4 * DBLKS, 0);
-#pragma unroll
-                for (int d = 0; d < DBLKS; ++d) {
-                    dv_acc[d] = E::mfma(af[d], pf, dv_acc[d]);
-                    dk_acc[d] = E::mfma(bfr[d], dsf, dk_acc[d]);
-                }
-                __builtin_amdgcn_sched_group_barrier(0x008, 2 * DBLKS, 0);
-#else
-#pragma unroll
-                for (int d = 0; d < DBLKS; ++d) {
-                    const u32x2 a0 = lds_read_tr16(dos + swzt_row_off<D>(row_a, d * 64 + cb));
-                    const u32x2 a1 = lds_read_tr16(dos + swzt_row_off<D>(row_a + 8, d * 64 + cb));
-                    u32x4 af = {a0[0], a0[1], a1[0], a1[1]};
-                    dv_acc[d] = E::mfma(af, pf, dv_acc[d]);
-                    const u32x2 b0 = lds_read_tr16(qs + swzt_row_off<D>(row_a, d * 64 + cb));
-                    const u32x2 b1 = lds_read_tr16(qs + swzt_row_off<D>(row_a + 8, d * 64 + cb));
-                    u32x4 bfr = {b0[0], b0[1], b1[0], b1[1]};
-                    dk_acc[d] = E::mfma(bfr, dsf, dk_acc[d]);
-                }
+            unsigned long long t0 = TMR_NOW();
+            (void)t0;
+            sd(qs, dos, sub, s_acc, dp_acc);
+#ifdef FA_TIMERS
+            asm volatile("s_nop 0" :: "v"(s_acc[0]), "v"(dp_acc[0]));
 #endif
-            }
+            TMR_ADD(0, t0);
+            sm_stats(st, sub, lse2, dsum);
+            sm(q0, needs_mask(q0), lse2, dsum, s_acc, dp_acc, pf, dsf);
+#ifdef FA_TIMERS
+            asm volatile("s_nop 0" :: "v"(pf[1][3]), "v"(dsf[1][3]), "v"(pf[0][0]), "v"(dsf[0][0]));
+#endif
+            TMR_ADD(1, t0);
+            bk(qs, dos, sub, pf, dsf);
+#ifdef FA_TIMERS
+            asm volatile("s_nop 0" :: "v"(dk_acc[DBLKS - 1][0]), "v"(dv_acc[DBLKS - 1][0]));
+#endif
+            TMR_ADD(2, t0);
         }
     };
     auto step = [&](auto stage_c, int it) {
         constexpr int stage = decltype(stage_c)::value;
         const bool has_next = it + 1 < n_iter;
+        unsigned long long t0 = TMR_NOW();
+        (void)t0;
         if (has_next) load_tile(it + 1, std::integral_constant<int, stage ^ 1>{});
+        TMR_ADD(3, t0);
         compute(stage_c, it);
+        t0 = TMR_NOW();
         if (has_next) store_tile(std::integral_constant<int, stage ^ 1>{});
+        TMR_ADD(4, t0);
         __syncthreads();
+        TMR_ADD(5, t0);
+        tmr[7] += 1;
     };
 
     if (n_iter > 0) { load_tile(0, std::integral_constant<int, 0>{}); store_tile(std::integral_constant<int, 0>{}); }
@@ -413,6 +509,12 @@ __global__ void __launch_bounds__(BWD_THREADS, 1) fa_bwd_dkdv_kernel(const KArgs
         if (it + 1 < n_iter) step(std::integral_constant<int, 1>{}, it + 1);
     }
 
+#ifdef FA_TIMERS
+    if (blockIdx.x == FA_TIMERS && tid == 0) {
+        for (int i = 0; i < 8; ++i) g_timers[pass * 8 + i] = tmr[i];
+        for (int i = 0; i < 8; ++i) tmr[i] = 0;
+    }
+#endif
     // ---- epilogue: lane (key = l31, g) holds dX[my_key][32 d + 8 rq + 4 g + (0..3)] ----
     if (my_key < sg.seqlen_k) {
         const int64_t dkb = p.cu_seqlens_k ? 0 : (int64_t)b * p.dk_batch_stride;
@@ -699,6 +801,11 @@ __global__ void __launch_bounds__(BWD_THREADS, OCC) fa_bwd_dq_kernel(const KArgs
 // host
 // ---------------------------------------------------------------------------------------------
 size_t bwd_workspace_bytes(const fa_params&) { return 0; }
+#ifdef FA_TIMERS
+extern "C" int fa_debug_read_timers(unsigned long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_timers), (size_t)n * 8);
+}
+#endif
 int g_bwd_phase_mask = 7;     // fa_debug_set_bwd_phases(): measurement aid
 
 template <typename T, int D>
