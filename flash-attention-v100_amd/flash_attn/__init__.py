@@ -12,6 +12,10 @@ from flash_attn_mi355 import (
     flash_attn_varlen_gpu,
     flash_attn_with_kvcache,
     flash_attn_with_kvcache_gpu,
+    flash_attn_qkvpacked_func,
+    flash_attn_kvpacked_func,
+    flash_attn_varlen_qkvpacked_func,
+    flash_attn_varlen_kvpacked_func,
     __version__ as _backend_version,
 )
 
@@ -24,6 +28,10 @@ __all__ = [
     "flash_attn_varlen_gpu",
     "flash_attn_with_kvcache",
     "flash_attn_with_kvcache_gpu",
+    "flash_attn_qkvpacked_func",
+    "flash_attn_kvpacked_func",
+    "flash_attn_varlen_qkvpacked_func",
+    "flash_attn_varlen_kvpacked_func",
     "__version__",
 ]
 

@@ -11,6 +11,10 @@ from .flash_attn_interface import (
     flash_attn_varlen_gpu,
     flash_attn_with_kvcache,
     flash_attn_with_kvcache_gpu,
+    flash_attn_qkvpacked_func,
+    flash_attn_kvpacked_func,
+    flash_attn_varlen_qkvpacked_func,
+    flash_attn_varlen_kvpacked_func,
 )
 
 __all__ = [
@@ -20,4 +24,8 @@ __all__ = [
     "flash_attn_varlen_gpu",
     "flash_attn_with_kvcache",
     "flash_attn_with_kvcache_gpu",
+    "flash_attn_qkvpacked_func",
+    "flash_attn_kvpacked_func",
+    "flash_attn_varlen_qkvpacked_func",
+    "flash_attn_varlen_kvpacked_func",
 ]

@@ -125,82 +125,165 @@ def _base_params(q, dtype, scale, causal, window_size, softcap):
 # ======================================================================================
 # DENSE ATTENTION (B, M, H, D)
 # ======================================================================================
+def _dense_forward(q, k, v, dropout_p, softmax_scale, causal, window_size, softcap, alibi_slopes,
+                   return_softmax):
+    """One fa_fwd call on [B, S, H, D] views (any strides with a contiguous last dim)."""
+    _check_device(q, k, v)
+    if q.dtype not in _DTYPES:
+        raise RuntimeError("q must be fp16 or bf16")
+    B, M, H_Q, head_size_og = q.shape
+    N, H_K = k.shape[1], k.shape[2]
+    dpad = _padded_head_dim(head_size_og)
+    q_, k_, v_ = _prep(q, dpad), _prep(k, dpad), _prep(v, dpad)
+    if softmax_scale is None:
+        softmax_scale = head_size_og ** -0.5
+
+    out_ = torch.empty((B, M, H_Q, dpad), dtype=q.dtype, device=q.device)
+    lse = torch.empty((B, H_Q, M), dtype=torch.float32, device=q.device)
+    p = _base_params(q_, q.dtype, softmax_scale, causal, window_size, softcap)
+    p.q, p.k, p.v, p.o, p.lse = _ptr(q_), _ptr(k_), _ptr(v_), _ptr(out_), _ptr(lse)
+    _set3(p, "q", q_, "bshd"); _set3(p, "k", k_, "bshd"); _set3(p, "v", v_, "bshd")
+    _set3(p, "o", out_, "bshd")
+    p.lse_batch_stride, p.lse_head_stride = lse.stride(0), lse.stride(1)
+    p.batch, p.nheads_q, p.nheads_k = B, H_Q, H_K
+    p.seqlen_q, p.seqlen_k, p.head_dim = M, N, dpad
+    _alibi(p, alibi_slopes, B, H_Q, q.device)
+    rng = _philox(p, dropout_p, B, H_Q, q.device)
+    dmask = torch.empty((0,), dtype=q.dtype, device=q.device)
+    if return_softmax and dropout_p > 0.0:
+        dmask = torch.zeros((B, H_Q, M, N), dtype=q.dtype, device=q.device)
+        p.dmask = _ptr(dmask)
+    with torch.cuda.device(q.device):
+        _lib.call("fa_fwd", p, _stream(q.device))
+    out = out_ if dpad == head_size_og else out_[..., :head_size_og].contiguous()
+    return out, lse, dmask, (q_, k_, v_, out_), rng, softmax_scale
+
+
+def _dense_backward(dout, q_, k_, v_, out_, lse, alibi_slopes, dropout_p, softmax_scale, causal,
+                    window_size, softcap, rng, dq_, dk_, dv_):
+    """One fa_bwd call; dq_/dk_/dv_ are caller-allocated [B, S, H, dpad] views (written in place)."""
+    B, M, H_Q, dpad = q_.shape
+    N, H_K = k_.shape[1], k_.shape[2]
+    dout_ = _prep(dout, dpad)
+    softmax_d = torch.empty((B, H_Q, M), dtype=torch.float32, device=q_.device)
+    p = _base_params(q_, q_.dtype, softmax_scale, causal, window_size, softcap)
+    p.q, p.k, p.v, p.o, p.lse = _ptr(q_), _ptr(k_), _ptr(v_), _ptr(out_), _ptr(lse)
+    p.dout, p.dq, p.dk, p.dv, p.softmax_d = _ptr(dout_), _ptr(dq_), _ptr(dk_), _ptr(dv_), _ptr(softmax_d)
+    for name, t in (("q", q_), ("k", k_), ("v", v_), ("o", out_), ("do", dout_),
+                    ("dq", dq_), ("dk", dk_), ("dv", dv_)):
+        _set3(p, name, t, "bshd")
+    p.lse_batch_stride, p.lse_head_stride = lse.stride(0), lse.stride(1)
+    p.batch, p.nheads_q, p.nheads_k = B, H_Q, H_K
+    p.seqlen_q, p.seqlen_k, p.head_dim = M, N, dpad
+    _alibi(p, alibi_slopes, B, H_Q, q_.device)
+    _philox(p, dropout_p, B, H_Q, q_.device, rng=rng)
+    ws = _workspace(_lib.lib.fa_bwd_workspace_bytes(ctypes.byref(p)), q_.device)
+    if ws is not None:
+        p.workspace, p.workspace_bytes = _ptr(ws), ws.numel()
+    with torch.cuda.device(q_.device):
+        _lib.call("fa_bwd", p, _stream(q_.device))
+    return softmax_d
+
+
+def _save_dense(ctx, saved, lse, alibi_slopes, dropout_p, softmax_scale, causal, window_size, softcap,
+                deterministic, head_size_og, rng):
+    ctx.save_for_backward(*saved, lse, alibi_slopes)
+    ctx.dropout_p = dropout_p
+    ctx.softmax_scale = softmax_scale
+    ctx.causal = causal
+    ctx.window_size = window_size
+    ctx.softcap = softcap
+    ctx.deterministic = deterministic
+    ctx.head_size_og = head_size_og
+    ctx.rng = rng
+
+
 class FlashAttnFunc(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, k, v, dropout_p, softmax_scale, causal, window_size, softcap,
                 alibi_slopes, deterministic, return_softmax, is_grad_enabled):
         is_grad = is_grad_enabled and any(x.requires_grad for x in [q, k, v])
-        _check_device(q, k, v)
-        if q.dtype not in _DTYPES:
-            raise RuntimeError("q must be fp16 or bf16")
-        B, M, H_Q, head_size_og = q.shape
-        N, H_K = k.shape[1], k.shape[2]
-        dpad = _padded_head_dim(head_size_og)
-        q_, k_, v_ = _prep(q, dpad), _prep(k, dpad), _prep(v, dpad)
-        if softmax_scale is None:
-            softmax_scale = head_size_og ** -0.5
-
-        out_ = torch.empty((B, M, H_Q, dpad), dtype=q.dtype, device=q.device)
-        lse = torch.empty((B, H_Q, M), dtype=torch.float32, device=q.device)
-        p = _base_params(q_, q.dtype, softmax_scale, causal, window_size, softcap)
-        p.q, p.k, p.v, p.o, p.lse = _ptr(q_), _ptr(k_), _ptr(v_), _ptr(out_), _ptr(lse)
-        _set3(p, "q", q_, "bshd"); _set3(p, "k", k_, "bshd"); _set3(p, "v", v_, "bshd")
-        _set3(p, "o", out_, "bshd")
-        p.lse_batch_stride, p.lse_head_stride = lse.stride(0), lse.stride(1)
-        p.batch, p.nheads_q, p.nheads_k = B, H_Q, H_K
-        p.seqlen_q, p.seqlen_k, p.head_dim = M, N, dpad
-        _alibi(p, alibi_slopes, B, H_Q, q.device)
-        rng = _philox(p, dropout_p, B, H_Q, q.device)
-        dmask = torch.empty((0,), dtype=q.dtype, device=q.device)
-        if return_softmax and dropout_p > 0.0:
-            dmask = torch.zeros((B, H_Q, M, N), dtype=q.dtype, device=q.device)
-            p.dmask = _ptr(dmask)
-        with torch.cuda.device(q.device):
-            _lib.call("fa_fwd", p, _stream(q.device))
-        out = out_ if dpad == head_size_og else out_[..., :head_size_og].contiguous()
-
+        out, lse, dmask, saved, rng, softmax_scale = _dense_forward(
+            q, k, v, dropout_p, softmax_scale, causal, window_size, softcap, alibi_slopes, return_softmax)
         if is_grad:
-            ctx.save_for_backward(q_, k_, v_, out_, lse, alibi_slopes)
-            ctx.dropout_p = dropout_p
-            ctx.softmax_scale = softmax_scale
-            ctx.causal = causal
-            ctx.window_size = window_size
-            ctx.softcap = softcap
-            ctx.deterministic = deterministic
-            ctx.head_size_og = head_size_og
-            ctx.rng = rng
+            _save_dense(ctx, saved, lse, alibi_slopes, dropout_p, softmax_scale, causal, window_size,
+                        softcap, deterministic, q.shape[-1], rng)
         return (out, lse, dmask) if return_softmax else out
 
     @staticmethod
     def backward(ctx, dout, *args):
         q_, k_, v_, out_, lse, alibi_slopes = ctx.saved_tensors
-        head_size_og = ctx.head_size_og
-        B, M, H_Q, dpad = q_.shape
-        N, H_K = k_.shape[1], k_.shape[2]
-        dout_ = _prep(dout, dpad)
+        d = ctx.head_size_og
         dq_, dk_, dv_ = torch.empty_like(q_), torch.empty_like(k_), torch.empty_like(v_)
-        dq_, dk_, dv_ = (_prep(t, dpad) for t in (dq_, dk_, dv_))
-        softmax_d = torch.empty((B, H_Q, M), dtype=torch.float32, device=q_.device)
-        p = _base_params(q_, q_.dtype, ctx.softmax_scale, ctx.causal, ctx.window_size, ctx.softcap)
-        p.q, p.k, p.v, p.o, p.lse = _ptr(q_), _ptr(k_), _ptr(v_), _ptr(out_), _ptr(lse)
-        p.dout, p.dq, p.dk, p.dv, p.softmax_d = _ptr(dout_), _ptr(dq_), _ptr(dk_), _ptr(dv_), _ptr(softmax_d)
-        for name, t in (("q", q_), ("k", k_), ("v", v_), ("o", out_), ("do", dout_),
-                        ("dq", dq_), ("dk", dk_), ("dv", dv_)):
-            _set3(p, name, t, "bshd")
-        p.lse_batch_stride, p.lse_head_stride = lse.stride(0), lse.stride(1)
-        p.batch, p.nheads_q, p.nheads_k = B, H_Q, H_K
-        p.seqlen_q, p.seqlen_k, p.head_dim = M, N, dpad
-        _alibi(p, alibi_slopes, B, H_Q, q_.device)
-        _philox(p, ctx.dropout_p, B, H_Q, q_.device, rng=ctx.rng)
-        ws = _workspace(_lib.lib.fa_bwd_workspace_bytes(ctypes.byref(p)), q_.device)
-        if ws is not None:
-            p.workspace, p.workspace_bytes = _ptr(ws), ws.numel()
-        with torch.cuda.device(q_.device):
-            _lib.call("fa_bwd", p, _stream(q_.device))
-        dq = dq_[..., :head_size_og]
-        dk = dk_[..., :head_size_og]
-        dv = dv_[..., :head_size_og]
-        return dq, dk, dv, None, None, None, None, None, None, None, None, None, None
+        dq_, dk_, dv_ = (_prep(t, q_.shape[-1]) for t in (dq_, dk_, dv_))
+        _dense_backward(dout, q_, k_, v_, out_, lse, alibi_slopes, ctx.dropout_p, ctx.softmax_scale,
+                        ctx.causal, ctx.window_size, ctx.softcap, ctx.rng, dq_, dk_, dv_)
+        return (dq_[..., :d], dk_[..., :d], dv_[..., :d]) + (None,) * 10
+
+
+class FlashAttnQKVPackedFunc(torch.autograd.Function):
+    """qkv [B, S, 3, H, D]: q/k/v are strided views of the packed tensor in both directions -
+    dq/dk/dv are written straight into one dqkv allocation (no concatenation pass)."""
+
+    @staticmethod
+    def forward(ctx, qkv, dropout_p, softmax_scale, causal, window_size, softcap, alibi_slopes,
+                deterministic, return_softmax, is_grad_enabled):
+        is_grad = is_grad_enabled and qkv.requires_grad
+        q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
+        out, lse, dmask, saved, rng, softmax_scale = _dense_forward(
+            q, k, v, dropout_p, softmax_scale, causal, window_size, softcap, alibi_slopes, return_softmax)
+        if is_grad:
+            _save_dense(ctx, saved, lse, alibi_slopes, dropout_p, softmax_scale, causal, window_size,
+                        softcap, deterministic, qkv.shape[-1], rng)
+        return (out, lse, dmask) if return_softmax else out
+
+    @staticmethod
+    def backward(ctx, dout, *args):
+        q_, k_, v_, out_, lse, alibi_slopes = ctx.saved_tensors
+        d = ctx.head_size_og
+        B, S, H, dpad = q_.shape
+        dqkv = torch.empty((B, S, 3, H, dpad), dtype=q_.dtype, device=q_.device)
+        _dense_backward(dout, q_, k_, v_, out_, lse, alibi_slopes, ctx.dropout_p, ctx.softmax_scale,
+                        ctx.causal, ctx.window_size, ctx.softcap, ctx.rng,
+                        dqkv[:, :, 0], dqkv[:, :, 1], dqkv[:, :, 2])
+        return (dqkv[..., :d],) + (None,) * 9
+
+
+class FlashAttnKVPackedFunc(torch.autograd.Function):
+    """q [B, Sq, H, D], kv [B, Sk, 2, Hk, D]; dk/dv are written into one dkv allocation."""
+
+    @staticmethod
+    def forward(ctx, q, kv, dropout_p, softmax_scale, causal, window_size, softcap, alibi_slopes,
+                deterministic, return_softmax, is_grad_enabled):
+        is_grad = is_grad_enabled and any(x.requires_grad for x in [q, kv])
+        k, v = kv[:, :, 0], kv[:, :, 1]
+        out, lse, dmask, saved, rng, softmax_scale = _dense_forward(
+            q, k, v, dropout_p, softmax_scale, causal, window_size, softcap, alibi_slopes, return_softmax)
+        if is_grad:
+            _save_dense(ctx, saved, lse, alibi_slopes, dropout_p, softmax_scale, causal, window_size,
+                        softcap, deterministic, q.shape[-1], rng)
+        return (out, lse, dmask) if return_softmax else out
+
+    @staticmethod
+    def backward(ctx, dout, *args):
+        q_, k_, v_, out_, lse, alibi_slopes = ctx.saved_tensors
+        d = ctx.head_size_og
+        B, Sk, Hk, dpad = k_.shape
+        dq_ = torch.empty_like(q_)
+        dq_ = _prep(dq_, dpad)
+        dkv = torch.empty((B, Sk, 2, Hk, dpad), dtype=q_.dtype, device=q_.device)
+        _dense_backward(dout, q_, k_, v_, out_, lse, alibi_slopes, ctx.dropout_p, ctx.softmax_scale,
+                        ctx.causal, ctx.window_size, ctx.softcap, ctx.rng, dq_, dkv[:, :, 0], dkv[:, :, 1])
+        return (dq_[..., :d], dkv[..., :d]) + (None,) * 9
+
+
+def _warn_deterministic(deterministic):
+    if deterministic:
+        # the reference warns and clears the flag (flash_attn_interface.py:129-131); our backward is
+        # atomic-free, i.e. always deterministic, so the request is honoured either way.
+        warnings.warn("Forward is always deterministic. Backward on gfx950 is atomic-free and "
+                      "deterministic as well.", RuntimeWarning)
+    return False
 
 
 def flash_attn_func(q, k, v, dropout_p: float = 0.0, softmax_scale: float = None,
@@ -208,12 +291,7 @@ def flash_attn_func(q, k, v, dropout_p: float = 0.0, softmax_scale: float = None
                     softcap: float = 0.0, alibi_slopes: Optional[torch.Tensor] = None,
                     deterministic: bool = False, return_attn_probs: bool = False):
     """Dense Flash Attention (B, M, H, D)"""
-    if deterministic:
-        # the reference warns and clears the flag (flash_attn_interface.py:129-131); our
-        # backward is atomic-free, i.e. always deterministic, so the request is honoured.
-        warnings.warn("Forward is always deterministic. Backward on gfx950 is atomic-free and "
-                      "deterministic as well.", RuntimeWarning)
-        deterministic = False
+    deterministic = _warn_deterministic(deterministic)
     try:
         return FlashAttnFunc.apply(q, k, v, dropout_p, softmax_scale, causal, window_size, softcap,
                                    alibi_slopes, deterministic, return_attn_probs,
@@ -227,65 +305,103 @@ def flash_attn_func(q, k, v, dropout_p: float = 0.0, softmax_scale: float = None
 # ======================================================================================
 # VARLEN ATTENTION (T, H, D)
 # ======================================================================================
+def _varlen_forward(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, dropout_p,
+                    softmax_scale, causal, window_size, softcap, alibi_slopes, return_attn_probs,
+                    block_table):
+    """One fa_varlen_fwd call on [T, H, D] tensors (K/V optionally paged [nblk, page, Hk, D])."""
+    _check_device(q, k, v, cu_seqlens_q, cu_seqlens_k)
+    if q.dtype not in _DTYPES:
+        raise RuntimeError("q must be fp16 or bf16")
+    cu_seqlens_q = cu_seqlens_q.to(torch.int32).contiguous()
+    cu_seqlens_k = cu_seqlens_k.to(torch.int32).contiguous()
+    head_size_og = q.size(-1)
+    dpad = _padded_head_dim(head_size_og)
+    q_, k_, v_ = _prep(q, dpad), _prep(k, dpad), _prep(v, dpad)
+    if softmax_scale is None:
+        softmax_scale = head_size_og ** -0.5
+    T_Q, H_Q = q_.shape[0], q_.shape[1]
+    H_K = k_.shape[-2]
+    B = cu_seqlens_q.numel() - 1
+    paged = block_table is not None
+
+    out_ = torch.empty((T_Q, H_Q, dpad), dtype=q.dtype, device=q.device)
+    lse = torch.empty((H_Q, T_Q), dtype=torch.float32, device=q.device)
+    p = _base_params(q_, q.dtype, softmax_scale, causal, window_size, softcap)
+    p.q, p.k, p.v, p.o, p.lse = _ptr(q_), _ptr(k_), _ptr(v_), _ptr(out_), _ptr(lse)
+    _set3(p, "q", q_, "thd"); _set3(p, "o", out_, "thd")
+    _set3(p, "k", k_, "pshd" if paged else "thd"); _set3(p, "v", v_, "pshd" if paged else "thd")
+    p.lse_batch_stride, p.lse_head_stride = 0, lse.stride(0)
+    p.batch, p.nheads_q, p.nheads_k = B, H_Q, H_K
+    p.seqlen_q, p.seqlen_k, p.head_dim = int(max_seqlen_q), int(max_seqlen_k), dpad
+    p.cu_seqlens_q, p.cu_seqlens_k = _ptr(cu_seqlens_q), _ptr(cu_seqlens_k)
+    p.total_q = T_Q
+    p.total_k = 0 if paged else k_.shape[0]
+    if paged:
+        block_table = block_table.to(torch.int32).contiguous()
+        p.block_table = _ptr(block_table)
+        p.block_table_batch_stride = block_table.stride(0)
+        p.page_block_size = k_.shape[1]
+    _alibi(p, alibi_slopes, B, H_Q, q.device)
+    rng = _philox(p, dropout_p, B, H_Q, q.device)
+    dmask = torch.empty((0,), dtype=q.dtype, device=q.device)
+    if return_attn_probs and dropout_p > 0.0:
+        dmask = torch.zeros((T_Q, H_Q, max_seqlen_k), dtype=q.dtype, device=q.device)
+        p.dmask = _ptr(dmask)
+    with torch.cuda.device(q.device):
+        _lib.call("fa_varlen_fwd", p, _stream(q.device))
+    out = out_ if dpad == head_size_og else out_[..., :head_size_og].contiguous()
+    return out, lse, dmask, (q_, k_, v_, out_, cu_seqlens_q, cu_seqlens_k), rng, softmax_scale
+
+
+def _varlen_backward(dout, q_, k_, v_, out_, lse, cu_seqlens_q, cu_seqlens_k, alibi_slopes,
+                     max_seqlen_q, max_seqlen_k, dropout_p, softmax_scale, causal, window_size,
+                     softcap, rng, dq_, dk_, dv_):
+    T_Q, H_Q, dpad = q_.shape
+    H_K = k_.shape[1]
+    B = cu_seqlens_q.numel() - 1
+    dout_ = _prep(dout, dpad)
+    softmax_d = torch.empty((H_Q, T_Q), dtype=torch.float32, device=q_.device)
+    p = _base_params(q_, q_.dtype, softmax_scale, causal, window_size, softcap)
+    p.q, p.k, p.v, p.o, p.lse = _ptr(q_), _ptr(k_), _ptr(v_), _ptr(out_), _ptr(lse)
+    p.dout, p.dq, p.dk, p.dv, p.softmax_d = _ptr(dout_), _ptr(dq_), _ptr(dk_), _ptr(dv_), _ptr(softmax_d)
+    for name, t in (("q", q_), ("k", k_), ("v", v_), ("o", out_), ("do", dout_),
+                    ("dq", dq_), ("dk", dk_), ("dv", dv_)):
+        _set3(p, name, t, "thd")
+    p.lse_batch_stride, p.lse_head_stride = 0, lse.stride(0)
+    p.batch, p.nheads_q, p.nheads_k = B, H_Q, H_K
+    p.seqlen_q, p.seqlen_k, p.head_dim = int(max_seqlen_q), int(max_seqlen_k), dpad
+    p.cu_seqlens_q, p.cu_seqlens_k = _ptr(cu_seqlens_q), _ptr(cu_seqlens_k)
+    p.total_q, p.total_k = T_Q, k_.shape[0]
+    _alibi(p, alibi_slopes, B, H_Q, q_.device)
+    _philox(p, dropout_p, B, H_Q, q_.device, rng=rng)
+    ws = _workspace(_lib.lib.fa_bwd_workspace_bytes(ctypes.byref(p)), q_.device)
+    if ws is not None:
+        p.workspace, p.workspace_bytes = _ptr(ws), ws.numel()
+    with torch.cuda.device(q_.device):
+        _lib.call("fa_varlen_bwd", p, _stream(q_.device))
+    return softmax_d
+
+
 class FlashAttnVarlenFunc(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, dropout_p,
                 softmax_scale, causal, window_size, softcap, alibi_slopes, deterministic,
                 return_attn_probs, block_table, is_grad_enabled):
         is_grad = is_grad_enabled and any(x.requires_grad for x in [q, k, v])
-        _check_device(q, k, v, cu_seqlens_q, cu_seqlens_k)
-        if q.dtype not in _DTYPES:
-            raise RuntimeError("q must be fp16 or bf16")
-        cu_seqlens_q = cu_seqlens_q.to(torch.int32).contiguous()
-        cu_seqlens_k = cu_seqlens_k.to(torch.int32).contiguous()
-        head_size_og = q.size(-1)
-        dpad = _padded_head_dim(head_size_og)
-        q_, k_, v_ = _prep(q, dpad), _prep(k, dpad), _prep(v, dpad)
-        if softmax_scale is None:
-            softmax_scale = head_size_og ** -0.5
-        T_Q, H_Q = q_.shape[0], q_.shape[1]
-        H_K = k_.shape[-2]
-        B = cu_seqlens_q.numel() - 1
-        paged = block_table is not None
-
-        out_ = torch.empty((T_Q, H_Q, dpad), dtype=q.dtype, device=q.device)
-        lse = torch.empty((H_Q, T_Q), dtype=torch.float32, device=q.device)
-        p = _base_params(q_, q.dtype, softmax_scale, causal, window_size, softcap)
-        p.q, p.k, p.v, p.o, p.lse = _ptr(q_), _ptr(k_), _ptr(v_), _ptr(out_), _ptr(lse)
-        _set3(p, "q", q_, "thd"); _set3(p, "o", out_, "thd")
-        _set3(p, "k", k_, "pshd" if paged else "thd"); _set3(p, "v", v_, "pshd" if paged else "thd")
-        p.lse_batch_stride, p.lse_head_stride = 0, lse.stride(0)
-        p.batch, p.nheads_q, p.nheads_k = B, H_Q, H_K
-        p.seqlen_q, p.seqlen_k, p.head_dim = int(max_seqlen_q), int(max_seqlen_k), dpad
-        p.cu_seqlens_q, p.cu_seqlens_k = _ptr(cu_seqlens_q), _ptr(cu_seqlens_k)
-        p.total_q = T_Q
-        p.total_k = 0 if paged else k_.shape[0]
-        if paged:
-            block_table = block_table.to(torch.int32).contiguous()
-            p.block_table = _ptr(block_table)
-            p.block_table_batch_stride = block_table.stride(0)
-            p.page_block_size = k_.shape[1]
-        _alibi(p, alibi_slopes, B, H_Q, q.device)
-        rng = _philox(p, dropout_p, B, H_Q, q.device)
-        dmask = torch.empty((0,), dtype=q.dtype, device=q.device)
-        if return_attn_probs and dropout_p > 0.0:
-            dmask = torch.zeros((T_Q, H_Q, max_seqlen_k), dtype=q.dtype, device=q.device)
-            p.dmask = _ptr(dmask)
-        with torch.cuda.device(q.device):
-            _lib.call("fa_varlen_fwd", p, _stream(q.device))
-        out = out_ if dpad == head_size_og else out_[..., :head_size_og].contiguous()
-
+        out, lse, dmask, saved, rng, softmax_scale = _varlen_forward(
+            q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, dropout_p, softmax_scale,
+            causal, window_size, softcap, alibi_slopes, return_attn_probs, block_table)
         if is_grad:
-            if paged:
+            if block_table is not None:
                 raise RuntimeError("backward through paged K/V (block_table) is not supported")
-            ctx.save_for_backward(q_, k_, v_, out_, lse, cu_seqlens_q, cu_seqlens_k, alibi_slopes)
+            ctx.save_for_backward(*saved, lse, alibi_slopes)
             ctx.dropout_p = dropout_p
             ctx.softmax_scale = softmax_scale
             ctx.causal = causal
             ctx.window_size = window_size
             ctx.softcap = softcap
             ctx.deterministic = deterministic
-            ctx.head_size_og = head_size_og
+            ctx.head_size_og = q.size(-1)
             ctx.max_seqlen_q = max_seqlen_q
             ctx.max_seqlen_k = max_seqlen_k
             ctx.rng = rng
@@ -293,37 +409,14 @@ class FlashAttnVarlenFunc(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout, *args):
-        q_, k_, v_, out_, lse, cu_seqlens_q, cu_seqlens_k, alibi_slopes = ctx.saved_tensors
-        head_size_og = ctx.head_size_og
-        T_Q, H_Q, dpad = q_.shape
-        H_K = k_.shape[1]
-        B = cu_seqlens_q.numel() - 1
-        dout_ = _prep(dout, dpad)
+        q_, k_, v_, out_, cu_seqlens_q, cu_seqlens_k, lse, alibi_slopes = ctx.saved_tensors
+        d = ctx.head_size_og
         dq_, dk_, dv_ = torch.empty_like(q_), torch.empty_like(k_), torch.empty_like(v_)
-        dq_, dk_, dv_ = (_prep(t, dpad) for t in (dq_, dk_, dv_))
-        softmax_d = torch.empty((H_Q, T_Q), dtype=torch.float32, device=q_.device)
-        p = _base_params(q_, q_.dtype, ctx.softmax_scale, ctx.causal, ctx.window_size, ctx.softcap)
-        p.q, p.k, p.v, p.o, p.lse = _ptr(q_), _ptr(k_), _ptr(v_), _ptr(out_), _ptr(lse)
-        p.dout, p.dq, p.dk, p.dv, p.softmax_d = _ptr(dout_), _ptr(dq_), _ptr(dk_), _ptr(dv_), _ptr(softmax_d)
-        for name, t in (("q", q_), ("k", k_), ("v", v_), ("o", out_), ("do", dout_),
-                        ("dq", dq_), ("dk", dk_), ("dv", dv_)):
-            _set3(p, name, t, "thd")
-        p.lse_batch_stride, p.lse_head_stride = 0, lse.stride(0)
-        p.batch, p.nheads_q, p.nheads_k = B, H_Q, H_K
-        p.seqlen_q, p.seqlen_k, p.head_dim = int(ctx.max_seqlen_q), int(ctx.max_seqlen_k), dpad
-        p.cu_seqlens_q, p.cu_seqlens_k = _ptr(cu_seqlens_q), _ptr(cu_seqlens_k)
-        p.total_q, p.total_k = T_Q, k_.shape[0]
-        _alibi(p, alibi_slopes, B, H_Q, q_.device)
-        _philox(p, ctx.dropout_p, B, H_Q, q_.device, rng=ctx.rng)
-        ws = _workspace(_lib.lib.fa_bwd_workspace_bytes(ctypes.byref(p)), q_.device)
-        if ws is not None:
-            p.workspace, p.workspace_bytes = _ptr(ws), ws.numel()
-        with torch.cuda.device(q_.device):
-            _lib.call("fa_varlen_bwd", p, _stream(q_.device))
-        dq = dq_[..., :head_size_og]
-        dk = dk_[..., :head_size_og]
-        dv = dv_[..., :head_size_og]
-        return (dq, dk, dv) + (None,) * 14
+        dq_, dk_, dv_ = (_prep(t, q_.shape[-1]) for t in (dq_, dk_, dv_))
+        _varlen_backward(dout, q_, k_, v_, out_, lse, cu_seqlens_q, cu_seqlens_k, alibi_slopes,
+                         ctx.max_seqlen_q, ctx.max_seqlen_k, ctx.dropout_p, ctx.softmax_scale,
+                         ctx.causal, ctx.window_size, ctx.softcap, ctx.rng, dq_, dk_, dv_)
+        return (dq_[..., :d], dk_[..., :d], dv_[..., :d]) + (None,) * 14
 
 
 def flash_attn_varlen_func(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q: int,
@@ -333,10 +426,7 @@ def flash_attn_varlen_func(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q: in
                            deterministic: bool = False, return_attn_probs: bool = False,
                            block_table: Optional[torch.Tensor] = None):
     """Varlen Flash Attention (T, H, D)"""
-    if deterministic:
-        warnings.warn("Forward is always deterministic. Backward on gfx950 is atomic-free and "
-                      "deterministic as well.", RuntimeWarning)
-        deterministic = False
+    deterministic = _warn_deterministic(deterministic)
     try:
         return FlashAttnVarlenFunc.apply(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q,
                                          max_seqlen_k, dropout_p, softmax_scale, causal,
@@ -442,6 +532,54 @@ def flash_attn_with_kvcache(q, k_cache, v_cache, k=None, v=None, rotary_cos=None
     return out
 
 
+# ======================================================================================
+# PACKED ENTRY POINTS (upstream flash-attn API)
+# ======================================================================================
+def flash_attn_qkvpacked_func(qkv, dropout_p: float = 0.0, softmax_scale: float = None,
+                              causal: bool = False, window_size: Tuple[int, int] = (-1, -1),
+                              softcap: float = 0.0, alibi_slopes: Optional[torch.Tensor] = None,
+                              deterministic: bool = False, return_attn_probs: bool = False):
+    """qkv: (B, S, 3, H, D).  Same semantics as flash_attn_func(qkv[:,:,0], qkv[:,:,1], qkv[:,:,2])."""
+    deterministic = _warn_deterministic(deterministic)
+    return FlashAttnQKVPackedFunc.apply(qkv, dropout_p, softmax_scale, causal, window_size, softcap,
+                                        alibi_slopes, deterministic, return_attn_probs,
+                                        torch.is_grad_enabled())
+
+
+def flash_attn_kvpacked_func(q, kv, dropout_p: float = 0.0, softmax_scale: float = None,
+                             causal: bool = False, window_size: Tuple[int, int] = (-1, -1),
+                             softcap: float = 0.0, alibi_slopes: Optional[torch.Tensor] = None,
+                             deterministic: bool = False, return_attn_probs: bool = False):
+    """q: (B, Sq, H, D), kv: (B, Sk, 2, Hk, D)."""
+    deterministic = _warn_deterministic(deterministic)
+    return FlashAttnKVPackedFunc.apply(q, kv, dropout_p, softmax_scale, causal, window_size, softcap,
+                                       alibi_slopes, deterministic, return_attn_probs,
+                                       torch.is_grad_enabled())
+
+
+def flash_attn_varlen_qkvpacked_func(qkv, cu_seqlens, max_seqlen: int, dropout_p: float = 0.0,
+                                     softmax_scale: float = None, causal: bool = False,
+                                     window_size: Tuple[int, int] = (-1, -1), softcap: float = 0.0,
+                                     alibi_slopes: Optional[torch.Tensor] = None,
+                                     deterministic: bool = False, return_attn_probs: bool = False):
+    """qkv: (T, 3, H, D) - strided views into the packed tensor, no unpacking copy in forward."""
+    return flash_attn_varlen_func(qkv[:, 0], qkv[:, 1], qkv[:, 2], cu_seqlens, cu_seqlens, max_seqlen,
+                                  max_seqlen, dropout_p, softmax_scale, causal, window_size, softcap,
+                                  alibi_slopes, deterministic, return_attn_probs)
+
+
+def flash_attn_varlen_kvpacked_func(q, kv, cu_seqlens_q, cu_seqlens_k, max_seqlen_q: int,
+                                    max_seqlen_k: int, dropout_p: float = 0.0,
+                                    softmax_scale: float = None, causal: bool = False,
+                                    window_size: Tuple[int, int] = (-1, -1), softcap: float = 0.0,
+                                    alibi_slopes: Optional[torch.Tensor] = None,
+                                    deterministic: bool = False, return_attn_probs: bool = False):
+    """q: (Tq, H, D), kv: (Tk, 2, Hk, D)."""
+    return flash_attn_varlen_func(q, kv[:, 0], kv[:, 1], cu_seqlens_q, cu_seqlens_k, max_seqlen_q,
+                                  max_seqlen_k, dropout_p, softmax_scale, causal, window_size, softcap,
+                                  alibi_slopes, deterministic, return_attn_probs)
+
+
 flash_attn_gpu = flash_attn_func
 flash_attn_varlen_gpu = flash_attn_varlen_func
 flash_attn_with_kvcache_gpu = flash_attn_with_kvcache
@@ -450,4 +588,6 @@ __all__ = [
     "flash_attn_func", "flash_attn_gpu",
     "flash_attn_varlen_func", "flash_attn_varlen_gpu",
     "flash_attn_with_kvcache", "flash_attn_with_kvcache_gpu",
+    "flash_attn_qkvpacked_func", "flash_attn_kvpacked_func",
+    "flash_attn_varlen_qkvpacked_func", "flash_attn_varlen_kvpacked_func",
 ]
