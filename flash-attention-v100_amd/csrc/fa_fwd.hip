@@ -34,7 +34,8 @@ template <int D> struct FwdSmem {
     static constexpr int TOTAL = 2 * STAGE;            // double buffered
 };
 
-template <typename T, int D, bool BIAS, bool PAGED, bool DROPOUT>
+// BIAS: 0 none, 1 general (ALiBi and/or softcap per element), 2 causal ALiBi through the matrix pipe
+template <typename T, int D, int BIAS, bool PAGED, bool DROPOUT>
 __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : 2)) fa_fwd_kernel(const KArgs a) {
     using E = Elem<T>;
     constexpr int KSTEPS = D / 16;
@@ -244,7 +245,26 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : 2)) fa_fwd_kernel(
     for (int ks = 0; ks < KSTEPS; ++ks) k_rd[ks] = swz_row_off<D>(l31, 32 * ks + 16 * g);
     const int v_rr = (lane & 15) >> 2;                                  // row within a 4-row transpose group
     const int v_cb = (((lane >> 4) & 1) << 5) + ((lane & 3) << 3);       // byte column within a 64-byte d-block
-    const float c = BIAS ? 1.0f : a.scale_log2e;
+    // ALiBi fast path ("rank-2 update"): when every visible key is at or left of the diagonal
+    // (causal / window_right == 0) and there is no softcap, the bias -slope (i + off - j) is linear
+    // in the key position j = n0 + pos.  Its row- and tile-constant part slope (n0 - i - off) only
+    // shifts the row maximum (`shift`, one VALU per tile); the pos-dependent part slope * pos is
+    // added by the matrix pipe: one extra MFMA per 32-key block whose A operand holds pos (exact
+    // in 16 bits) in contraction slots 0 and 1 and whose B operand holds slope / softmax_scale
+    // split into a 16-bit head and tail.  No per-element VALU work is left, versus 5 per element
+    // on the general path below (measured at BASELINE config 5's shard: 652 -> see DESIGN.md).
+    constexpr bool lin = BIAS == 2;        // host guarantees: slopes given, no softcap, wr == 0
+    const float c = (BIAS && !lin) ? 1.0f : a.scale_log2e;
+    const float slope2 = slope * kLog2e;
+    u32x4 pos_a[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    u32x4 slope_b = {0, 0, 0, 0};
+    if (BIAS && lin && g == 0) {
+        const float sv = slope / p.softmax_scale;
+        const float head = E::lo(E::pack2(sv, 0.f));
+        slope_b[0] = E::pack2(head, sv - head);
+        pos_a[0][0] = E::pack2((float)l31, (float)l31);
+        pos_a[1][0] = E::pack2((float)(32 + l31), (float)(32 + l31));
+    }
 
     // one KV tile for this wave; STAGE is a compile-time constant (all LDS offsets immediates)
     auto compute_tile = [&](auto stage_c, int nb) {
@@ -269,7 +289,13 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : 2)) fa_fwd_kernel(
         __builtin_amdgcn_s_setprio(0);
 #endif
         // ---- bias / softcap (rare variants), then masking on edge tiles ----
-        if (BIAS) {
+        float shift = 0.f;
+        if (BIAS && lin) {
+            sacc[0] = E::mfma(pos_a[0], slope_b, sacc[0]);
+            sacc[1] = E::mfma(pos_a[1], slope_b, sacc[1]);
+            shift = slope2 * (float)(n0 - my_row - off);
+        }
+        if (BIAS && !lin) {
             const float cap = p.softcap;
             const float rcap = cap > 0.f ? 1.0f / cap : 0.f;
 #pragma unroll
@@ -301,6 +327,7 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : 2)) fa_fwd_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[1][r]);
         mx = xhalf_max(mx) * c;
+        if (BIAS) mx += shift;
         // keep the old max unless some row of the wave would exceed it by > 2^THR
         // (NaN-safe: -inf - -inf compares false -> takes the rescale path)
         if (!__all(mx - m_run <= FWD_RESCALE_THR)) {
@@ -315,12 +342,13 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : 2)) fa_fwd_kernel(
                 for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
         }
         const float m_use = (m_run == -INFINITY) ? 0.f : m_run;
+        const float ms = BIAS ? m_use - shift : m_use;
         float psum = 0.f;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float e = fast_exp2(fmaf(sacc[kb][r], c, -m_use));
+                const float e = fast_exp2(fmaf(sacc[kb][r], c, -ms));
                 sacc[kb][r] = e;
                 psum += e;
             }
@@ -430,9 +458,14 @@ static int launch_fwd_td(const KArgs& a, bool paged, hipStream_t stream) {
         hipLaunchKernelGGL(kern, dim3(grid), dim3(FWD_THREADS), smem, stream, a);               \
     } while (0)
     const bool drop = a.p.p_dropout > 0.f;
-    if (drop) { if (a.has_bias) FA_LAUNCH(true, false, true); else FA_LAUNCH(false, false, true); }
-    else if (a.has_bias) { if (paged) FA_LAUNCH(true, true, false); else FA_LAUNCH(true, false, false); }
-    else            { if (paged) FA_LAUNCH(false, true, false); else FA_LAUNCH(false, false, false); }
+    const bool lin_alibi = a.p.alibi_slopes && a.p.softcap <= 0.f && (a.p.is_causal || a.p.window_right == 0);
+    if (drop) { if (a.has_bias) FA_LAUNCH(1, false, true); else FA_LAUNCH(0, false, true); }
+    else if (a.has_bias) {
+        if (paged) FA_LAUNCH(1, true, false);
+        else if (lin_alibi) FA_LAUNCH(2, false, false);
+        else FA_LAUNCH(1, false, false);
+    }
+    else            { if (paged) FA_LAUNCH(0, true, false); else FA_LAUNCH(0, false, false); }
 #undef FA_LAUNCH
     return 0;
 }

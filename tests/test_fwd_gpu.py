@@ -54,6 +54,13 @@ CASES = [
     (2, 4, 2, 256, 256, 128, "bf16", False, (-1, -1), 30.0, False),   # softcap
     (1, 4, 4, 192, 192, 64, "fp16", True, (-1, -1), 15.0, True),      # ALiBi then softcap
     (1, 2, 2, 512, 512, 128, "bf16", True, (-1, -1), 0.0, False),     # multi q-block
+    # ALiBi: the causal / window_right == 0 cases take the rank-2 MFMA fast path, the others the general one
+    (2, 8, 2, 700, 700, 128, "bf16", True, (-1, -1), 0.0, True),      # fast path, GQA, several tiles
+    (1, 4, 4, 300, 520, 64, "fp16", True, (-1, -1), 0.0, True),       # fast path, Sq < Sk (off > 0)
+    (1, 4, 4, 520, 300, 128, "bf16", True, (-1, -1), 0.0, True),      # fast path, Sq > Sk (empty rows)
+    (1, 4, 4, 640, 640, 128, "bf16", False, (200, 0), 0.0, True),     # fast path via window_right == 0
+    (1, 4, 4, 320, 320, 128, "bf16", False, (-1, -1), 0.0, True),     # general path (keys right of the diagonal)
+    (1, 4, 4, 320, 320, 64, "fp16", False, (64, 32), 0.0, True),      # general path, two-sided window
 ]
 
 

@@ -45,6 +45,7 @@ def run(B=128, H=32, Hk=32, D=128, L=8192, page=256, dtype=torch.float16, kv_dty
     nbytes = 2.0 * B * (L + 1) * Hk * D * kc.element_size()
     print(f"B{B} H{H}/{Hk} D{D} L{L} page{page} kv={kv_dtype}: {ms:.3f} ms  {nbytes/ms/1e6:.0f} GB/s "
           f"({nbytes/ms/1e6/8000*100:.1f}% of 8 TB/s)", flush=True)
+    return ms
 
 
 if __name__ == "__main__":
