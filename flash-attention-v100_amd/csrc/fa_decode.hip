@@ -39,14 +39,31 @@ struct DecArgs {
     float* lse_partial;        // [n_splits, B, Hq, T_q]
 };
 
+// 16 x fp8-e4m3 -> 16 x 16-bit with gfx950's packed converts: one VALU op per TWO elements
+// (v_cvt_scalef32_pk_{f16,bf16}_fp8; probed in tools/probes/probe_cvt_scalef32.hip: exact for all
+// 256 byte patterns at scale 1.0, and the f32 scale operand contributes only its exponent - so the
+// cache descales stay folded into the softmax scale / the final normalisation).
+template <typename T>
+__device__ __forceinline__ uint32_t fp8x2_to_16bit(uint32_t w, bool hi_word);
+template <>
+__device__ __forceinline__ uint32_t fp8x2_to_16bit<fp16_tag>(uint32_t w, bool hi_word) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const h2 r = hi_word ? __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w, 1.0f, true)
+                         : __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w, 1.0f, false);
+    return __builtin_bit_cast(uint32_t, r);
+}
+template <>
+__device__ __forceinline__ uint32_t fp8x2_to_16bit<bf16_tag>(uint32_t w, bool hi_word) {
+    typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+    const b2 r = hi_word ? __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w, 1.0f, true)
+                         : __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w, 1.0f, false);
+    return __builtin_bit_cast(uint32_t, r);
+}
 template <typename T>
 __device__ __forceinline__ void fp8x16_to_16bit(const u32x4& in, u32x4& lo, u32x4& hi) {
-    using E = Elem<T>;
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
-        const f32x2 a = __builtin_amdgcn_cvt_pk_f32_fp8(in[w], false);
-        const f32x2 b = __builtin_amdgcn_cvt_pk_f32_fp8(in[w], true);
-        const uint32_t p0 = E::pack2(a[0], a[1]), p1 = E::pack2(b[0], b[1]);
+        const uint32_t p0 = fp8x2_to_16bit<T>(in[w], false), p1 = fp8x2_to_16bit<T>(in[w], true);
         if (w < 2) { lo[2 * w] = p0; lo[2 * w + 1] = p1; }
         else       { hi[2 * (w - 2)] = p0; hi[2 * (w - 2) + 1] = p1; }
     }
@@ -133,7 +150,16 @@ __global__ void __launch_bounds__(DEC_THREADS, 1) fa_decode_kernel(const DecArgs
     const uint8_t* kbase = reinterpret_cast<const uint8_t*>(p.k) + (int64_t)hk * p.k_head_stride * EB;
     const uint8_t* vbase = reinterpret_cast<const uint8_t*>(p.v) + (int64_t)hk * p.v_head_stride * EB;
     const int32_t* btab = PAGED ? p.block_table + (int64_t)b * p.block_table_batch_stride : nullptr;
-    u32x4 kA[CH], vA[CH], kB[CH], vB[CH];                 // two register sets: two tiles in flight
+    // register sets = tiles in flight per wave.  An fp8 tile is half the bytes of a 16-bit one, and
+    // with two sets the CU had only 64 KiB in flight (3.0 TB/s, latency-bound): fp8 uses four.
+#ifndef FA_DEC_NS8
+#define FA_DEC_NS8 4
+#endif
+#ifndef FA_DEC_NS16
+#define FA_DEC_NS16 2
+#endif
+    constexpr int NS = KV8 ? FA_DEC_NS8 : FA_DEC_NS16;
+    u32x4 kS[NS][CH], vS[NS][CH];
     // loop-invariant per-lane byte offsets inside a tile (row * row_stride + 16-byte column)
     uint32_t k_voff[CH], v_voff[CH];
 #pragma unroll
@@ -145,30 +171,31 @@ __global__ void __launch_bounds__(DEC_THREADS, 1) fa_decode_kernel(const DecArgs
     }
     // a 32-key tile lies inside one page when the left pad keeps tiles 32-aligned (page % 64 == 0)
     const bool tiles_aligned = !PAGED || ((lp & (DEC_BN - 1)) == 0);
+    // a full, page-aligned tile: ONE scalar base per tile, no predication, no branch (so that the
+    // compiler can count the loads in flight: see the steady-state loop below)
+    auto load_fast = [&](int tile, u32x4 (&kreg)[CH], u32x4 (&vreg)[CH]) {
+        const int pos0 = lp + tile * DEC_BN;
+        int64_t ko, vo;
+        if (PAGED) {
+            const int pg = da.page_shift >= 0 ? (pos0 >> da.page_shift) : pos0 / p.page_block_size;
+            const int pr = pos0 - pg * p.page_block_size;
+            const int64_t phys = btab[pg];
+            ko = phys * p.k_batch_stride + (int64_t)pr * p.k_row_stride;
+            vo = phys * p.v_batch_stride + (int64_t)pr * p.v_row_stride;
+        } else {
+            ko = (int64_t)cb * p.k_batch_stride + (int64_t)pos0 * p.k_row_stride;
+            vo = (int64_t)cb * p.v_batch_stride + (int64_t)pos0 * p.v_row_stride;
+        }
+        const uint8_t* kb = kbase + ko * EB;
+        const uint8_t* vb = vbase + vo * EB;
+#pragma unroll
+        for (int i = 0; i < CH; ++i) kreg[i] = *reinterpret_cast<const u32x4*>(kb + k_voff[i]);
+#pragma unroll
+        for (int i = 0; i < CH; ++i) vreg[i] = *reinterpret_cast<const u32x4*>(vb + v_voff[i]);
+    };
     auto load_tile = [&](int tile, u32x4 (&kreg)[CH], u32x4 (&vreg)[CH]) {
         const int j0 = tile * DEC_BN;
-        if (tiles_aligned && j0 + DEC_BN <= seqlen_k) {
-            // fast path: ONE scalar base per tile, no predication
-            const int pos0 = lp + j0;
-            int64_t ko, vo;
-            if (PAGED) {
-                const int pg = da.page_shift >= 0 ? (pos0 >> da.page_shift) : pos0 / p.page_block_size;
-                const int pr = pos0 - pg * p.page_block_size;
-                const int64_t phys = btab[pg];
-                ko = phys * p.k_batch_stride + (int64_t)pr * p.k_row_stride;
-                vo = phys * p.v_batch_stride + (int64_t)pr * p.v_row_stride;
-            } else {
-                ko = (int64_t)cb * p.k_batch_stride + (int64_t)pos0 * p.k_row_stride;
-                vo = (int64_t)cb * p.v_batch_stride + (int64_t)pos0 * p.v_row_stride;
-            }
-            const uint8_t* kb = kbase + ko * EB;
-            const uint8_t* vb = vbase + vo * EB;
-#pragma unroll
-            for (int i = 0; i < CH; ++i) kreg[i] = *reinterpret_cast<const u32x4*>(kb + k_voff[i]);
-#pragma unroll
-            for (int i = 0; i < CH; ++i) vreg[i] = *reinterpret_cast<const u32x4*>(vb + v_voff[i]);
-            return;
-        }
+        if (tiles_aligned && j0 + DEC_BN <= seqlen_k) { load_fast(tile, kreg, vreg); return; }
 #pragma unroll 1
         for (int i = 0; i < CH; ++i) {
             const int cidx = lane + 64 * i;
@@ -279,24 +306,50 @@ __global__ void __launch_bounds__(DEC_THREADS, 1) fa_decode_kernel(const DecArgs
         }
     };
 
-    // pipeline: LDS stage s holds tile t; register set X holds t+4 (landing), Y loads t+8.
+    // pipeline over this wave's tiles t0 + 4 s: LDS stage s & 1 holds tile s while the register sets
+    // hold tiles s+1 .. s+NS-1 (landed / landing) and the set just stored is re-loaded with s+1+NS.
     const int t0 = s_lo + wave;
-    if (t0 < s_hi) {
-        load_tile(t0, kA, vA);
-        if (t0 + 4 < s_hi) load_tile(t0 + 4, kB, vB);
-        store_tile(0, kA, vA);
-        if (t0 + 8 < s_hi) load_tile(t0 + 8, kA, vA);
+    const int n_my = t0 < s_hi ? (s_hi - t0 + 3) / 4 : 0;
+    // my tiles that lie completely inside [0, seqlen_k): s < n_full
+    const int n_full = t0 < s_hi ? ((seqlen_k / DEC_BN < s_hi ? seqlen_k / DEC_BN : s_hi) - t0 + 3) / 4 : 0;
+    int s0 = 0;
+    if (tiles_aligned && 2 * NS < n_full) {
+        // steady state: every store / load is unconditional, so the vmcnt waits in front of the
+        // stores are exact counts (NS - 1 tiles stay in flight) instead of conservative drains
+#pragma unroll
+        for (int j = 0; j < NS; ++j) load_fast(t0 + 4 * j, kS[j], vS[j]);
+        store_tile(0, kS[0], vS[0]);
+        load_fast(t0 + 4 * NS, kS[0], vS[0]);
+        for (; s0 + 2 * NS < n_full; s0 += NS) {
+#pragma unroll
+            for (int j = 0; j < NS; ++j) {
+                const int nxt = (j + 1) % NS;
+                store_tile((j + 1) & 1, kS[nxt], vS[nxt]);
+                load_fast(t0 + 4 * (s0 + j + 1 + NS), kS[nxt], vS[nxt]);
+                compute_tile(t0 + 4 * (s0 + j), j & 1);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < NS; ++j)
+            if (j < n_my) load_tile(t0 + 4 * j, kS[j], vS[j]);
+        if (n_my > 0) {
+            store_tile(0, kS[0], vS[0]);
+            if (NS < n_my) load_tile(t0 + 4 * NS, kS[0], vS[0]);
+        }
     }
-    for (int tile = t0; tile < s_hi; tile += 8) {
-        // even step: stage 0 holds `tile`; B holds tile+4; A is loading tile+8
-        if (tile + 4 < s_hi) store_tile(1, kB, vB);
-        if (tile + 12 < s_hi) load_tile(tile + 12, kB, vB);
-        compute_tile(tile, 0);
-        if (tile + 4 >= s_hi) break;
-        // odd step: stage 1 holds tile+4; A holds tile+8; B is loading tile+12
-        if (tile + 8 < s_hi) store_tile(0, kA, vA);
-        if (tile + 16 < s_hi) load_tile(tile + 16, kA, vA);
-        compute_tile(tile + 4, 1);
+    // remaining tiles (and short sequences): same schedule with every step guarded
+    for (; s0 < n_my; s0 += NS) {
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+            const int ss = s0 + j;
+            if (ss < n_my) {
+                const int nxt = (j + 1) % NS;              // compile-time after unrolling
+                if (ss + 1 < n_my) store_tile((j + 1) & 1, kS[nxt], vS[nxt]);
+                if (ss + 1 + NS < n_my) load_tile(t0 + 4 * (ss + 1 + NS), kS[nxt], vS[nxt]);
+                compute_tile(t0 + 4 * ss, j & 1);
+            }
+        }
     }
 
     // ---- merge the 4 waves through LDS ----
