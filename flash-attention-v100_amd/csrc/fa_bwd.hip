@@ -447,6 +447,19 @@ __global__ void __launch_bounds__(BWD_THREADS, 1) fa_bwd_dkdv_kernel(const KArgs
         }
     };
 
+    // dS tiles produced in this step, stored after the step's LDS writes (see compute)
+    u32x4 ds_chunk[DKV_BQ / 32][2];
+    char* ds_tile[DKV_BQ / 32];
+    uint32_t ds_pending = 0;
+    auto flush_ds = [&]() {
+#pragma unroll
+        for (int sub = 0; sub < DKV_BQ / 32; ++sub)
+            if (ds_pending & (1u << sub)) {
+                *reinterpret_cast<u32x4*>(ds_tile[sub]) = ds_chunk[sub][0];
+                *reinterpret_cast<u32x4*>(ds_tile[sub] + 1024) = ds_chunk[sub][1];
+            }
+        ds_pending = 0;
+    };
     auto compute = [&](auto stage_c, int it) {
         constexpr int stage = decltype(stage_c)::value;
         constexpr int NSUB = DKV_BQ / 32;
@@ -479,6 +492,25 @@ __global__ void __launch_bounds__(BWD_THREADS, 1) fa_bwd_dkdv_kernel(const KArgs
             asm volatile("s_nop 0" :: "v"(pf[1][3]), "v"(dsf[1][3]), "v"(pf[0][0]), "v"(dsf[0][0]));
 #endif
             TMR_ADD(1, t0);
+            if (a.ds_ws) {
+                // hand dS to the dQ kernel: after one half-exchange per register pair a lane holds 8
+                // consecutive query rows of its key (16 bytes) -> two coalesced 1-KiB stores per sub-tile.
+                // Tile layout: [t = 16-row group][key][row-octet g][8 rows].  The stores are issued at
+                // the END of the step (flush_ds): vmcnt counts stores too, and stores issued before the
+                // wait on the next tile's loads would put their latency on the critical path.
+                const int h = hk * group + gq;
+                ds_tile[sub] = reinterpret_cast<char*>(a.ds_ws) +
+                               ((((int64_t)b * p.nheads_q + h) * a.ds_nqb + (q0 >> 5)) * a.ds_nkb + (kw0 >> 5)) * 2048 +
+                               l31 * 32 + g * 16;
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    uint32_t x0 = dsf[t][0], x1 = dsf[t][1], y0 = dsf[t][2], y1 = dsf[t][3];
+                    permlane32_swap(x0, y0);
+                    permlane32_swap(x1, y1);
+                    ds_chunk[sub][t] = u32x4{x0, x1, y0, y1};
+                }
+                ds_pending |= 1u << sub;
+            }
             bk(qs, dos, sub, pf, dsf);
 #ifdef FA_TIMERS
             asm volatile("s_nop 0" :: "v"(dk_acc[DBLKS - 1][0]), "v"(dv_acc[DBLKS - 1][0]));
@@ -496,6 +528,7 @@ __global__ void __launch_bounds__(BWD_THREADS, 1) fa_bwd_dkdv_kernel(const KArgs
         compute(stage_c, it);
         t0 = TMR_NOW();
         if (has_next) store_tile(std::integral_constant<int, stage ^ 1>{});
+        flush_ds();
         TMR_ADD(4, t0);
         __syncthreads();
         TMR_ADD(5, t0);
@@ -798,9 +831,190 @@ __global__ void __launch_bounds__(BWD_THREADS, OCC) fa_bwd_dq_kernel(const KArgs
 }
 
 // ---------------------------------------------------------------------------------------------
+// 3b. dQ from the dS tiles written by the dK/dV kernel:  dQ = scale * dS K   (one GEMM, no exp)
+// ---------------------------------------------------------------------------------------------
+// Workgroup = 128 query rows (32 per wave).  K tiles (64 keys) are shared through LDS (LDS-DMA,
+// transposable swizzle); every wave DMA-loads its own two 2-KiB dS tiles per K tile into a private
+// LDS area and reads them back with ds_read_b64_tr_b16 as the B operand of dQ^T += K^T dS^T.
+// It reads B*Hq*pairs*2 bytes of dS instead of recomputing S and dP (16 of the 24 MFMAs per
+// sub-tile of fa_bwd_dq_kernel): HBM-bound where the other one is matrix-pipe bound.
+template <int D> struct DqdsSmem {
+    static constexpr int KTILE = DQ_BN * D * 2;
+    static constexpr int DS = 4 * 2 * 2048;              // 4 waves x 2 key blocks
+    static constexpr int STAGE = KTILE + DS;
+    static constexpr int TOTAL = 2 * STAGE;
+};
+
+template <typename T, int D>
+__global__ void __launch_bounds__(BWD_THREADS, 2) fa_bwd_dq_from_ds_kernel(const KArgs a) {
+    using E = Elem<T>;
+    constexpr int DBLKS = D / 32;
+    constexpr int CPR = D / 8;
+    constexpr int CHUNKS = DQ_BN * CPR / BWD_THREADS;
+    constexpr int KTILE = DqdsSmem<D>::KTILE;
+    constexpr int STAGE = DqdsSmem<D>::STAGE;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const fa_params& p = a.p;
+    const WorkItem w = decode_work(blockIdx.x, p.batch, p.nheads_q, p.nheads_k, a.n_qblocks);
+    if (!w.valid) return;
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, g = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const SeqGeom sg = seq_geom(p, w.b);
+    const int off = sg.off;
+    const int wl = p.window_left;
+    const int wr = p.is_causal ? 0 : p.window_right;
+
+    const int64_t kb_off = p.cu_seqlens_k ? 0 : (int64_t)w.b * p.k_batch_stride;
+    const uint16_t* kp = reinterpret_cast<const uint16_t*>(p.k) + kb_off + sg.k_row0 * p.k_row_stride + (int64_t)w.hk * p.k_head_stride;
+    const __amdgpu_buffer_rsrc_t k_rsrc = make_rsrc(kp, p.k_row_stride, sg.seqlen_k, D);
+    const uint32_t k_tile_bytes = (uint32_t)(DQ_BN * p.k_row_stride * 2);
+    constexpr int ROWS_PI = 64 / CPR;
+    uint32_t k_voff[CHUNKS];
+    int k_lds[CHUNKS];
+#pragma unroll
+    for (int i = 0; i < CHUNKS; ++i) {
+        const int inst = wave * CHUNKS + i;
+        const int row = inst * ROWS_PI + lane / CPR;
+        const int k_cb = swzt_row_off<D>(row, (lane % CPR) * 16) - row * D * 2;
+        k_voff[i] = (uint32_t)(row * p.k_row_stride * 2 + k_cb);
+        k_lds[i] = inst * 1024;
+    }
+    // dS tiles of this (batch, head): one descriptor, tile offsets travel in the scalar offset.
+    // LDS image of a tile: [key][64 B = 32 query rows]; DMA lane L of instruction j lands on row
+    // 16 j + L/4, 16-byte chunk c = L & 3 (row octet) = global piece (t = c >> 1, g = c & 1).
+    const int64_t ds_head = ((int64_t)w.b * p.nheads_q + w.h) * a.ds_nqb * (int64_t)a.ds_nkb * 2048;
+    const char* ds_base = reinterpret_cast<const char*>(a.ds_ws) + ds_head;
+    const uint32_t ds_lim = (uint32_t)((int64_t)a.ds_nqb * a.ds_nkb * 2048 > 0xffffffffll ? 0xffffffffll
+                                                                                          : (int64_t)a.ds_nqb * a.ds_nkb * 2048);
+    const __amdgpu_buffer_rsrc_t ds_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(ds_base), 0, (int)__builtin_amdgcn_readfirstlane(ds_lim), 0x00020000);
+    uint32_t ds_voff[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = 16 * j + (lane >> 2), cch = lane & 3;
+        ds_voff[j] = (uint32_t)((cch >> 1) * 1024 + row * 32 + (cch & 1) * 16);
+    }
+    const int rr = (lane & 15) >> 2;
+    const int cb = (((lane >> 4) & 1) << 5) + ((lane & 3) << 3);
+
+    const int n_pass = (a.pair_qblocks && (a.n_qblocks_total - 1 - w.qb) != w.qb) ? 2 : 1;
+    for (int pass = 0; pass < n_pass; ++pass) {
+    const int qb_cur = pass == 0 ? w.qb : a.n_qblocks_total - 1 - w.qb;
+    const int m_block = qb_cur * DQ_BM;
+    if (m_block >= sg.seqlen_q) continue;
+    int n_min = 0, n_max = (sg.seqlen_k + DQ_BN - 1) / DQ_BN;
+    {
+        const int m_last = (m_block + DQ_BM < sg.seqlen_q ? m_block + DQ_BM : sg.seqlen_q) - 1;
+        if (wr >= 0) {
+            const int kmax = m_last + off + wr;
+            const int t = kmax < 0 ? 0 : kmax / DQ_BN + 1;
+            n_max = t < n_max ? t : n_max;
+        }
+        if (wl >= 0) { const int kmin = m_block + off - wl; if (kmin > 0) n_min = kmin / DQ_BN; }
+    }
+    const int wave_row0 = m_block + wave * 32;
+    const int my_row = wave_row0 + l31;
+    const int64_t qrow_tiles = (int64_t)(wave_row0 >> 5) * a.ds_nkb;     // tile index of (my 32 rows, key block 0)
+
+    auto active = [&](int nb, int kb) {
+        return wave_row0 < sg.seqlen_q && subtile_active(wave_row0, nb * DQ_BN + kb * 32, sg.seqlen_q, sg.seqlen_k, off, wl, wr);
+    };
+    auto load_tile = [&](int nb, auto stage_c) {
+        constexpr int stage = decltype(stage_c)::value;
+        char* base = smem + stage * STAGE;
+        const uint32_t ks_off = (uint32_t)nb * k_tile_bytes;
+#pragma unroll
+        for (int i = 0; i < CHUNKS; ++i) buf_load_lds_b128(k_rsrc, base + k_lds[i], k_voff[i], ks_off);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            if (!active(nb, kb)) continue;
+            const int64_t tile_off = (qrow_tiles + nb * 2 + kb) * 2048;
+            char* dst = base + KTILE + (wave * 2 + kb) * 2048;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) buf_load_lds_b128(ds_rsrc, dst + j * 1024, ds_voff[j], (uint32_t)tile_off);
+        }
+    };
+
+    f32x16 dq_acc[DBLKS];
+#pragma unroll
+    for (int d = 0; d < DBLKS; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dq_acc[d][r] = 0.f;
+
+    auto compute = [&](auto stage_c, int nb) {
+        constexpr int stage = decltype(stage_c)::value;
+        const char* sbase = smem + stage * STAGE;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            if (!active(nb, kb)) continue;
+            const char* dsb = sbase + KTILE + (wave * 2 + kb) * 2048;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                // B = dS^T: lane (query l31, g) takes keys 16 t + 8 g + (0..7) of its column
+                const u32x2 b0 = lds_read_tr16(dsb + (16 * t + 8 * g + rr) * 64 + cb);
+                const u32x2 b1 = lds_read_tr16(dsb + (16 * t + 8 * g + 4 + rr) * 64 + cb);
+                const u32x4 dsf = {b0[0], b0[1], b1[0], b1[1]};
+                // A = K^T in the same key order
+                const int row_a = kb * 32 + 16 * t + 8 * g + rr;
+#pragma unroll
+                for (int d = 0; d < DBLKS; ++d) {
+                    const u32x2 a0 = lds_read_tr16(sbase + swzt_row_off<D>(row_a, d * 64 + cb));
+                    const u32x2 a1 = lds_read_tr16(sbase + swzt_row_off<D>(row_a + 4, d * 64 + cb));
+                    u32x4 af = {a0[0], a0[1], a1[0], a1[1]};
+                    dq_acc[d] = E::mfma(af, dsf, dq_acc[d]);
+                }
+            }
+        }
+    };
+    auto step = [&](auto stage_c, int nb) {
+        constexpr int stage = decltype(stage_c)::value;
+        if (nb + 1 < n_max) load_tile(nb + 1, std::integral_constant<int, stage ^ 1>{});
+        compute(stage_c, nb);
+        __syncthreads();
+    };
+
+    if (n_min < n_max) load_tile(n_min, std::integral_constant<int, 0>{});
+    __syncthreads();
+    for (int nb = n_min; nb < n_max; nb += 2) {
+        step(std::integral_constant<int, 0>{}, nb);
+        if (nb + 1 < n_max) step(std::integral_constant<int, 1>{}, nb + 1);
+    }
+
+    if (my_row < sg.seqlen_q) {
+        const int64_t dqb = p.cu_seqlens_q ? 0 : (int64_t)w.b * p.dq_batch_stride;
+        uint16_t* dqp = reinterpret_cast<uint16_t*>(p.dq) + dqb + (sg.q_row0 + my_row) * p.dq_row_stride + (int64_t)w.h * p.dq_head_stride;
+        const float sc = p.softmax_scale;
+#pragma unroll
+        for (int d = 0; d < DBLKS; ++d)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                u32x2 o2;
+                o2[0] = E::pack2(dq_acc[d][4 * rq + 0] * sc, dq_acc[d][4 * rq + 1] * sc);
+                o2[1] = E::pack2(dq_acc[d][4 * rq + 2] * sc, dq_acc[d][4 * rq + 3] * sc);
+                *reinterpret_cast<u32x2*>(dqp + d * 32 + 8 * rq + 4 * g) = o2;
+            }
+    }
+    }   // pass
+}
+
+// ---------------------------------------------------------------------------------------------
 // host
 // ---------------------------------------------------------------------------------------------
-size_t bwd_workspace_bytes(const fa_params&) { return 0; }
+// dS hand-off workspace: B * Hq * ceil(Sq/32) * ceil(Sk/32) tiles of 2 KiB (0 = not used: the dQ
+// kernel then recomputes S and dP).  OPT-IN through FA_BWD_DS_MAX_GB=<limit>: measured at config 2
+// the dQ kernel drops from 0.81 to 0.53 ms, but writing the tiles costs the one-wave-per-SIMD dK/dV
+// kernel +0.29 ms (1.55 -> 1.84 ms; store issue is fully exposed there) - a wash that costs 4.3 GB.
+size_t bwd_workspace_bytes(const fa_params& p) {
+    static const double max_gb = getenv("FA_BWD_DS_MAX_GB") ? atof(getenv("FA_BWD_DS_MAX_GB")) : 0.0;
+    if (p.head_dim > 128 || max_gb <= 0.0) return 0;
+    const int64_t nqb = (p.seqlen_q + 31) / 32, nkb = (p.seqlen_k + 31) / 32;
+    const int64_t per_head = nqb * nkb * 2048;
+    if (per_head <= 0 || per_head >= (int64_t)0xffffffffll) return 0;       // tile offsets are 32-bit
+    const double total = (double)per_head * p.batch * p.nheads_q;
+    if (total > max_gb * 1073741824.0) return 0;
+    return (size_t)total;
+}
 #ifdef FA_TIMERS
 extern "C" int fa_debug_read_timers(unsigned long long* out, int n) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_timers), (size_t)n * 8);
@@ -840,8 +1054,16 @@ static int launch_bwd_td(const KArgs& a, hipStream_t stream) {
         }
 #undef FA_LAUNCH_DKV
     }
-    // 3. dQ  (D = 128 needs > 256 registers at two waves per SIMD: development switch FA_DQ_OCC)
-    if (g_bwd_phase_mask & 4) {
+    // 3. dQ
+    if ((g_bwd_phase_mask & 4) && a.ds_ws) {
+        if constexpr (D <= 128) {
+            const int grid = work_grid(p.batch, p.nheads_q, p.nheads_k, a.n_qblocks);
+            const size_t smem = DqdsSmem<D>::TOTAL;
+            auto kern = fa_bwd_dq_from_ds_kernel<T, D>;
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            if (grid > 0) hipLaunchKernelGGL(kern, dim3(grid), dim3(BWD_THREADS), smem, stream, a);
+        }
+    } else if (g_bwd_phase_mask & 4) {
         const int grid = work_grid(p.batch, p.nheads_q, p.nheads_k, a.n_qblocks);
         const size_t smem = DqSmem<D>::TOTAL;
         // D = 128: two waves per SIMD spill ~10 registers but measure 11 % faster than one wave
@@ -861,7 +1083,15 @@ static int launch_bwd_td(const KArgs& a, hipStream_t stream) {
     return 0;
 }
 
-int launch_bwd(const KArgs& a, hipStream_t stream) {
+int launch_bwd(const KArgs& a_in, hipStream_t stream) {
+    KArgs a = a_in;
+    a.ds_ws = nullptr;
+    const size_t need = bwd_workspace_bytes(a.p);
+    if (need > 0 && a.p.workspace && a.p.workspace_bytes >= need) {
+        a.ds_ws = a.p.workspace;
+        a.ds_nqb = (a.p.seqlen_q + 31) / 32;
+        a.ds_nkb = (a.p.seqlen_k + 31) / 32;
+    }
     const bool bf = a.p.dtype == FA_BF16;
     switch (a.p.head_dim) {
         case 64:  return bf ? launch_bwd_td<bf16_tag, 64>(a, stream) : launch_bwd_td<fp16_tag, 64>(a, stream);

@@ -262,6 +262,20 @@ struct KArgs {
     int seqlen_k_add;              // added to seqlens_k[b] (kvcache: T_new)
     const int32_t* kv_batch_idx;   // cache_batch_idx or NULL
     const int32_t* leftpad_k;      // or NULL
+    // backward: dS hand-off from the dK/dV kernel to the dQ kernel (NULL: dQ recomputes S and dP)
+    void* ds_ws;                   // [B, Hq, ds_nqb, ds_nkb][2 KiB]: one 32-query x 32-key dS tile each
+    int ds_nqb, ds_nkb;            // ceil(seqlen_q / 32), ceil(seqlen_k / 32)
 };
+
+// One 32 x 32 (query, key) sub-tile holds at least one visible pair.  The dK/dV kernel writes a dS
+// tile exactly when this is true and the dQ kernel reads exactly those tiles.
+__device__ __forceinline__ bool subtile_active(int q0, int k0, int seqlen_q, int seqlen_k, int off, int wl, int wr) {
+    if (k0 >= seqlen_k) return false;
+    const int k_last = k0 + 31 < seqlen_k ? k0 + 31 : seqlen_k - 1;
+    int qlo_min = 0, qhi_max = seqlen_q - 1;
+    if (wr >= 0) { const int t = k0 - off - wr; qlo_min = t > 0 ? t : 0; }
+    if (wl >= 0) { const int t = k_last - off + wl; qhi_max = t < qhi_max ? t : qhi_max; }
+    return q0 <= qhi_max && q0 + 31 >= qlo_min;
+}
 
 }  // namespace fa
