@@ -135,3 +135,30 @@ def test_full_size_property_config2(dt):
         o_ref, lse_ref, _ = oracle.attn_fwd(qq, kk, vv, D ** -0.5)
         assert_close(f64(out[b, i, h]), o_ref[0, 0, 0], dt, f"row {b},{h},{i}", mult=2.0)
         assert abs(float(lse[b, h, i]) - float(lse_ref[0, 0, 0])) < 2e-3
+
+
+def test_full_size_property_config5_shard():
+    """BASELINE config 5, one GPU's shard at full size (B64, heads 4..7 of 32, S8192, D128, bf16,
+    causal + ALiBi with the sharded slopes): slicing commutes with attention and sampled rows
+    equal the oracle (row i of causal attention only needs keys <= i; bottom-right alignment makes
+    the one-row problem carry the same ALiBi distances)."""
+    from flash_attn_mi355.sharding import shard_alibi
+    B, S, Htot, D, dt = 64, 8192, 32, 128, "bf16"
+    slopes_all = (2.0 ** (-8.0 * (torch.arange(Htot) + 1) / Htot)).float()
+    h0, h1 = 4, 8                                                  # rank 1 of 8
+    slopes = shard_alibi(slopes_all, slice(h0, h1), slice(0, B)).cuda()
+    H = h1 - h0
+    q = rand16((B, S, H, D), dt, 421); k = rand16((B, S, H, D), dt, 422); v = rand16((B, S, H, D), dt, 423)
+    out, lse, _ = _fa().flash_attn_func(q, k, v, causal=True, alibi_slopes=slopes, return_attn_probs=True)
+    assert torch.isfinite(out).all() and torch.isfinite(lse).all()
+    sub = _fa().flash_attn_func(q[9:10, :, 1:3], k[9:10, :, 1:3], v[9:10, :, 1:3], causal=True,
+                                alibi_slopes=slopes[1:3].contiguous())
+    assert torch.equal(sub, out[9:10, :, 1:3])
+    for (b, h, i) in [(0, 0, 0), (63, 3, 8191), (17, 2, 4097), (5, 1, 63), (40, 0, 64), (33, 3, 6000)]:
+        qq = f64(q[b, i:i + 1, h])[None, None]
+        kk = f64(k[b, :i + 1, h])[None, None]
+        vv = f64(v[b, :i + 1, h])[None, None]
+        o_ref, lse_ref, _ = oracle.attn_fwd(qq, kk, vv, D ** -0.5, causal=True,
+                                            alibi_slopes=f64(slopes[h:h + 1]))
+        assert_close(f64(out[b, i, h]), o_ref[0, 0, 0], dt, f"row {b},{h},{i}", mult=2.0)
+        assert abs(float(lse[b, h, i]) - float(lse_ref[0, 0, 0])) < 3e-3

@@ -168,3 +168,50 @@ def test_decode_fp8_kv_cache(Hk):
     assert np.array_equal(got_v, vc_ref)
     assert_close(f64(out), o_ref, dt, "out", mult=1.5)
     assert_lse_close(f64(lse), lse_ref, "lse", atol=3e-2)
+
+
+def test_full_size_config4_decode_paged_rotary_fp8():
+    """BASELINE config 4 at full size (B128, 32 heads, D128, cache_seqlen 8192, paged KV with a random
+    block table, NeoX rotary, fp8-e4m3 KV), checked through size-independent properties:
+      * two sampled batch entries against the oracle (their pages gathered into a one-entry cache),
+      * the appended row lands in the right physical page and equals the rotated + quantised new key,
+      * split-KV invariance (num_splits 1 vs 4) and GQA consistency are covered at small size above."""
+    B, Hq, Hk, D, L, page, dt = 128, 32, 32, 128, 8192, 256, "fp16"
+    # power-of-two descales: value / descale is exact, so the kernel (fp32) and the oracle (fp64) quantise
+    # the appended V row to identical fp8 codes (with 0.03 a handful of round-to-nearest ties differ, and
+    # the new token carries a large softmax weight here)
+    kd, vd = 2.0 ** -6, 2.0 ** -5
+    pps = (L + 1 + page - 1) // page
+    nblk = B * pps
+    g = torch.Generator(device="cuda").manual_seed(421)
+    kc = (torch.randn(nblk, page, Hk, D, device="cuda", dtype=torch.float16, generator=g) * 0.5).to(torch.float8_e4m3fn)
+    vc = (torch.randn(nblk, page, Hk, D, device="cuda", dtype=torch.float16, generator=g) * 0.5).to(torch.float8_e4m3fn)
+    bt = torch.randperm(nblk, generator=torch.Generator().manual_seed(2)).reshape(B, pps).to(torch.int32)
+    q = rand16((B, 1, Hq, D), dt, 1)
+    knew = rand16((B, 1, Hk, D), dt, 4); vnew = rand16((B, 1, Hk, D), dt, 5)
+    seqlens = torch.full((B,), L, dtype=torch.int32)
+    cos, sin = _rotary(pps * page + 8, D, dt)
+    sample = [0, 77]
+    # reference copies of the sampled entries' pages BEFORE the call (the op appends in place)
+    ref_pages = {b: (kc[bt[b].long().cuda()].float().double().cpu().numpy().copy(),
+                     vc[bt[b].long().cuda()].float().double().cpu().numpy().copy()) for b in sample}
+    out, lse = _fa().flash_attn_with_kvcache(q, kc, vc, k=knew, v=vnew, rotary_cos=cos, rotary_sin=sin,
+                                             cache_seqlens=seqlens.cuda(), block_table=bt.cuda(), causal=True,
+                                             rotary_interleaved=False, return_softmax_lse=True,
+                                             k_descale=kd, v_descale=vd)
+    assert torch.isfinite(out).all() and torch.isfinite(lse).all()
+    for b in sample:
+        kref, vref = ref_pages[b]                              # [pps, page, Hk, D] in logical order
+        bt1 = np.arange(pps, dtype=np.int32)[None]
+        o_ref, lse_ref = oracle.kvcache_fwd(f64(q[b:b + 1]), kref, vref, k=f64(knew[b:b + 1]), v=f64(vnew[b:b + 1]),
+                                            rotary_cos=f64(cos), rotary_sin=f64(sin),
+                                            cache_seqlens=np.array([L], dtype=np.int32), block_table=bt1,
+                                            causal=True, rotary_interleaved=False, io_dtype=dt,
+                                            k_descale=kd, v_descale=vd)
+        assert_close(f64(out[b:b + 1]), o_ref, dt, f"out[{b}]", mult=1.5)
+        assert_lse_close(f64(lse[b:b + 1]), lse_ref, f"lse[{b}]", atol=3e-2)
+        # the appended row: logical position L -> page L // 256, row L % 256 of this entry's table
+        phys = int(bt[b, L // page])
+        got_k = kc[phys, L % page].float().double().cpu().numpy()
+        assert (np.abs(got_k - kref[L // page, L % page]) <= 0.13 * np.maximum(np.abs(kref[L // page, L % page]), 2.0 ** -6)).all()
+        assert np.array_equal(vc[phys, L % page].float().double().cpu().numpy(), vref[L // page, L % page])
