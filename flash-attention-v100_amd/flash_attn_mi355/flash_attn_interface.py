@@ -208,7 +208,10 @@ class FlashAttnFunc(torch.autograd.Function):
         if is_grad:
             _save_dense(ctx, saved, lse, alibi_slopes, dropout_p, softmax_scale, causal, window_size,
                         softcap, deterministic, q.shape[-1], rng)
-        return (out, lse, dmask) if return_softmax else out
+        if return_softmax:
+            ctx.mark_non_differentiable(lse, dmask)
+            return out, lse, dmask
+        return out
 
     @staticmethod
     def backward(ctx, dout, *args):
@@ -235,7 +238,10 @@ class FlashAttnQKVPackedFunc(torch.autograd.Function):
         if is_grad:
             _save_dense(ctx, saved, lse, alibi_slopes, dropout_p, softmax_scale, causal, window_size,
                         softcap, deterministic, qkv.shape[-1], rng)
-        return (out, lse, dmask) if return_softmax else out
+        if return_softmax:
+            ctx.mark_non_differentiable(lse, dmask)
+            return out, lse, dmask
+        return out
 
     @staticmethod
     def backward(ctx, dout, *args):
@@ -262,7 +268,10 @@ class FlashAttnKVPackedFunc(torch.autograd.Function):
         if is_grad:
             _save_dense(ctx, saved, lse, alibi_slopes, dropout_p, softmax_scale, causal, window_size,
                         softcap, deterministic, q.shape[-1], rng)
-        return (out, lse, dmask) if return_softmax else out
+        if return_softmax:
+            ctx.mark_non_differentiable(lse, dmask)
+            return out, lse, dmask
+        return out
 
     @staticmethod
     def backward(ctx, dout, *args):
@@ -405,7 +414,10 @@ class FlashAttnVarlenFunc(torch.autograd.Function):
             ctx.max_seqlen_q = max_seqlen_q
             ctx.max_seqlen_k = max_seqlen_k
             ctx.rng = rng
-        return (out, lse, dmask) if return_attn_probs else out
+        if return_attn_probs:
+            ctx.mark_non_differentiable(lse, dmask)
+            return out, lse, dmask
+        return out
 
     @staticmethod
     def backward(ctx, dout, *args):
