@@ -470,11 +470,7 @@ static int launch_fwd_td(const KArgs& a, bool paged, hipStream_t stream) {
     return 0;
 }
 
-int launch_fwd_pipe(const KArgs& a, hipStream_t stream);
-
 int launch_fwd(const KArgs& a, hipStream_t stream) {
-    static const bool use_pipe = getenv("FA_USE_PIPE") != nullptr;    // experimental kernel: measured slower, off by default
-    if (use_pipe && launch_fwd_pipe(a, stream) == 0) return 0;
     const bool paged = a.p.block_table != nullptr;
     const bool bf = a.p.dtype == FA_BF16;
     switch (a.p.head_dim) {

@@ -1,0 +1,52 @@
+"""bench.py's output contract (the driver parses this line)."""
+import importlib.util
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+
+
+def _bench_module():
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_cpu_baseline_leg_runs_on_the_oracle():
+    """The reported CPU baseline is the oracle (kind 'port'), on a bounded sample."""
+    m = _bench_module()
+    small = dict(m.CFG, seqlen=256)
+    r = m.cpu_baseline(small, budget_s=0.5)
+    assert r["kind"] == "port" and r["unit"] == "TFLOP/s" and r["value"] > 0 and r["cores"] >= 1
+    assert "oracle" in r["sample"]
+
+
+def test_flop_convention_matches_baseline_md():
+    m = _bench_module()
+    # BASELINE.md / SURVEY 8(d): config 2 forward = 549.76 GFLOP, fwd+bwd = 3.5x
+    assert abs(m.fwd_flops(m.CFG) / 1e9 - 549.76) < 0.01
+
+
+@pytest.mark.gpu
+def test_bench_json_line_contract():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1",
+                          "--no-cpu-baseline"], capture_output=True, text=True, cwd=ROOT, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True
+    assert d["scaling"] == "weak" and d["dtype"] == "bf16" and d["data"] == "synthetic" and d["vs_baseline"] is None
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 2500.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert r["traffic"] is None or r["traffic"] > 1e8
+    # value is consistent with ms_per_step and the algorithmic FLOPs of config 2
+    assert abs(d["value"] - 1924.16e9 / (d["ms_per_step"] * 1e-3) / 1e12) / d["value"] < 1e-2
