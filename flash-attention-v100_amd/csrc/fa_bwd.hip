@@ -104,6 +104,11 @@ __global__ void __launch_bounds__(BWD_THREADS, 1) fa_bwd_dkdv_kernel(const KArgs
     using E = Elem<T>;
     constexpr int KSTEPS = D / 16;
     constexpr int DBLKS = D / 32;
+    // D = 256: dK / dV are produced in two 128-column halves (two sweeps over the query tiles, S and dP
+    // recomputed) - 256 accumulator registers + 128 K/V fragment registers do not fit beside the rest
+    // (the one-sweep build spilled 400-900 registers: 10 ms -> see DESIGN.md)
+    constexpr int NDH = D > 128 ? 2 : 1;
+    constexpr int ADB = DBLKS / NDH;                     // accumulated 32-column blocks per sweep
     constexpr int CPR = D / 8;
     constexpr int CHUNKS = DKV_BQ * CPR / BWD_THREADS;
     constexpr int TILE = DkvSmem<D>::TILE;
@@ -145,8 +150,8 @@ __global__ void __launch_bounds__(BWD_THREADS, 1) fa_bwd_dkdv_kernel(const KArgs
 #ifndef FA_DKV_DMA
     // Q / dO tiles staged through registers (buffer_load -> ds_write after the MFMAs): measured
     // 13 % faster than LDS-DMA for this one-wave-per-SIMD kernel (1.54 vs 1.74 ms), while
-    // LDS-DMA wins in the two-wave kernels (fwd, dQ).
-    constexpr bool DMA = false;
+    // LDS-DMA wins in the two-wave kernels (fwd, dQ).  D = 256 has no registers to stage through.
+    constexpr bool DMA = D > 128;
 #else
     // Q / dO tiles by LDS-DMA (see fa_fwd.hip): instruction `inst` = wave*CHUNKS + i covers
     // ROWS_PI rows, lane -> (row, physical slot); the source offset carries the swizzle.
@@ -295,11 +300,8 @@ __global__ void __launch_bounds__(BWD_THREADS, 1) fa_bwd_dkdv_kernel(const KArgs
         if (tid < 2 * DKV_BQ) st[tid] = statreg;          // [0,64): lse2, [64,128): D
     };
 
-    f32x16 dk_acc[DBLKS], dv_acc[DBLKS];
-#pragma unroll
-    for (int d = 0; d < DBLKS; ++d)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { dk_acc[d][r] = 0.f; dv_acc[d][r] = 0.f; }
+    f32x16 dk_acc[ADB], dv_acc[ADB];
+    int dh_off = 0;                                      // byte offset of the sweep's columns in a Q / dO row
 
     float slope = 0.f;
 
@@ -311,6 +313,7 @@ __global__ void __launch_bounds__(BWD_THREADS, 1) fa_bwd_dkdv_kernel(const KArgs
         // (measured: alternating the S and dP chains is 6 % SLOWER here - one wave per SIMD -
         //  while it is 10 % faster in the two-wave dQ kernel)
 #ifndef FA_DKV_NO_PREFETCH
+        if constexpr (D <= 128) {
         // one wave per SIMD: nothing else hides the LDS latency, so all Q fragments are fetched
         // up front and the dO fragments stream in behind the S MFMAs
         u32x4 qa[KSTEPS], da[KSTEPS];
@@ -330,7 +333,9 @@ __global__ void __launch_bounds__(BWD_THREADS, 1) fa_bwd_dkdv_kernel(const KArgs
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         }
         __builtin_amdgcn_sched_group_barrier(0x008, KSTEPS, 0);
-#else
+        } else
+#endif
+        {
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks) {
             const u32x4 qa = lds_read_b128(qs + a_rd[ks] + sub * 32 * D * 2);
@@ -341,7 +346,7 @@ __global__ void __launch_bounds__(BWD_THREADS, 1) fa_bwd_dkdv_kernel(const KArgs
             const u32x4 da = lds_read_b128(dos + a_rd[ks] + sub * 32 * D * 2);
             dp_acc = E::mfma(da, vf[ks], dp_acc);
         }
-#endif
+        }
     };
     // row statistics for q = q0 + 8 i + 4 g + (0..3)
     auto sm_stats = [&](const float* st, int sub, f32x4 (&lse2)[4], f32x4 (&dsum)[4]) {
@@ -401,6 +406,45 @@ __global__ void __launch_bounds__(BWD_THREADS, 1) fa_bwd_dkdv_kernel(const KArgs
                 dsf[t][w2] = E::pack2(dsv[8 * t + 2 * w2], dsv[8 * t + 2 * w2 + 1]);
             }
     };
+    // sm for ONE group of four accumulator registers (rows 8 i + 4 g + 0..3): the register-lean form
+    auto sm_rows = [&](int i, int q0, bool need_mask, const f32x4& l2v, const f32x4& dsm, const f32x16& s_acc,
+                       const f32x16& dp_acc, u32x4 (&pf)[2], u32x4 (&dsf)[2]) {
+        float pv[4], dsv[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int r = 4 * i + e;
+            const int qi = q0 + e + 8 * i + 4 * g;
+            float dpe = dp_acc[r];
+            bool keep = true;
+            if (DROPOUT) {
+                keep = dropout_keep1(dc, (uint64_t)(sg.q_row0 + qi) * drop_n_glob + (uint64_t)my_key);
+                dpe = keep ? dpe * a.rp_dropout : 0.f;
+            }
+            float pr, dsr;
+            if (BIAS) {
+                float sv = s_acc[r] * p.softmax_scale;
+                sv = fmaf(-slope, fabsf((float)(qi + off - my_key)), sv);
+                float chain = 1.f;
+                if (p.softcap > 0.f) {
+                    const float t = fast_tanh(sv / p.softcap);
+                    sv = p.softcap * t;
+                    chain = 1.f - t * t;
+                }
+                pr = fast_exp2(fmaf(sv, kLog2e, -l2v[e]));
+                dsr = pr * (dpe - dsm[e]) * chain;
+            } else {
+                pr = fast_exp2(fmaf(s_acc[r], c, -l2v[e]));
+                dsr = pr * (dpe - dsm[e]);
+            }
+            float pk = (DROPOUT && !keep) ? 0.f : pr;
+            if (need_mask && (qi < qlo || qi > qhi)) { pk = 0.f; dsr = 0.f; }
+            pv[e] = pk; dsv[e] = dsr;
+        }
+        pf[i >> 1][2 * (i & 1)] = E::pack2(pv[0], pv[1]);
+        pf[i >> 1][2 * (i & 1) + 1] = E::pack2(pv[2], pv[3]);
+        dsf[i >> 1][2 * (i & 1)] = E::pack2(dsv[0], dsv[1]);
+        dsf[i >> 1][2 * (i & 1) + 1] = E::pack2(dsv[2], dsv[3]);
+    };
     // bk: dV^T += dO^T P,  dK^T += Q^T dS
     auto bk = [&](const char* qs, const char* dos, int sub, const u32x4 (&pf)[2], const u32x4 (&dsf)[2]) {
 #pragma unroll
@@ -408,32 +452,35 @@ __global__ void __launch_bounds__(BWD_THREADS, 1) fa_bwd_dkdv_kernel(const KArgs
             // rows sub*32 + 16 t + 8 hf + 4 g + rr ; cols 32 d + 16 ((lane>>4)&1) + 4 (lane&3)
             const int row_a = sub * 32 + 16 * t + 4 * g + rr;
 #ifndef FA_DKV_NO_PREFETCH
-            u32x4 af[DBLKS], bfr[DBLKS];
+            if constexpr (D <= 128) {
+            u32x4 af[ADB], bfr[ADB];
 #pragma unroll
-            for (int d = 0; d < DBLKS; ++d) {
+            for (int d = 0; d < ADB; ++d) {
                 const u32x2 a0 = lds_read_tr16(dos + swzt_row_off<D>(row_a, d * 64 + cb));
                 const u32x2 a1 = lds_read_tr16(dos + swzt_row_off<D>(row_a + 8, d * 64 + cb));
                 af[d] = u32x4{a0[0], a0[1], a1[0], a1[1]};
             }
 #pragma unroll
-            for (int d = 0; d < DBLKS; ++d) {
+            for (int d = 0; d < ADB; ++d) {
                 const u32x2 b0 = lds_read_tr16(qs + swzt_row_off<D>(row_a, d * 64 + cb));
                 const u32x2 b1 = lds_read_tr16(qs + swzt_row_off<D>(row_a + 8, d * 64 + cb));
                 bfr[d] = u32x4{b0[0], b0[1], b1[0], b1[1]};
                 dv_acc[d] = E::mfma(af[d], pf[t], dv_acc[d]);
             }
 #pragma unroll
-            for (int d = 0; d < DBLKS; ++d) dk_acc[d] = E::mfma(bfr[d], dsf[t], dk_acc[d]);
-            __builtin_amdgcn_sched_group_barrier(0x100, 2 * DBLKS, 0);
+            for (int d = 0; d < ADB; ++d) dk_acc[d] = E::mfma(bfr[d], dsf[t], dk_acc[d]);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * ADB, 0);
 #pragma unroll
-            for (int d = 0; d < DBLKS; ++d) {
+            for (int d = 0; d < ADB; ++d) {
                 __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             }
-            __builtin_amdgcn_sched_group_barrier(0x008, DBLKS, 0);
-#else
+            __builtin_amdgcn_sched_group_barrier(0x008, ADB, 0);
+            } else
+#endif
+            {
 #pragma unroll
-            for (int d = 0; d < DBLKS; ++d) {
+            for (int d = 0; d < ADB; ++d) {
                 const u32x2 a0 = lds_read_tr16(dos + swzt_row_off<D>(row_a, d * 64 + cb));
                 const u32x2 a1 = lds_read_tr16(dos + swzt_row_off<D>(row_a + 8, d * 64 + cb));
                 u32x4 af = {a0[0], a0[1], a1[0], a1[1]};
@@ -443,7 +490,7 @@ __global__ void __launch_bounds__(BWD_THREADS, 1) fa_bwd_dkdv_kernel(const KArgs
                 u32x4 bfr = {b0[0], b0[1], b1[0], b1[1]};
                 dk_acc[d] = E::mfma(bfr, dsf[t], dk_acc[d]);
             }
-#endif
+            }
         }
     };
 
@@ -486,13 +533,26 @@ __global__ void __launch_bounds__(BWD_THREADS, 1) fa_bwd_dkdv_kernel(const KArgs
             asm volatile("s_nop 0" :: "v"(s_acc[0]), "v"(dp_acc[0]));
 #endif
             TMR_ADD(0, t0);
-            sm_stats(st, sub, lse2, dsum);
-            sm(q0, needs_mask(q0), lse2, dsum, s_acc, dp_acc, pf, dsf);
+            if constexpr (D <= 128) {
+                sm_stats(st, sub, lse2, dsum);
+                sm(q0, needs_mask(q0), lse2, dsum, s_acc, dp_acc, pf, dsf);
+            } else {
+                // D = 256 is register-starved: one row group's statistics at a time
+                const bool nm = needs_mask(q0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    f32x4 l4[4], d4[4];
+                    l4[i] = *reinterpret_cast<const f32x4*>(st + sub * 32 + 8 * i + 4 * g);
+                    d4[i] = *reinterpret_cast<const f32x4*>(st + DKV_BQ + sub * 32 + 8 * i + 4 * g);
+                    sm_rows(i, q0, nm, l4[i], d4[i], s_acc, dp_acc, pf, dsf);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
 #ifdef FA_TIMERS
             asm volatile("s_nop 0" :: "v"(pf[1][3]), "v"(dsf[1][3]), "v"(pf[0][0]), "v"(dsf[0][0]));
 #endif
             TMR_ADD(1, t0);
-            if (a.ds_ws) {
+            if (a.ds_ws && dh_off == 0) {
                 // hand dS to the dQ kernel: after one half-exchange per register pair a lane holds 8
                 // consecutive query rows of its key (16 bytes) -> two coalesced 1-KiB stores per sub-tile.
                 // Tile layout: [t = 16-row group][key][row-octet g][8 rows].  The stores are issued at
@@ -511,9 +571,9 @@ __global__ void __launch_bounds__(BWD_THREADS, 1) fa_bwd_dkdv_kernel(const KArgs
                 }
                 ds_pending |= 1u << sub;
             }
-            bk(qs, dos, sub, pf, dsf);
+            bk(qs + dh_off, dos + dh_off, sub, pf, dsf);
 #ifdef FA_TIMERS
-            asm volatile("s_nop 0" :: "v"(dk_acc[DBLKS - 1][0]), "v"(dv_acc[DBLKS - 1][0]));
+            asm volatile("s_nop 0" :: "v"(dk_acc[ADB - 1][0]), "v"(dv_acc[ADB - 1][0]));
 #endif
             TMR_ADD(2, t0);
         }
@@ -535,6 +595,13 @@ __global__ void __launch_bounds__(BWD_THREADS, 1) fa_bwd_dkdv_kernel(const KArgs
         tmr[7] += 1;
     };
 
+#pragma unroll 1
+    for (int dh = 0; dh < NDH; ++dh) {
+    dh_off = dh * ADB * 64;
+#pragma unroll
+    for (int d = 0; d < ADB; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dk_acc[d][r] = 0.f; dv_acc[d][r] = 0.f; }
     if (n_iter > 0) { load_tile(0, std::integral_constant<int, 0>{}); store_tile(std::integral_constant<int, 0>{}); }
     __syncthreads();
     for (int it = 0; it < n_iter; it += 2) {
@@ -556,7 +623,7 @@ __global__ void __launch_bounds__(BWD_THREADS, 1) fa_bwd_dkdv_kernel(const KArgs
         uint16_t* dvp = reinterpret_cast<uint16_t*>(p.dv) + dvb + (sg.k_row0 + my_key) * p.dv_row_stride + (int64_t)hk * p.dv_head_stride;
         const float sc = p.softmax_scale;
 #pragma unroll
-        for (int d = 0; d < DBLKS; ++d)
+        for (int d = 0; d < ADB; ++d)
 #pragma unroll
             for (int rq = 0; rq < 4; ++rq) {
                 u32x2 k2, v2;
@@ -565,10 +632,11 @@ __global__ void __launch_bounds__(BWD_THREADS, 1) fa_bwd_dkdv_kernel(const KArgs
                 const float rp = DROPOUT ? a.rp_dropout : 1.0f;
                 v2[0] = E::pack2(dv_acc[d][4 * rq + 0] * rp, dv_acc[d][4 * rq + 1] * rp);
                 v2[1] = E::pack2(dv_acc[d][4 * rq + 2] * rp, dv_acc[d][4 * rq + 3] * rp);
-                *reinterpret_cast<u32x2*>(dkp + d * 32 + 8 * rq + 4 * g) = k2;
-                *reinterpret_cast<u32x2*>(dvp + d * 32 + 8 * rq + 4 * g) = v2;
+                *reinterpret_cast<u32x2*>(dkp + (dh * ADB + d) * 32 + 8 * rq + 4 * g) = k2;
+                *reinterpret_cast<u32x2*>(dvp + (dh * ADB + d) * 32 + 8 * rq + 4 * g) = v2;
             }
     }
+    }   // dh (column sweep)
     }   // pass
 }
 
