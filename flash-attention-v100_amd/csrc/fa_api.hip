@@ -68,6 +68,16 @@ static int check_common(const fa_params& p, bool need_out) {
              (reinterpret_cast<uintptr_t>(p.v) & 15) == 0, "q/k/v must be 16-byte aligned");
     if (!supported_head_dim(p.head_dim))
         return fail(FA_ERR_UNSUPPORTED, "head dimension %d has no gfx950 kernel in this build (64, 128, 256)", p.head_dim);
+    // The kernels address one (batch, head) slice through a buffer descriptor: 32-bit byte offsets.
+    // (varlen tensors are one slice of total_q / total_k rows; paged caches one page.)
+    {
+        const int64_t rows_q = p.cu_seqlens_q ? (p.total_q > 0 ? p.total_q : p.seqlen_q) : p.seqlen_q;
+        const int64_t rows_k = p.block_table ? p.page_block_size
+                                             : (p.cu_seqlens_k ? (p.total_k > 0 ? p.total_k : p.seqlen_k) : p.seqlen_k);
+        const int64_t lim = (int64_t)1 << 32;
+        FA_CHECK(rows_q * p.q_row_stride * 2 < lim && rows_k * p.k_row_stride * 2 < lim && rows_k * p.v_row_stride * 2 < lim,
+                 "one (batch, head) slice of q/k/v spans more than 4 GiB: not addressable by the gfx950 kernels");
+    }
     return FA_OK;
 }
 
