@@ -99,7 +99,8 @@ template <int D> struct DkvSmem {
     static constexpr int TOTAL = 2 * STAGE;
 };
 
-template <typename T, int D, bool BIAS, bool DROPOUT>
+// BIAS: 0 none, 1 general (ALiBi / softcap per element), 2 causal ALiBi through the matrix pipe (fa_common.h)
+template <typename T, int D, int BIAS, bool DROPOUT>
 __global__ void __launch_bounds__(BWD_THREADS, 1) fa_bwd_dkdv_kernel(const KArgs a) {
     using E = Elem<T>;
     constexpr int KSTEPS = D / 16;
@@ -307,9 +308,12 @@ __global__ void __launch_bounds__(BWD_THREADS, 1) fa_bwd_dkdv_kernel(const KArgs
 
     // ---- the three phases of one 32-query x 32-key sub-tile of this wave ----
     // sd: S = Q K^T, dP = dO V^T : acc[r] = X[q0 + row(r,g)][my_key]
+    u32x4 alibi_b = {0, 0, 0, 0};                          // BIAS == 2: per sub-tile, set in compute()
+    const u32x4 alibi_a = alibi_pos_operand<T>(lane);      // A side = query rows: position of the register
     auto sd = [&](const char* qs, const char* dos, int sub, f32x16& s_acc, f32x16& dp_acc) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) { s_acc[r] = 0.f; dp_acc[r] = 0.f; }
+        if (BIAS == 2) s_acc = E::mfma(alibi_a, alibi_b, s_acc);
         // (measured: alternating the S and dP chains is 6 % SLOWER here - one wave per SIMD -
         //  while it is 10 % faster in the two-wave dQ kernel)
 #ifndef FA_DKV_NO_PREFETCH
@@ -372,7 +376,7 @@ __global__ void __launch_bounds__(BWD_THREADS, 1) fa_bwd_dkdv_kernel(const KArgs
                 dpe = keep ? dpe * a.rp_dropout : 0.f;
             }
             float pr, dsr;
-            if (BIAS) {
+            if (BIAS == 1) {
                 float sv = s_acc[r] * p.softmax_scale;
                 sv = fmaf(-slope, fabsf((float)(qi + off - my_key)), sv);
                 float chain = 1.f;
@@ -421,7 +425,7 @@ __global__ void __launch_bounds__(BWD_THREADS, 1) fa_bwd_dkdv_kernel(const KArgs
                 dpe = keep ? dpe * a.rp_dropout : 0.f;
             }
             float pr, dsr;
-            if (BIAS) {
+            if (BIAS == 1) {
                 float sv = s_acc[r] * p.softmax_scale;
                 sv = fmaf(-slope, fabsf((float)(qi + off - my_key)), sv);
                 float chain = 1.f;
@@ -528,6 +532,8 @@ __global__ void __launch_bounds__(BWD_THREADS, 1) fa_bwd_dkdv_kernel(const KArgs
             f32x4 lse2[4], dsum[4];
             unsigned long long t0 = TMR_NOW();
             (void)t0;
+            if (BIAS == 2)      // bias = slope ((kw0 - off - q0) + key_pos - row_pos)
+                alibi_b = alibi_lane_operand<T>(lane, slope / p.softmax_scale, -1.f, (float)l31, (float)(kw0 - off - q0));
             sd(qs, dos, sub, s_acc, dp_acc);
 #ifdef FA_TIMERS
             asm volatile("s_nop 0" :: "v"(s_acc[0]), "v"(dp_acc[0]));
@@ -652,7 +658,7 @@ template <int D> struct DqSmem {
     static constexpr int TOTAL = 2 * STAGE;
 };
 
-template <typename T, int D, bool BIAS, int OCC, bool DROPOUT>
+template <typename T, int D, int BIAS, int OCC, bool DROPOUT>
 __global__ void __launch_bounds__(BWD_THREADS, OCC) fa_bwd_dq_kernel(const KArgs a) {
     using E = Elem<T>;
     constexpr int KSTEPS = D / 16;
@@ -709,6 +715,7 @@ __global__ void __launch_bounds__(BWD_THREADS, OCC) fa_bwd_dq_kernel(const KArgs
     const int cb = (((lane >> 4) & 1) << 5) + ((lane & 3) << 3);
     float slope = 0.f;
     if (BIAS && p.alibi_slopes) slope = p.alibi_slopes[w.b * p.alibi_batch_stride + w.h];
+    const u32x4 alibi_a = alibi_pos_operand<T>(lane);
     DropCtx dc = {0, 0, 0, 0};
     if (DROPOUT) {
         dc.k0 = (uint32_t)p.philox_seed; dc.k1 = (uint32_t)(p.philox_seed >> 32);
@@ -799,6 +806,11 @@ __global__ void __launch_bounds__(BWD_THREADS, OCC) fa_bwd_dq_kernel(const KArgs
             f32x16 s_acc, dp_acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { s_acc[r] = 0.f; dp_acc[r] = 0.f; }
+            if (BIAS == 2) {    // A side = key rows: position of the register; bias = slope ((n0 + 32 kb - off - row0) + key_pos - row_pos)
+                const u32x4 ab = alibi_lane_operand<T>(lane, slope / p.softmax_scale, 1.f, -(float)l31,
+                                                       (float)(n0 + kb * 32 - off - wave_row0));
+                s_acc = E::mfma(alibi_a, ab, s_acc);
+            }
 #pragma unroll
             for (int ks = 0; ks < KSTEPS; ++ks) {                // two alternating accumulator chains
                 const u32x4 ka = lds_read_b128(sbase + k_rd[ks] + kb * 32 * D * 2);
@@ -822,7 +834,7 @@ __global__ void __launch_bounds__(BWD_THREADS, OCC) fa_bwd_dq_kernel(const KArgs
                 float dpe = dp_acc[r];
                 if (DROPOUT) dpe = ((kbits >> r) & 1u) ? dpe * a.rp_dropout : 0.f;   // dS = P (keep rp dP - D)
                 float pr, dsr;
-                if (BIAS) {
+                if (BIAS == 1) {
                     const int j = n0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
                     float s = s_acc[r] * p.softmax_scale;
                     s = fmaf(-slope, fabsf((float)(my_row + off - j)), s);
@@ -1104,6 +1116,8 @@ static int launch_bwd_td(const KArgs& a, hipStream_t stream) {
     }
     // 2. dK/dV
     const bool drop = p.p_dropout > 0.f;
+    // causal ALiBi without softcap: the bias rides on one extra MFMA per sub-tile (BIAS = 2)
+    const bool lin_alibi = p.alibi_slopes && p.softcap <= 0.f && (p.is_causal || p.window_right == 0);
     if (g_bwd_phase_mask & 2) {
         const int n_kblocks = (p.seqlen_k + DKV_BN - 1) / DKV_BN;
         const int n_kb_grid = (a.pair_qblocks && n_kblocks >= 2) ? (n_kblocks + 1) / 2 : n_kblocks;
@@ -1117,8 +1131,9 @@ static int launch_bwd_td(const KArgs& a, hipStream_t stream) {
             hipLaunchKernelGGL(kern, dim3(grid), dim3(BWD_THREADS), smem, stream, a);                             \
         } while (0)
         if (grid > 0) {
-            if (drop) { if (a.has_bias) FA_LAUNCH_DKV(true, true); else FA_LAUNCH_DKV(false, true); }
-            else      { if (a.has_bias) FA_LAUNCH_DKV(true, false); else FA_LAUNCH_DKV(false, false); }
+            if (drop) { if (a.has_bias) FA_LAUNCH_DKV(1, true); else FA_LAUNCH_DKV(0, true); }
+            else if (a.has_bias) { if (lin_alibi) FA_LAUNCH_DKV(2, false); else FA_LAUNCH_DKV(1, false); }
+            else      FA_LAUNCH_DKV(0, false);
         }
 #undef FA_LAUNCH_DKV
     }
@@ -1143,8 +1158,9 @@ static int launch_bwd_td(const KArgs& a, hipStream_t stream) {
             hipLaunchKernelGGL(kern, dim3(grid), dim3(BWD_THREADS), smem, stream, a);                             \
         } while (0)
         if (grid > 0) {
-            if (drop) { if (a.has_bias) FA_LAUNCH_DQ(true, true); else FA_LAUNCH_DQ(false, true); }
-            else      { if (a.has_bias) FA_LAUNCH_DQ(true, false); else FA_LAUNCH_DQ(false, false); }
+            if (drop) { if (a.has_bias) FA_LAUNCH_DQ(1, true); else FA_LAUNCH_DQ(0, true); }
+            else if (a.has_bias) { if (lin_alibi) FA_LAUNCH_DQ(2, false); else FA_LAUNCH_DQ(1, false); }
+            else      FA_LAUNCH_DQ(0, false);
         }
 #undef FA_LAUNCH_DQ
     }

@@ -267,6 +267,51 @@ struct KArgs {
     int ds_nqb, ds_nkb;            // ceil(seqlen_q / 32), ceil(seqlen_k / 32)
 };
 
+// ---- ALiBi through the matrix pipe (causal-like masks: every visible key is at or left of the diagonal) ----
+// bias(q, key) = slope (key - off - q) is split into three small terms relative to the 32 x 32 sub-tile,
+//   slope * [ +-pos(register)  +  lane term  +  tile term ],
+// and added to the score accumulator by ONE extra MFMA whose contraction slots carry
+//   k0,k1: A = pos (0..31, exact in 16 bit)   B = head / tail of +-slope/scale
+//   k2,k3: A = 1                               B = head / tail of the lane's term
+//   k4-k6: A = 1                               B = three-way split of the tile term (24-bit mantissa)
+// so no per-element VALU work is left.  All terms are small near the diagonal (where P matters) and the
+// 16-bit splits bound the error by ~3e-4 in log2 units elsewhere.
+template <typename T>
+__device__ __forceinline__ u32x4 alibi_pos_operand(int lane) {       // the operand indexed by register position
+    using E = Elem<T>;
+    u32x4 r = {0, 0, 0, 0};
+    if ((lane >> 5) == 0) {
+        const float pos = (float)(lane & 31);
+        r[0] = E::pack2(pos, pos);
+        r[1] = E::pack2(1.f, 1.f);
+        r[2] = E::pack2(1.f, 1.f);
+        r[3] = E::pack2(1.f, 0.f);
+    }
+    return r;
+}
+template <typename T>
+__device__ __forceinline__ uint32_t split2_16(float x) {
+    using E = Elem<T>;
+    const float hi = E::lo(E::pack2(x, 0.f));
+    return E::pack2(hi, x - hi);
+}
+// sv = slope / softmax_scale; pos_sign: sign of the register-position term; lane_term, tile_term in key units
+template <typename T>
+__device__ __forceinline__ u32x4 alibi_lane_operand(int lane, float sv, float pos_sign, float lane_term, float tile_term) {
+    using E = Elem<T>;
+    u32x4 r = {0, 0, 0, 0};
+    if ((lane >> 5) == 0) {
+        r[0] = split2_16<T>(pos_sign * sv);
+        r[1] = split2_16<T>(sv * lane_term);
+        const float x = sv * tile_term;
+        const float hi = E::lo(E::pack2(x, 0.f));
+        const float mid = E::lo(E::pack2(x - hi, 0.f));
+        r[2] = E::pack2(hi, mid);
+        r[3] = E::pack2(x - hi - mid, 0.f);
+    }
+    return r;
+}
+
 // One 32 x 32 (query, key) sub-tile holds at least one visible pair.  The dK/dV kernel writes a dS
 // tile exactly when this is true and the dQ kernel reads exactly those tiles.
 __device__ __forceinline__ bool subtile_active(int q0, int k0, int seqlen_q, int seqlen_k, int off, int wl, int wr) {

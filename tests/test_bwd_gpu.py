@@ -62,6 +62,13 @@ CASES = [
     (2, 4, 2, 256, 256, 128, "bf16", False, (-1, -1), 30.0, False),   # softcap
     (1, 4, 4, 192, 192, 64, "fp16", True, (-1, -1), 15.0, True),
     (1, 2, 2, 512, 512, 128, "bf16", True, (-1, -1), 0.0, False),
+    # ALiBi: causal / window_right == 0 take the matrix-pipe path in both backward kernels, the rest the general one
+    (2, 8, 2, 700, 700, 128, "bf16", True, (-1, -1), 0.0, True),      # GQA (slope changes inside a dK/dV workgroup)
+    (1, 4, 4, 300, 520, 64, "fp16", True, (-1, -1), 0.0, True),       # Sq < Sk (off > 0)
+    (1, 4, 4, 520, 300, 128, "bf16", True, (-1, -1), 0.0, True),      # Sq > Sk (empty rows)
+    (1, 4, 4, 640, 640, 128, "bf16", False, (200, 0), 0.0, True),     # window_right == 0
+    (1, 4, 4, 320, 320, 128, "bf16", False, (-1, -1), 0.0, True),     # general path (keys right of the diagonal)
+    (1, 2, 2, 1500, 1500, 128, "fp16", True, (-1, -1), 0.0, True),    # long distances: tile term split three ways
 ]
 
 
