@@ -74,7 +74,10 @@ static int check_common(const fa_params& p, bool need_out) {
         const int64_t rows_q = p.cu_seqlens_q ? (p.total_q > 0 ? p.total_q : p.seqlen_q) : p.seqlen_q;
         const int64_t rows_k = p.block_table ? p.page_block_size
                                              : (p.cu_seqlens_k ? (p.total_k > 0 ? p.total_k : p.seqlen_k) : p.seqlen_k);
-        const int64_t lim = (int64_t)1 << 32;
+        FA_CHECK(p.head_dim_v >= 0 && p.head_dim_v <= p.head_dim && p.head_dim_v % 8 == 0,
+                 "head_dim_v must be a multiple of 8 in [0, head_dim]");
+        const bool narrow = p.head_dim_v > 0 && p.head_dim_v < p.head_dim;
+        const int64_t lim = (int64_t)1 << (narrow ? 31 : 32);
         FA_CHECK(rows_q * p.q_row_stride * 2 < lim && rows_k * p.k_row_stride * 2 < lim && rows_k * p.v_row_stride * 2 < lim,
                  "one (batch, head) slice of q/k/v spans more than 4 GiB: not addressable by the gfx950 kernels");
     }

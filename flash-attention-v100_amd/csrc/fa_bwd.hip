@@ -40,7 +40,7 @@ __global__ void __launch_bounds__(256) bwd_preprocess_kernel(const KArgs a) {
     float acc = 0.f;
     int64_t b = 0, i = row;
     if (!p.cu_seqlens_q) { b = row / p.seqlen_q; i = row - b * p.seqlen_q; }
-    if (row < total_rows) {
+    if (row < total_rows && cc * 8 < valid_cols(p)) {
         const uint16_t* op = reinterpret_cast<const uint16_t*>(p.o) + b * p.o_batch_stride + i * p.o_row_stride +
                              (int64_t)h * p.o_head_stride + cc * 8;
         const uint16_t* dp = reinterpret_cast<const uint16_t*>(p.dout) + b * p.do_batch_stride + i * p.do_row_stride +
@@ -147,6 +147,7 @@ __global__ void __launch_bounds__(BWD_THREADS, 1) fa_bwd_dkdv_kernel(const KArgs
     }
     const uint64_t drop_n_glob = (uint64_t)p.seqlen_k;
 
+    const int dv = valid_cols(p);
     // loop-invariant staging geometry
 #ifndef FA_DKV_DMA
     // Q / dO tiles staged through registers (buffer_load -> ds_write after the MFMAs): measured
@@ -167,14 +168,14 @@ __global__ void __launch_bounds__(BWD_THREADS, 1) fa_bwd_dkdv_kernel(const KArgs
             const int inst = wave * CHUNKS + i;
             const int row = inst * ROWS_PI + lane / CPR;
             const int cbs = swzt_row_off<D>(row, (lane % CPR) * 16) - row * D * 2;
-            q_voff[i] = (uint32_t)(row * p.q_row_stride * 2 + cbs);
-            do_voff[i] = (uint32_t)(row * p.do_row_stride * 2 + cbs);
+            q_voff[i] = cbs < dv * 2 ? (uint32_t)(row * p.q_row_stride * 2 + cbs) : kOobVoff;
+            do_voff[i] = cbs < dv * 2 ? (uint32_t)(row * p.do_row_stride * 2 + cbs) : kOobVoff;
             t_lds[i] = inst * 1024;
         } else {
             const int cidx = tid + i * BWD_THREADS;
             const int row = cidx / CPR, cc = cidx % CPR;
-            q_voff[i] = (uint32_t)(row * p.q_row_stride + cc * 8) * 2u;
-            do_voff[i] = (uint32_t)(row * p.do_row_stride + cc * 8) * 2u;
+            q_voff[i] = cc * 8 < dv ? (uint32_t)(row * p.q_row_stride + cc * 8) * 2u : kOobVoff;
+            do_voff[i] = cc * 8 < dv ? (uint32_t)(row * p.do_row_stride + cc * 8) * 2u : kOobVoff;
             t_lds[i] = swzt_row_off<D>(row, cc * 16);
         }
     }
@@ -243,8 +244,9 @@ __global__ void __launch_bounds__(BWD_THREADS, 1) fa_bwd_dkdv_kernel(const KArgs
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks) {
             u32x4 z = {0, 0, 0, 0};
-            kf[ks] = ok ? *reinterpret_cast<const u32x4*>(kr + 16 * ks) : z;
-            vf[ks] = ok ? *reinterpret_cast<const u32x4*>(vr + 16 * ks) : z;
+            const bool okc = ok && 16 * ks + 8 * g < dv;
+            kf[ks] = okc ? *reinterpret_cast<const u32x4*>(kr + 16 * ks) : z;
+            vf[ks] = okc ? *reinterpret_cast<const u32x4*>(vr + 16 * ks) : z;
         }
     }
 
@@ -260,8 +262,8 @@ __global__ void __launch_bounds__(BWD_THREADS, 1) fa_bwd_dkdv_kernel(const KArgs
         const int gq = it / n_tiles;
         const int m0 = (mt0 + it - gq * n_tiles) * DKV_BQ;
         const int h = hk * group + gq;
-        const __amdgpu_buffer_rsrc_t q_rsrc = make_rsrc(q_base + (int64_t)h * p.q_head_stride, p.q_row_stride, sg.seqlen_q, D);
-        const __amdgpu_buffer_rsrc_t do_rsrc = make_rsrc(do_base + (int64_t)h * p.do_head_stride, p.do_row_stride, sg.seqlen_q, D);
+        const __amdgpu_buffer_rsrc_t q_rsrc = make_rsrc(q_base + (int64_t)h * p.q_head_stride, p.q_row_stride, sg.seqlen_q, dv);
+        const __amdgpu_buffer_rsrc_t do_rsrc = make_rsrc(do_base + (int64_t)h * p.do_head_stride, p.do_row_stride, sg.seqlen_q, dv);
         const uint32_t q_soff = (uint32_t)(m0 * p.q_row_stride * 2);
         const uint32_t do_soff = (uint32_t)(m0 * p.do_row_stride * 2);
         if (DMA) {
@@ -638,8 +640,10 @@ __global__ void __launch_bounds__(BWD_THREADS, 1) fa_bwd_dkdv_kernel(const KArgs
                 const float rp = DROPOUT ? a.rp_dropout : 1.0f;
                 v2[0] = E::pack2(dv_acc[d][4 * rq + 0] * rp, dv_acc[d][4 * rq + 1] * rp);
                 v2[1] = E::pack2(dv_acc[d][4 * rq + 2] * rp, dv_acc[d][4 * rq + 3] * rp);
-                *reinterpret_cast<u32x2*>(dkp + (dh * ADB + d) * 32 + 8 * rq + 4 * g) = k2;
-                *reinterpret_cast<u32x2*>(dvp + (dh * ADB + d) * 32 + 8 * rq + 4 * g) = v2;
+                if ((dh * ADB + d) * 32 + 8 * rq + 4 * g < dv) {
+                    *reinterpret_cast<u32x2*>(dkp + (dh * ADB + d) * 32 + 8 * rq + 4 * g) = k2;
+                    *reinterpret_cast<u32x2*>(dvp + (dh * ADB + d) * 32 + 8 * rq + 4 * g) = v2;
+                }
             }
     }
     }   // dh (column sweep)
@@ -684,8 +688,9 @@ __global__ void __launch_bounds__(BWD_THREADS, OCC) fa_bwd_dq_kernel(const KArgs
     const int64_t vb_off = p.cu_seqlens_k ? 0 : (int64_t)w.b * p.v_batch_stride;
     const uint16_t* kp = reinterpret_cast<const uint16_t*>(p.k) + kb_off + sg.k_row0 * p.k_row_stride + (int64_t)w.hk * p.k_head_stride;
     const uint16_t* vp = reinterpret_cast<const uint16_t*>(p.v) + vb_off + sg.k_row0 * p.v_row_stride + (int64_t)w.hk * p.v_head_stride;
-    const __amdgpu_buffer_rsrc_t k_rsrc = make_rsrc(kp, p.k_row_stride, sg.seqlen_k, D);
-    const __amdgpu_buffer_rsrc_t v_rsrc = make_rsrc(vp, p.v_row_stride, sg.seqlen_k, D);
+    const int dv = valid_cols(p);
+    const __amdgpu_buffer_rsrc_t k_rsrc = make_rsrc(kp, p.k_row_stride, sg.seqlen_k, dv);
+    const __amdgpu_buffer_rsrc_t v_rsrc = make_rsrc(vp, p.v_row_stride, sg.seqlen_k, dv);
     const uint32_t k_tile_bytes = (uint32_t)(DQ_BN * p.k_row_stride * 2);
     const uint32_t v_tile_bytes = (uint32_t)(DQ_BN * p.v_row_stride * 2);
     // LDS-DMA staging (see fa_fwd.hip): instruction `inst` = wave*CHUNKS + i covers ROWS_PI rows,
@@ -700,8 +705,8 @@ __global__ void __launch_bounds__(BWD_THREADS, OCC) fa_bwd_dq_kernel(const KArgs
         const int slot = lane % CPR;
         const int k_cb = swzt_row_off<D>(row, slot * 16) - row * D * 2;
         const int v_cb = swz_row_off<D>(row, slot * 16) - row * D * 2;
-        k_voff[i] = (uint32_t)(row * p.k_row_stride * 2 + k_cb);
-        v_voff[i] = (uint32_t)(row * p.v_row_stride * 2 + v_cb);
+        k_voff[i] = k_cb < dv * 2 ? (uint32_t)(row * p.k_row_stride * 2 + k_cb) : kOobVoff;
+        v_voff[i] = v_cb < dv * 2 ? (uint32_t)(row * p.v_row_stride * 2 + v_cb) : kOobVoff;
         k_lds[i] = inst * 1024;
         v_lds[i] = TILE + inst * 1024;
     }
@@ -768,8 +773,9 @@ __global__ void __launch_bounds__(BWD_THREADS, OCC) fa_bwd_dq_kernel(const KArgs
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks) {
             u32x4 z = {0, 0, 0, 0};
-            qf[ks] = ok ? *reinterpret_cast<const u32x4*>(qrow + 16 * ks) : z;
-            dof[ks] = ok ? *reinterpret_cast<const u32x4*>(dorow + 16 * ks) : z;
+            const bool okc = ok && 16 * ks + 8 * g < dv;
+            qf[ks] = okc ? *reinterpret_cast<const u32x4*>(qrow + 16 * ks) : z;
+            dof[ks] = okc ? *reinterpret_cast<const u32x4*>(dorow + 16 * ks) : z;
         }
         if (ok) {
             const int64_t so = (int64_t)w.b * p.lse_batch_stride + (int64_t)w.h * p.lse_head_stride + sg.q_row0 + my_row;
@@ -904,7 +910,7 @@ __global__ void __launch_bounds__(BWD_THREADS, OCC) fa_bwd_dq_kernel(const KArgs
                 u32x2 o2;
                 o2[0] = E::pack2(dq_acc[d][4 * rq + 0] * sc, dq_acc[d][4 * rq + 1] * sc);
                 o2[1] = E::pack2(dq_acc[d][4 * rq + 2] * sc, dq_acc[d][4 * rq + 3] * sc);
-                *reinterpret_cast<u32x2*>(dqp + d * 32 + 8 * rq + 4 * g) = o2;
+                if (d * 32 + 8 * rq + 4 * g < dv) *reinterpret_cast<u32x2*>(dqp + d * 32 + 8 * rq + 4 * g) = o2;
             }
     }
     }   // pass
@@ -947,7 +953,8 @@ __global__ void __launch_bounds__(BWD_THREADS, 2) fa_bwd_dq_from_ds_kernel(const
 
     const int64_t kb_off = p.cu_seqlens_k ? 0 : (int64_t)w.b * p.k_batch_stride;
     const uint16_t* kp = reinterpret_cast<const uint16_t*>(p.k) + kb_off + sg.k_row0 * p.k_row_stride + (int64_t)w.hk * p.k_head_stride;
-    const __amdgpu_buffer_rsrc_t k_rsrc = make_rsrc(kp, p.k_row_stride, sg.seqlen_k, D);
+    const int dv = valid_cols(p);
+    const __amdgpu_buffer_rsrc_t k_rsrc = make_rsrc(kp, p.k_row_stride, sg.seqlen_k, dv);
     const uint32_t k_tile_bytes = (uint32_t)(DQ_BN * p.k_row_stride * 2);
     constexpr int ROWS_PI = 64 / CPR;
     uint32_t k_voff[CHUNKS];
@@ -957,7 +964,7 @@ __global__ void __launch_bounds__(BWD_THREADS, 2) fa_bwd_dq_from_ds_kernel(const
         const int inst = wave * CHUNKS + i;
         const int row = inst * ROWS_PI + lane / CPR;
         const int k_cb = swzt_row_off<D>(row, (lane % CPR) * 16) - row * D * 2;
-        k_voff[i] = (uint32_t)(row * p.k_row_stride * 2 + k_cb);
+        k_voff[i] = k_cb < dv * 2 ? (uint32_t)(row * p.k_row_stride * 2 + k_cb) : kOobVoff;
         k_lds[i] = inst * 1024;
     }
     // dS tiles of this (batch, head): one descriptor, tile offsets travel in the scalar offset.
@@ -1072,7 +1079,7 @@ __global__ void __launch_bounds__(BWD_THREADS, 2) fa_bwd_dq_from_ds_kernel(const
                 u32x2 o2;
                 o2[0] = E::pack2(dq_acc[d][4 * rq + 0] * sc, dq_acc[d][4 * rq + 1] * sc);
                 o2[1] = E::pack2(dq_acc[d][4 * rq + 2] * sc, dq_acc[d][4 * rq + 3] * sc);
-                *reinterpret_cast<u32x2*>(dqp + d * 32 + 8 * rq + 4 * g) = o2;
+                if (d * 32 + 8 * rq + 4 * g < dv) *reinterpret_cast<u32x2*>(dqp + d * 32 + 8 * rq + 4 * g) = o2;
             }
     }
     }   // pass

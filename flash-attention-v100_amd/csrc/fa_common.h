@@ -312,6 +312,12 @@ __device__ __forceinline__ u32x4 alibi_lane_operand(int lane, float sv, float po
     return r;
 }
 
+// Valid columns of a row (fa_params::head_dim_v).  A 16-byte chunk at or past this column is fetched with
+// kOobVoff, an offset the buffer descriptor's range check turns into zeros (slices are < 2 GiB then, so
+// voffset + soffset cannot wrap), and is never stored.
+constexpr uint32_t kOobVoff = 0x80000000u;
+__device__ __forceinline__ int valid_cols(const fa_params& p) { return p.head_dim_v > 0 ? p.head_dim_v : p.head_dim; }
+
 // One 32 x 32 (query, key) sub-tile holds at least one visible pair.  The dK/dV kernel writes a dS
 // tile exactly when this is true and the dQ kernel reads exactly those tiles.
 __device__ __forceinline__ bool subtile_active(int q0, int k0, int seqlen_q, int seqlen_k, int off, int wl, int wr) {

@@ -140,6 +140,7 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : 2)) fa_fwd_kernel(
     float slope = 0.f;                                 // ALiBi slope (natural-log score units)
     if (BIAS && p.alibi_slopes) slope = p.alibi_slopes[w.b * p.alibi_batch_stride + w.h];
 
+    const int dv = valid_cols(p);
     // ---- Q fragments: B operand of S^T = K Q^T, lane holds Q[my_row][16ks + 8g .. +7] --------
     u32x4 qf[KSTEPS];
     {
@@ -148,7 +149,7 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : 2)) fa_fwd_kernel(
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks) {
             u32x4 z = {0, 0, 0, 0};
-            qf[ks] = ok ? *reinterpret_cast<const u32x4*>(qrow + 16 * ks) : z;
+            qf[ks] = (ok && 16 * ks + 8 * g < dv) ? *reinterpret_cast<const u32x4*>(qrow + 16 * ks) : z;
         }
     }
 
@@ -176,14 +177,14 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : 2)) fa_fwd_kernel(
             const int slot = lane % CPR;
             const int k_cb = swz_row_off<D>(row, slot * 16) - row * D * 2;      // logical byte column
             const int v_cb = swzt_row_off<D>(row, slot * 16) - row * D * 2;
-            k_voff[i] = (uint32_t)(row * p.k_row_stride * 2 + k_cb);
-            v_voff[i] = (uint32_t)(row * p.v_row_stride * 2 + v_cb);
+            k_voff[i] = k_cb < dv * 2 ? (uint32_t)(row * p.k_row_stride * 2 + k_cb) : kOobVoff;
+            v_voff[i] = v_cb < dv * 2 ? (uint32_t)(row * p.v_row_stride * 2 + v_cb) : kOobVoff;
             k_lds[i] = inst * 1024;                                             // wave-uniform destination
             v_lds[i] = TILE + inst * 1024;
         }
     }
-    const __amdgpu_buffer_rsrc_t k_rsrc = make_rsrc(kp, p.k_row_stride, PAGED ? 0 : seqlen_k, D);
-    const __amdgpu_buffer_rsrc_t v_rsrc = make_rsrc(vp, p.v_row_stride, PAGED ? 0 : seqlen_k, D);
+    const __amdgpu_buffer_rsrc_t k_rsrc = make_rsrc(kp, p.k_row_stride, PAGED ? 0 : seqlen_k, dv);
+    const __amdgpu_buffer_rsrc_t v_rsrc = make_rsrc(vp, p.v_row_stride, PAGED ? 0 : seqlen_k, dv);
     const uint32_t k_tile_bytes = (uint32_t)(FWD_BN * p.k_row_stride * 2);
     const uint32_t v_tile_bytes = (uint32_t)(FWD_BN * p.v_row_stride * 2);
 
@@ -199,7 +200,7 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : 2)) fa_fwd_kernel(
                 const int j = n0 + row;
                 u32x4 z = {0, 0, 0, 0};
                 kreg[i] = z; vreg[i] = z;
-                if (j < seqlen_k) {
+                if (j < seqlen_k && cc * 8 < dv) {
                     const int pos = j + (int)k_row0;
                     const int pg = pos / p.page_block_size;
                     const int pr = pos - pg * p.page_block_size;
@@ -434,7 +435,7 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : 2)) fa_fwd_kernel(
                 u32x2 o2;
                 o2[0] = E::pack2(oacc[d][4 * rq + 0] * inv, oacc[d][4 * rq + 1] * inv);
                 o2[1] = E::pack2(oacc[d][4 * rq + 2] * inv, oacc[d][4 * rq + 3] * inv);
-                *reinterpret_cast<u32x2*>(op + d * 32 + 8 * rq + 4 * g) = o2;
+                if (d * 32 + 8 * rq + 4 * g < dv) *reinterpret_cast<u32x2*>(op + d * 32 + 8 * rq + 4 * g) = o2;
             }
         if (g == 0) {
             const float lse = l_tot > 0.f ? (m_run + fast_log2(l_tot)) * kLn2 : -INFINITY;

@@ -39,7 +39,7 @@ class FaParams(ctypes.Structure):
         ("cu_seqlens_q", _ptr), ("cu_seqlens_k", _ptr), ("seqused_k", _ptr),
         ("total_q", _i32), ("total_k", _i32),
         ("block_table", _ptr), ("block_table_batch_stride", _i64),
-        ("page_block_size", _i32), ("_pad0", _i32),
+        ("page_block_size", _i32), ("head_dim_v", _i32),
         ("cache_seqlens", _ptr), ("cache_batch_idx", _ptr), ("cache_leftpad", _ptr),
         ("k_new", _ptr), ("v_new", _ptr),
         ("knew_batch_stride", _i64), ("knew_row_stride", _i64), ("knew_head_stride", _i64),

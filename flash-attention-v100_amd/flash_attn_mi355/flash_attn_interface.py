@@ -40,13 +40,21 @@ def _padded_head_dim(d: int) -> int:
     raise RuntimeError(f"head dimension {d} > 256 is not supported (reference limit, fused_mha_forward.cu:337)")
 
 
-def _prep(x: torch.Tensor, dpad: int) -> torch.Tensor:
-    """Last dim contiguous, 16-byte aligned rows, head dim padded with zeros to `dpad`."""
+def _prep(x: torch.Tensor, d8: int) -> torch.Tensor:
+    """Last dim contiguous, 16-byte aligned rows; the head dim is padded only up to the next multiple of 8
+    (`d8`, as the reference does, flash_attn_interface.py:44-49).  The kernel width (64 / 128 / 256) is NOT
+    materialised: the C ABI's head_dim_v makes the kernels read the missing columns as zeros."""
     d = x.shape[-1]
-    if d != dpad:
-        x = torch.nn.functional.pad(x, [0, dpad - d])
+    if d != d8:
+        x = torch.nn.functional.pad(x, [0, d8 - d])
     ok = x.stride(-1) == 1 and x.data_ptr() % 16 == 0 and all(s % 8 == 0 for s in x.stride()[:-1])
     return x if ok else x.contiguous()
+
+
+def _set_head_dim(p, d8: int):
+    """kernel width + valid columns"""
+    p.head_dim = _padded_head_dim(d8)
+    p.head_dim_v = d8 if d8 != p.head_dim else 0
 
 
 def _check_device(*tensors):
@@ -133,7 +141,8 @@ def _dense_forward(q, k, v, dropout_p, softmax_scale, causal, window_size, softc
         raise RuntimeError("q must be fp16 or bf16")
     B, M, H_Q, head_size_og = q.shape
     N, H_K = k.shape[1], k.shape[2]
-    dpad = _padded_head_dim(head_size_og)
+    dpad = (head_size_og + 7) // 8 * 8
+    _padded_head_dim(dpad)                                   # raises above 256
     q_, k_, v_ = _prep(q, dpad), _prep(k, dpad), _prep(v, dpad)
     if softmax_scale is None:
         softmax_scale = head_size_og ** -0.5
@@ -146,7 +155,8 @@ def _dense_forward(q, k, v, dropout_p, softmax_scale, causal, window_size, softc
     _set3(p, "o", out_, "bshd")
     p.lse_batch_stride, p.lse_head_stride = lse.stride(0), lse.stride(1)
     p.batch, p.nheads_q, p.nheads_k = B, H_Q, H_K
-    p.seqlen_q, p.seqlen_k, p.head_dim = M, N, dpad
+    p.seqlen_q, p.seqlen_k = M, N
+    _set_head_dim(p, dpad)
     _alibi(p, alibi_slopes, B, H_Q, q.device)
     rng = _philox(p, dropout_p, B, H_Q, q.device)
     dmask = torch.empty((0,), dtype=q.dtype, device=q.device)
@@ -174,7 +184,8 @@ def _dense_backward(dout, q_, k_, v_, out_, lse, alibi_slopes, dropout_p, softma
         _set3(p, name, t, "bshd")
     p.lse_batch_stride, p.lse_head_stride = lse.stride(0), lse.stride(1)
     p.batch, p.nheads_q, p.nheads_k = B, H_Q, H_K
-    p.seqlen_q, p.seqlen_k, p.head_dim = M, N, dpad
+    p.seqlen_q, p.seqlen_k = M, N
+    _set_head_dim(p, dpad)
     _alibi(p, alibi_slopes, B, H_Q, q_.device)
     _philox(p, dropout_p, B, H_Q, q_.device, rng=rng)
     ws = _workspace(_lib.lib.fa_bwd_workspace_bytes(ctypes.byref(p)), q_.device)
@@ -324,7 +335,8 @@ def _varlen_forward(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqle
     cu_seqlens_q = cu_seqlens_q.to(torch.int32).contiguous()
     cu_seqlens_k = cu_seqlens_k.to(torch.int32).contiguous()
     head_size_og = q.size(-1)
-    dpad = _padded_head_dim(head_size_og)
+    dpad = (head_size_og + 7) // 8 * 8
+    _padded_head_dim(dpad)                                   # raises above 256
     q_, k_, v_ = _prep(q, dpad), _prep(k, dpad), _prep(v, dpad)
     if softmax_scale is None:
         softmax_scale = head_size_og ** -0.5
@@ -341,7 +353,8 @@ def _varlen_forward(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqle
     _set3(p, "k", k_, "pshd" if paged else "thd"); _set3(p, "v", v_, "pshd" if paged else "thd")
     p.lse_batch_stride, p.lse_head_stride = 0, lse.stride(0)
     p.batch, p.nheads_q, p.nheads_k = B, H_Q, H_K
-    p.seqlen_q, p.seqlen_k, p.head_dim = int(max_seqlen_q), int(max_seqlen_k), dpad
+    p.seqlen_q, p.seqlen_k = int(max_seqlen_q), int(max_seqlen_k)
+    _set_head_dim(p, dpad)
     p.cu_seqlens_q, p.cu_seqlens_k = _ptr(cu_seqlens_q), _ptr(cu_seqlens_k)
     p.total_q = T_Q
     p.total_k = 0 if paged else k_.shape[0]
@@ -378,7 +391,8 @@ def _varlen_backward(dout, q_, k_, v_, out_, lse, cu_seqlens_q, cu_seqlens_k, al
         _set3(p, name, t, "thd")
     p.lse_batch_stride, p.lse_head_stride = 0, lse.stride(0)
     p.batch, p.nheads_q, p.nheads_k = B, H_Q, H_K
-    p.seqlen_q, p.seqlen_k, p.head_dim = int(max_seqlen_q), int(max_seqlen_k), dpad
+    p.seqlen_q, p.seqlen_k = int(max_seqlen_q), int(max_seqlen_k)
+    _set_head_dim(p, dpad)
     p.cu_seqlens_q, p.cu_seqlens_k = _ptr(cu_seqlens_q), _ptr(cu_seqlens_k)
     p.total_q, p.total_k = T_Q, k_.shape[0]
     _alibi(p, alibi_slopes, B, H_Q, q_.device)

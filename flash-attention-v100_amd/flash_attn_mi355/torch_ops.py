@@ -68,7 +68,7 @@ def bwd(dout: Tensor, q: Tensor, k: Tensor, v: Tensor, out: Tensor, softmax_lse:
         window_size_left: int, window_size_right: int, softcap: float, deterministic: bool,
         rng_state: Optional[Tensor]) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
     d = q.shape[-1]
-    dpad = _fi._padded_head_dim(d)
+    dpad = (d + 7) // 8 * 8
     q_, k_, v_, out_ = (_fi._prep(t, dpad) for t in (q, k, v, out))
     dq_, dk_, dv_ = torch.empty_like(q_), torch.empty_like(k_), torch.empty_like(v_)
     dq_, dk_, dv_ = (_fi._prep(t, dpad) for t in (dq_, dk_, dv_))
@@ -140,7 +140,7 @@ def varlen_bwd(dout: Tensor, q: Tensor, k: Tensor, v: Tensor, out: Tensor, softm
                is_causal: bool, window_size_left: int, window_size_right: int, softcap: float,
                deterministic: bool, rng_state: Optional[Tensor]) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
     d = q.shape[-1]
-    dpad = _fi._padded_head_dim(d)
+    dpad = (d + 7) // 8 * 8
     q_, k_, v_, out_ = (_fi._prep(t, dpad) for t in (q, k, v, out))
     dq_, dk_, dv_ = torch.empty_like(q_), torch.empty_like(k_), torch.empty_like(v_)
     dq_, dk_, dv_ = (_fi._prep(t, dpad) for t in (dq_, dk_, dv_))

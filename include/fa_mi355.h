@@ -85,7 +85,7 @@ typedef struct fa_params {
     int32_t seqlen_q;         /* dense: Sq; varlen: max_seqlen_q; kvcache: Tq */
     int32_t seqlen_k;         /* dense: Sk; varlen: max_seqlen_k; kvcache: cache capacity
                                  (S_max, or pages_per_seq * page_block_size when paged) */
-    int32_t head_dim;         /* 32, 64, 128 or 256 (multiple of 8 <= 256 is padded by the host layer) */
+    int32_t head_dim;         /* kernel width: 64, 128 or 256 */
     int32_t dtype;            /* fa_dtype of q/o/dout/dq/dk/dv */
     int32_t kv_dtype;         /* fa_dtype of k/v (== dtype, or FA_FP8_E4M3 for fa_fwd_kvcache) */
 
@@ -117,7 +117,10 @@ typedef struct fa_params {
     const int32_t* block_table;     /* [B, max_blocks] or NULL */
     int64_t        block_table_batch_stride;
     int32_t        page_block_size;
-    int32_t        _pad0;
+    int32_t        head_dim_v;      /* valid columns of every row (multiple of 8, <= head_dim); 0 = head_dim.
+                                       Columns [head_dim_v, head_dim) are read as zero and never written: odd
+                                       head dims (40, 80, 96, 192 ...) run on the next kernel width without
+                                       padded copies of the tensors. */
 
     /* ---- KV cache (fa_fwd_kvcache) ---- */
     const int32_t* cache_seqlens;   /* [B] or NULL (=0) */

@@ -136,6 +136,28 @@ def test_head_dims_of_the_reference(D, dt):
     assert_close(t(dv), g[2], dt, "dv", mult=2.0)
 
 
+@pytest.mark.parametrize("D,dt", [(96, "bf16"), (80, "fp16"), (40, "bf16"), (192, "fp16"), (36, "fp16")])
+def test_odd_head_dims_without_padded_copies(D, dt):
+    """Head dims between the kernel widths run through head_dim_v (columns past D read as zero, never
+    written): results equal the oracle at the true D, and the tensors handed to the C ABI are the
+    caller's own (no padded copies) when D is a multiple of 8."""
+    B, S, H, Hk = 2, 200, 4, 2
+    q = rand16((B, S, H, D), dt, 421).requires_grad_(True)
+    k = rand16((B, S, Hk, D), dt, 422).requires_grad_(True)
+    v = rand16((B, S, Hk, D), dt, 423).requires_grad_(True)
+    do = rand16((B, S, H, D), dt, 424)
+    out, lse, _ = _fa().flash_attn_func(q, k, v, causal=True, return_attn_probs=True)
+    assert out.shape == q.shape
+    dq, dk, dv = torch.autograd.grad(out, (q, k, v), do)
+    tr = lambda t: f64(t).transpose(0, 2, 1, 3)
+    o_ref, lse_ref, _ = oracle.attn_fwd(tr(q), tr(k), tr(v), D ** -0.5, causal=True)
+    g_ref = oracle.attn_bwd(tr(do), tr(q), tr(k), tr(v), tr(out), f64(lse), D ** -0.5, causal=True)
+    assert_close(tr(out), o_ref, dt, "out")
+    for name, got, ref in (("dq", dq, g_ref[0]), ("dk", dk, g_ref[1]), ("dv", dv, g_ref[2])):
+        assert got.shape[-1] == D
+        assert_close(tr(got), ref, dt, name, mult=1.5)
+
+
 def test_ds_handoff_path_matches_default():
     """Opt-in variant (FA_BWD_DS_MAX_GB): the dK/dV kernel hands dS tiles to a one-GEMM dQ kernel.
     dK / dV come from the unchanged kernel (bit-identical); dQ sums the same products in another
