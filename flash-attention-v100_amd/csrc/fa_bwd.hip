@@ -397,10 +397,13 @@ __global__ void __launch_bounds__(BWD_THREADS, 1) fa_bwd_dkdv_kernel(const KArgs
             dsv[r] = dsr;
         }
         if (need_mask) {
+            const int lo_t = qlo - q0 - 4 * g;
+            const uint32_t width = (uint32_t)(qhi - qlo);
+            const bool empty = qhi < qlo;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int qi = q0 + (r & 3) + 8 * (r >> 2) + 4 * g;
-                if (qi < qlo || qi > qhi) { pv[r] = 0.f; dsv[r] = 0.f; }
+                const int cpos = (r & 3) + 8 * (r >> 2);
+                if (empty || (uint32_t)(cpos - lo_t) > width) { pv[r] = 0.f; dsv[r] = 0.f; }
             }
         }
         // k-step t of phase bk covers regs 8t .. 8t+7
@@ -859,10 +862,13 @@ __global__ void __launch_bounds__(BWD_THREADS, OCC) fa_bwd_dq_kernel(const KArgs
                 dsv[r] = dsr;
             }
             if (need_mask) {
+                const int lo_t = lo - n0 - kb * 32 - 4 * g;
+                const uint32_t width = (uint32_t)(hi - lo);
+                const bool empty = hi < lo;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int j = n0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
-                    if (j < lo || j > hi) dsv[r] = 0.f;
+                    const int cpos = (r & 3) + 8 * (r >> 2);
+                    if (empty || (uint32_t)(cpos - lo_t) > width) dsv[r] = 0.f;
                 }
             }
             // dQ^T += K^T dS^T

@@ -313,12 +313,17 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : 2)) fa_fwd_kernel(
         }
         const bool need_mask = (n0 + FWD_BN - 1 > w_hi_min) || (n0 < w_lo_max);
         if (need_mask) {
+            // the key of register (kb, r) is n0 + 4 g + c with c a compile-time constant: one unsigned
+            // compare of (c - lo_t) against the band width instead of rebuilding j per element
+            const int lo_t = lo - n0 - 4 * g;
+            const uint32_t width = (uint32_t)(hi - lo);                    // hi < lo (empty row) -> huge: see below
+            const bool empty = hi < lo;
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int j = n0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
-                    if (j < lo || j > hi) sacc[kb][r] = -INFINITY;
+                    const int cpos = kb * 32 + (r & 3) + 8 * (r >> 2);
+                    if (empty || (uint32_t)(cpos - lo_t) > width) sacc[kb][r] = -INFINITY;
                 }
         }
         // ---- online softmax (log2 domain) with deferred rescale ----
