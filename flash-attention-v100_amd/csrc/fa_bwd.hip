@@ -654,6 +654,312 @@ __global__ void __launch_bounds__(BWD_THREADS, 1) fa_bwd_dkdv_kernel(const KArgs
 }
 
 // ---------------------------------------------------------------------------------------------
+// 2b. dK / dV, two workgroups per CU
+// ---------------------------------------------------------------------------------------------
+// The one-wave-per-SIMD kernel above cannot overlap anything (knock-out: loads 0.39 + S/dP 0.31 + VALU
+// 0.26 + dV/dK 0.32 + rest 0.26 ms add up to its 1.54 ms).  This variant fits 256 registers and 80 KiB of
+// LDS so that TWO independent workgroups share a CU and one computes while the other loads or does its
+// exp2 / dS arithmetic (the mechanism that carries the forward and dQ kernels):
+//   * the 128 keys' K and V tiles live in LDS (64 KiB); their B fragments are re-read per use
+//     (the register version keeps them in 64 registers);
+//   * Q / dO arrive in 32-row single-buffered stages (16 KiB) by LDS-DMA - no staging registers;
+//   * the 32 row statistics of a stage sit in one register per lane (lanes 0..31 lse2, 32..63 D) and are
+//     gathered per accumulator register with ds_bpermute_b32 (crossbar only, no LDS space: there is
+//     none left - 2 x 81920 B is exactly the CU's 160 KiB).
+constexpr int DKV2_BQ = 32;
+template <int D> struct Dkv2Smem {
+    static constexpr int KT = DKV_BN * D * 2;            // K (or V) tile
+    static constexpr int QT = DKV2_BQ * D * 2;           // Q (or dO) stage
+#ifndef FA_DKV2_PADLDS
+#define FA_DKV2_PADLDS 0
+#endif
+#ifdef FA_DKV2_VLDS
+    static constexpr int TOTAL = 2 * KT + 2 * QT + FA_DKV2_PADLDS;          // K, V tiles + one stage
+#else
+    static constexpr int TOTAL = KT + 4 * QT + FA_DKV2_PADLDS;              // K tile + two stages (V fragments in registers)
+#endif
+};
+
+template <typename T, int D, int BIAS>
+__global__ void __launch_bounds__(BWD_THREADS, 2) fa_bwd_dkdv2_kernel(const KArgs a) {
+    using E = Elem<T>;
+    constexpr int KSTEPS = D / 16;
+    constexpr int DBLKS = D / 32;
+    constexpr int CPR = D / 8;
+    constexpr int KT = Dkv2Smem<D>::KT;
+    constexpr int QT = Dkv2Smem<D>::QT;
+    constexpr int ROWS_PI = 64 / CPR;                        // rows per 1-KiB DMA instruction
+    constexpr int K_INSTS = DKV_BN / ROWS_PI / 4;            // per wave, per tensor
+    constexpr int Q_INSTS = DKV2_BQ / ROWS_PI / 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef FA_DKV2_VLDS
+    constexpr bool VREG = false;
+    constexpr int NSTG = 1;
+    char* const ks_base = smem;                              // K tile   [128][D]  swz  (row reads)
+    char* const vs_base = smem + KT;                         // V tile
+    char* const stg_base = smem + 2 * KT;                    // Q stage  [32][D]   swzt (row + transposed reads), dO stage
+#else
+    constexpr bool VREG = true;                              // V fragments in registers: room for a second stage
+    constexpr int NSTG = 2;
+    char* const ks_base = smem;
+    char* const vs_base = smem;                              // (unused)
+    char* const stg_base = smem + KT;
+#endif
+
+    const fa_params& p = a.p;
+    const int n_kblocks = (p.seqlen_k + DKV_BN - 1) / DKV_BN;
+    const bool pair = a.pair_qblocks && n_kblocks >= 2;
+    const int n_kb_grid = pair ? (n_kblocks + 1) / 2 : n_kblocks;
+    int b, hk, nb0;
+    {
+        const int id = blockIdx.x, xcd = id & 7, j = id >> 3;
+        const int ul = j / n_kb_grid;
+        nb0 = j - ul * n_kb_grid;
+        const int unit = ul * 8 + xcd;
+        if (unit >= p.batch * p.nheads_k) return;
+        b = unit / p.nheads_k; hk = unit - b * p.nheads_k;
+    }
+    const SeqGeom sg = seq_geom(p, b);
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, g = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int group = p.nheads_q / p.nheads_k;
+    const int off = sg.off;
+    const int wl = p.window_left;
+    const int wr = p.is_causal ? 0 : p.window_right;
+    const float c = a.scale_log2e;
+    const int dv = valid_cols(p);
+
+    // DMA geometry: instruction `inst` covers ROWS_PI rows; lane -> (row, physical 16-byte slot); the source
+    // offset carries the swizzle (and the out-of-range trick for columns past head_dim_v)
+    uint32_t k_voff[K_INSTS], v_voff[K_INSTS], q_voff[Q_INSTS], do_voff[Q_INSTS];
+#pragma unroll
+    for (int i = 0; i < K_INSTS; ++i) {
+        const int row = (wave * K_INSTS + i) * ROWS_PI + lane / CPR;
+        const int cbs = swz_row_off<D>(row, (lane % CPR) * 16) - row * D * 2;
+        k_voff[i] = cbs < dv * 2 ? (uint32_t)(row * p.k_row_stride * 2 + cbs) : kOobVoff;
+        v_voff[i] = cbs < dv * 2 ? (uint32_t)(row * p.v_row_stride * 2 + cbs) : kOobVoff;
+    }
+#pragma unroll
+    for (int i = 0; i < Q_INSTS; ++i) {
+        const int row = (wave * Q_INSTS + i) * ROWS_PI + lane / CPR;
+        const int cbs = swzt_row_off<D>(row, (lane % CPR) * 16) - row * D * 2;
+        q_voff[i] = cbs < dv * 2 ? (uint32_t)(row * p.q_row_stride * 2 + cbs) : kOobVoff;
+        do_voff[i] = cbs < dv * 2 ? (uint32_t)(row * p.do_row_stride * 2 + cbs) : kOobVoff;
+    }
+    const int64_t qb_off = p.cu_seqlens_q ? 0 : (int64_t)b * p.q_batch_stride;
+    const int64_t dob_off = p.cu_seqlens_q ? 0 : (int64_t)b * p.do_batch_stride;
+    const uint16_t* q_base = reinterpret_cast<const uint16_t*>(p.q) + qb_off + sg.q_row0 * p.q_row_stride;
+    const uint16_t* do_base = reinterpret_cast<const uint16_t*>(p.dout) + dob_off + sg.q_row0 * p.do_row_stride;
+    const float* lse_base = p.lse + (int64_t)b * p.lse_batch_stride + sg.q_row0;
+    const float* dsum_base = p.softmax_d + (int64_t)b * p.lse_batch_stride + sg.q_row0;
+    const int64_t kb_off = p.cu_seqlens_k ? 0 : (int64_t)b * p.k_batch_stride;
+    const int64_t vb_off = p.cu_seqlens_k ? 0 : (int64_t)b * p.v_batch_stride;
+    const uint16_t* k_head = reinterpret_cast<const uint16_t*>(p.k) + kb_off + sg.k_row0 * p.k_row_stride + (int64_t)hk * p.k_head_stride;
+    const uint16_t* v_head = reinterpret_cast<const uint16_t*>(p.v) + vb_off + sg.k_row0 * p.v_row_stride + (int64_t)hk * p.v_head_stride;
+    const __amdgpu_buffer_rsrc_t k_rsrc = make_rsrc(k_head, p.k_row_stride, sg.seqlen_k, dv);
+    const __amdgpu_buffer_rsrc_t v_rsrc = make_rsrc(v_head, p.v_row_stride, sg.seqlen_k, dv);
+    // lane-constant LDS read offsets
+    int a_rd[KSTEPS], kv_rd[KSTEPS];
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+        a_rd[ks] = swzt_row_off<D>(l31, 32 * ks + 16 * g);
+        kv_rd[ks] = swz_row_off<D>(wave * 32 + l31, 32 * ks + 16 * g);
+    }
+    const int rr = (lane & 15) >> 2;
+    const int cb = (((lane >> 4) & 1) << 5) + ((lane & 3) << 3);
+    const u32x4 alibi_a = alibi_pos_operand<T>(lane);
+
+    const int n_pass = (pair && (n_kblocks - 1 - nb0) != nb0) ? 2 : 1;
+    for (int pass = 0; pass < n_pass; ++pass) {
+    const int nb = pass == 0 ? nb0 : n_kblocks - 1 - nb0;
+    const int n0 = nb * DKV_BN;
+    if (n0 >= sg.seqlen_k) continue;
+
+    const int kw0 = n0 + wave * 32;
+    const int my_key = kw0 + l31;
+    int qlo = 0, qhi = sg.seqlen_q - 1;
+    if (wr >= 0) { const int t = my_key - off - wr; qlo = t > qlo ? t : qlo; }
+    if (wl >= 0) { const int t = my_key - off + wl; qhi = t < qhi ? t : qhi; }
+    if (my_key >= sg.seqlen_k) { qlo = 0x7fffffff; qhi = -1; }
+    const int kw_last = (kw0 + 31 < sg.seqlen_k ? kw0 + 31 : sg.seqlen_k - 1);
+    int w_qlo_min = 0, w_qlo_max = 0, w_qhi_min = sg.seqlen_q - 1, w_qhi_max = sg.seqlen_q - 1;
+    if (wr >= 0) {
+        const int t0 = kw0 - off - wr, t1 = kw_last - off - wr;
+        w_qlo_min = t0 > 0 ? t0 : 0; w_qlo_max = t1 > 0 ? t1 : 0;
+    }
+    if (wl >= 0) {
+        const int t0 = kw0 - off + wl, t1 = kw_last - off + wl;
+        w_qhi_min = t0 < w_qhi_min ? t0 : w_qhi_min; w_qhi_max = t1 < w_qhi_max ? t1 : w_qhi_max;
+    }
+    const bool wave_has_keys = kw0 < sg.seqlen_k;
+    const bool key_tail = kw0 + 31 >= sg.seqlen_k;
+    int m_lo = 0, m_hi = sg.seqlen_q;
+    {
+        const int n_last = (n0 + DKV_BN < sg.seqlen_k ? n0 + DKV_BN : sg.seqlen_k) - 1;
+        if (wr >= 0) { const int t = n0 - off - wr; m_lo = t > 0 ? t : 0; }
+        if (wl >= 0) { const int t = n_last - off + wl + 1; m_hi = t < m_hi ? t : m_hi; }
+    }
+    const int mt0 = m_lo / DKV2_BQ;
+    const int mt1 = m_hi > m_lo ? (m_hi + DKV2_BQ - 1) / DKV2_BQ : mt0;
+    const int n_tiles = mt1 - mt0;
+    const int n_iter = n_tiles * group;
+
+    // ---- K / V tiles of the 128 keys -> LDS ----
+    __syncthreads();                                         // the previous pass is done with the LDS
+    {
+        const uint32_t ksoff = (uint32_t)(n0 * p.k_row_stride * 2), vsoff = (uint32_t)(n0 * p.v_row_stride * 2);
+#pragma unroll
+        for (int i = 0; i < K_INSTS; ++i) {
+            buf_load_lds_b128(k_rsrc, ks_base + (wave * K_INSTS + i) * 1024, k_voff[i], ksoff);
+            if (!VREG) buf_load_lds_b128(v_rsrc, vs_base + (wave * K_INSTS + i) * 1024, v_voff[i], vsoff);
+        }
+    }
+    u32x4 vf[VREG ? KSTEPS : 1];
+    if (VREG) {
+        const uint16_t* vr = v_head + (int64_t)my_key * p.v_row_stride + 8 * g;
+        const bool ok = my_key < sg.seqlen_k;
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            u32x4 z = {0, 0, 0, 0};
+            vf[ks] = (ok && 16 * ks + 8 * g < dv) ? *reinterpret_cast<const u32x4*>(vr + 16 * ks) : z;
+        }
+    }
+
+    f32x16 dk_acc[DBLKS], dv_acc[DBLKS];
+#pragma unroll
+    for (int d = 0; d < DBLKS; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dk_acc[d][r] = 0.f; dv_acc[d][r] = 0.f; }
+
+    // stage `it` lives in buffer it % NSTG.  Two buffers: the DMA of stage it+1 is issued right after the
+    // barrier that opens stage it and lands behind its compute (one barrier per stage).
+    auto issue_stage = [&](int it, float& stat_out) {
+        const int gq = it / n_tiles;
+        const int q0 = (mt0 + it - gq * n_tiles) * DKV2_BQ;
+        const int h = hk * group + gq;
+        char* qd = stg_base + (it % NSTG) * 2 * QT;
+        const __amdgpu_buffer_rsrc_t q_rsrc = make_rsrc(q_base + (int64_t)h * p.q_head_stride, p.q_row_stride, sg.seqlen_q, dv);
+        const __amdgpu_buffer_rsrc_t do_rsrc = make_rsrc(do_base + (int64_t)h * p.do_head_stride, p.do_row_stride, sg.seqlen_q, dv);
+        const uint32_t q_soff = (uint32_t)(q0 * p.q_row_stride * 2), do_soff = (uint32_t)(q0 * p.do_row_stride * 2);
+#pragma unroll
+        for (int i = 0; i < Q_INSTS; ++i) {
+            buf_load_lds_b128(q_rsrc, qd + (wave * Q_INSTS + i) * 1024, q_voff[i], q_soff);
+            buf_load_lds_b128(do_rsrc, qd + QT + (wave * Q_INSTS + i) * 1024, do_voff[i], do_soff);
+        }
+        const int qi = q0 + l31;
+        const int qc = qi < sg.seqlen_q ? qi : (sg.seqlen_q > 0 ? sg.seqlen_q - 1 : 0);
+        const float x = (g ? dsum_base : lse_base)[(int64_t)h * p.lse_head_stride + qc];
+        stat_out = qi < sg.seqlen_q ? (g ? x : x * kLog2e) : 0.f;
+    };
+    float statv = 0.f, stat_next = 0.f;
+    if (NSTG == 2 && n_iter > 0) issue_stage(0, stat_next);
+#pragma unroll 1
+    for (int it = 0; it < n_iter; ++it) {
+        const int gq = it / n_tiles;
+        const int q0 = (mt0 + it - gq * n_tiles) * DKV2_BQ;
+        const int h = hk * group + gq;
+        if (NSTG == 1) {
+            if (it > 0) __syncthreads();                     // everyone is done reading the previous stage
+            issue_stage(it, statv);
+            __syncthreads();                                 // (hipcc waits for the DMA in front of the barrier)
+        } else {
+            __syncthreads();                                 // stage it landed (vmcnt(0) before the barrier) and
+            statv = stat_next;                               // everyone left stage it-1, whose buffer is re-filled:
+            if (it + 1 < n_iter) issue_stage(it + 1, stat_next);
+        }
+        const char* qs = stg_base + (it % NSTG) * 2 * QT;
+        const char* dos = qs + QT;
+
+        const bool active = wave_has_keys && (q0 <= w_qhi_max) && (q0 + 31 >= w_qlo_min);
+        if (!active) continue;
+        // ---- S = Q K^T, dP = dO V^T ----
+        f32x16 s_acc, dp_acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s_acc[r] = 0.f; dp_acc[r] = 0.f; }
+        if (BIAS == 2) {
+            const float slope = p.alibi_slopes[b * p.alibi_batch_stride + h];
+            const u32x4 ab = alibi_lane_operand<T>(lane, slope / p.softmax_scale, -1.f, (float)l31, (float)(kw0 - off - q0));
+            s_acc = E::mfma(alibi_a, ab, s_acc);
+        }
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            const u32x4 qa = lds_read_b128(qs + a_rd[ks]);
+            const u32x4 kb2 = lds_read_b128(ks_base + kv_rd[ks]);
+            const u32x4 da = lds_read_b128(dos + a_rd[ks]);
+            u32x4 vb2;
+            if (VREG) vb2 = vf[ks]; else vb2 = lds_read_b128(vs_base + kv_rd[ks]);
+            s_acc = E::mfma(qa, kb2, s_acc);
+            dp_acc = E::mfma(da, vb2, dp_acc);
+        }
+        // ---- P, dS ----
+        const bool need_mask = key_tail || (q0 < w_qlo_max) || (q0 + 31 > w_qhi_min);
+        const int lo_t = qlo - q0 - 4 * g;
+        const uint32_t width = (uint32_t)(qhi - qlo);
+        const bool empty = qhi < qlo;
+        u32x4 pf[2], dsf[2];
+        const int sidx = 16 * g;                             // byte index of lane 4 g for ds_bpermute
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float pv[4], dsv[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = 4 * i + e;
+                const int cpos = e + 8 * i;                  // row = cpos + 4 g
+                const float l2 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(sidx + 4 * cpos, __builtin_bit_cast(int, statv)));
+                const float dsm = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(sidx + 4 * (32 + cpos), __builtin_bit_cast(int, statv)));
+                float pr = fast_exp2(fmaf(s_acc[r], c, -l2));
+                float dsr = pr * (dp_acc[r] - dsm);
+                if (need_mask && (empty || (uint32_t)(cpos - lo_t) > width)) { pr = 0.f; dsr = 0.f; }
+                pv[e] = pr; dsv[e] = dsr;
+            }
+            pf[i >> 1][2 * (i & 1)] = E::pack2(pv[0], pv[1]);
+            pf[i >> 1][2 * (i & 1) + 1] = E::pack2(pv[2], pv[3]);
+            dsf[i >> 1][2 * (i & 1)] = E::pack2(dsv[0], dsv[1]);
+            dsf[i >> 1][2 * (i & 1) + 1] = E::pack2(dsv[2], dsv[3]);
+        }
+        // ---- dV^T += dO^T P,  dK^T += Q^T dS ----
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int row_a = 16 * t + 4 * g + rr;
+#pragma unroll
+            for (int d = 0; d < DBLKS; ++d) {
+                const u32x2 a0 = lds_read_tr16(dos + swzt_row_off<D>(row_a, d * 64 + cb));
+                const u32x2 a1 = lds_read_tr16(dos + swzt_row_off<D>(row_a + 8, d * 64 + cb));
+                u32x4 af = {a0[0], a0[1], a1[0], a1[1]};
+                dv_acc[d] = E::mfma(af, pf[t], dv_acc[d]);
+                const u32x2 b0 = lds_read_tr16(qs + swzt_row_off<D>(row_a, d * 64 + cb));
+                const u32x2 b1 = lds_read_tr16(qs + swzt_row_off<D>(row_a + 8, d * 64 + cb));
+                u32x4 bfr = {b0[0], b0[1], b1[0], b1[1]};
+                dk_acc[d] = E::mfma(bfr, dsf[t], dk_acc[d]);
+            }
+        }
+    }
+
+    if (my_key < sg.seqlen_k) {
+        const int64_t dkb = p.cu_seqlens_k ? 0 : (int64_t)b * p.dk_batch_stride;
+        const int64_t dvb = p.cu_seqlens_k ? 0 : (int64_t)b * p.dv_batch_stride;
+        uint16_t* dkp = reinterpret_cast<uint16_t*>(p.dk) + dkb + (sg.k_row0 + my_key) * p.dk_row_stride + (int64_t)hk * p.dk_head_stride;
+        uint16_t* dvp = reinterpret_cast<uint16_t*>(p.dv) + dvb + (sg.k_row0 + my_key) * p.dv_row_stride + (int64_t)hk * p.dv_head_stride;
+        const float sc = p.softmax_scale;
+#pragma unroll
+        for (int d = 0; d < DBLKS; ++d)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                u32x2 k2, v2;
+                k2[0] = E::pack2(dk_acc[d][4 * rq + 0] * sc, dk_acc[d][4 * rq + 1] * sc);
+                k2[1] = E::pack2(dk_acc[d][4 * rq + 2] * sc, dk_acc[d][4 * rq + 3] * sc);
+                v2[0] = E::pack2(dv_acc[d][4 * rq + 0], dv_acc[d][4 * rq + 1]);
+                v2[1] = E::pack2(dv_acc[d][4 * rq + 2], dv_acc[d][4 * rq + 3]);
+                if (d * 32 + 8 * rq + 4 * g < dv) {
+                    *reinterpret_cast<u32x2*>(dkp + d * 32 + 8 * rq + 4 * g) = k2;
+                    *reinterpret_cast<u32x2*>(dvp + d * 32 + 8 * rq + 4 * g) = v2;
+                }
+            }
+    }
+    }   // pass
+}
+
+// ---------------------------------------------------------------------------------------------
 // 3. dQ
 // ---------------------------------------------------------------------------------------------
 constexpr int DQ_BM = 128;
@@ -1143,7 +1449,25 @@ static int launch_bwd_td(const KArgs& a, hipStream_t stream) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
             hipLaunchKernelGGL(kern, dim3(grid), dim3(BWD_THREADS), smem, stream, a);                             \
         } while (0)
-        if (grid > 0) {
+        // two-workgroups-per-CU kernel where it applies (6 % faster at config 2); FA_DKDV1 forces the other one
+        static const bool dkv2_env = getenv("FA_DKDV1") == nullptr;
+        bool done = false;
+        if constexpr (D <= 128) {
+            if (dkv2_env && !drop && !a.ds_ws && (!a.has_bias || lin_alibi) && grid > 0) {
+                const size_t smem2 = Dkv2Smem<D>::TOTAL;
+                if (a.has_bias) {
+                    auto kern = fa_bwd_dkdv2_kernel<T, D, 2>;
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2);
+                    hipLaunchKernelGGL(kern, dim3(grid), dim3(BWD_THREADS), smem2, stream, a);
+                } else {
+                    auto kern = fa_bwd_dkdv2_kernel<T, D, 0>;
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2);
+                    hipLaunchKernelGGL(kern, dim3(grid), dim3(BWD_THREADS), smem2, stream, a);
+                }
+                done = true;
+            }
+        }
+        if (grid > 0 && !done) {
             if (drop) { if (a.has_bias) FA_LAUNCH_DKV(1, true); else FA_LAUNCH_DKV(0, true); }
             else if (a.has_bias) { if (lin_alibi) FA_LAUNCH_DKV(2, false); else FA_LAUNCH_DKV(1, false); }
             else      FA_LAUNCH_DKV(0, false);
