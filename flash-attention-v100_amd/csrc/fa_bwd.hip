@@ -676,7 +676,8 @@ template <int D> struct Dkv2Smem {
 #ifdef FA_DKV2_VLDS
     static constexpr int TOTAL = 2 * KT + 2 * QT + FA_DKV2_PADLDS;          // K, V tiles + one stage
 #else
-    static constexpr int TOTAL = KT + 4 * QT + FA_DKV2_PADLDS;              // K tile + two stages (V fragments in registers)
+    static constexpr int STG = 2 * QT + 256;                                 // Q, dO, 64 row statistics
+    static constexpr int TOTAL = KT + 2 * STG + FA_DKV2_PADLDS;              // K tile + two stages (V fragments in registers)
 #endif
 };
 
@@ -695,12 +696,14 @@ __global__ void __launch_bounds__(BWD_THREADS, 2) fa_bwd_dkdv2_kernel(const KArg
 #ifdef FA_DKV2_VLDS
     constexpr bool VREG = false;
     constexpr int NSTG = 1;
+    constexpr int STG = 2 * QT;
     char* const ks_base = smem;                              // K tile   [128][D]  swz  (row reads)
     char* const vs_base = smem + KT;                         // V tile
     char* const stg_base = smem + 2 * KT;                    // Q stage  [32][D]   swzt (row + transposed reads), dO stage
 #else
     constexpr bool VREG = true;                              // V fragments in registers: room for a second stage
     constexpr int NSTG = 2;
+    constexpr int STG = Dkv2Smem<D>::STG;
     char* const ks_base = smem;
     char* const vs_base = smem;                              // (unused)
     char* const stg_base = smem + KT;
@@ -837,7 +840,7 @@ __global__ void __launch_bounds__(BWD_THREADS, 2) fa_bwd_dkdv2_kernel(const KArg
         const int gq = it / n_tiles;
         const int q0 = (mt0 + it - gq * n_tiles) * DKV2_BQ;
         const int h = hk * group + gq;
-        char* qd = stg_base + (it % NSTG) * 2 * QT;
+        char* qd = stg_base + (it % NSTG) * STG;
         const __amdgpu_buffer_rsrc_t q_rsrc = make_rsrc(q_base + (int64_t)h * p.q_head_stride, p.q_row_stride, sg.seqlen_q, dv);
         const __amdgpu_buffer_rsrc_t do_rsrc = make_rsrc(do_base + (int64_t)h * p.do_head_stride, p.do_row_stride, sg.seqlen_q, dv);
         const uint32_t q_soff = (uint32_t)(q0 * p.q_row_stride * 2), do_soff = (uint32_t)(q0 * p.do_row_stride * 2);
@@ -852,7 +855,11 @@ __global__ void __launch_bounds__(BWD_THREADS, 2) fa_bwd_dkdv2_kernel(const KArg
         stat_out = qi < sg.seqlen_q ? (g ? x : x * kLog2e) : 0.f;
     };
     float statv = 0.f, stat_next = 0.f;
-    if (NSTG == 2 && n_iter > 0) issue_stage(0, stat_next);
+    (void)statv;
+    if (NSTG == 2 && n_iter > 0) {
+        issue_stage(0, stat_next);
+        if (wave == 0) reinterpret_cast<float*>(stg_base + 2 * QT)[lane] = stat_next;     // stage 0's statistics
+    }
 #pragma unroll 1
     for (int it = 0; it < n_iter; ++it) {
         const int gq = it / n_tiles;
@@ -864,14 +871,17 @@ __global__ void __launch_bounds__(BWD_THREADS, 2) fa_bwd_dkdv2_kernel(const KArg
             __syncthreads();                                 // (hipcc waits for the DMA in front of the barrier)
         } else {
             __syncthreads();                                 // stage it landed (vmcnt(0) before the barrier) and
-            statv = stat_next;                               // everyone left stage it-1, whose buffer is re-filled:
-            if (it + 1 < n_iter) issue_stage(it + 1, stat_next);
+            if (it + 1 < n_iter) issue_stage(it + 1, stat_next);   // everyone left stage it-1: its buffer is re-filled
         }
-        const char* qs = stg_base + (it % NSTG) * 2 * QT;
+        const char* qs = stg_base + (it % NSTG) * STG;
         const char* dos = qs + QT;
 
         const bool active = wave_has_keys && (q0 <= w_qhi_max) && (q0 + 31 >= w_qlo_min);
-        if (!active) continue;
+        auto publish_stats = [&]() {      // next stage's statistics -> LDS (loaded a whole stage ago: no wait)
+            if (NSTG == 2 && wave == 0 && it + 1 < n_iter)
+                reinterpret_cast<float*>(stg_base + ((it + 1) % NSTG) * STG + 2 * QT)[lane] = stat_next;
+        };
+        if (!active) { publish_stats(); continue; }
         // ---- S = Q K^T, dP = dO V^T ----
         f32x16 s_acc, dp_acc;
 #pragma unroll
@@ -901,12 +911,22 @@ __global__ void __launch_bounds__(BWD_THREADS, 2) fa_bwd_dkdv2_kernel(const KArg
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             float pv[4], dsv[4];
+            f32x4 l4 = {0, 0, 0, 0}, d4 = {0, 0, 0, 0};
+            if (NSTG == 2) {
+                const float* st = reinterpret_cast<const float*>(qs + 2 * QT);
+                l4 = *reinterpret_cast<const f32x4*>(st + 8 * i + 4 * g);
+                d4 = *reinterpret_cast<const f32x4*>(st + 32 + 8 * i + 4 * g);
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int r = 4 * i + e;
                 const int cpos = e + 8 * i;                  // row = cpos + 4 g
-                const float l2 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(sidx + 4 * cpos, __builtin_bit_cast(int, statv)));
-                const float dsm = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(sidx + 4 * (32 + cpos), __builtin_bit_cast(int, statv)));
+                float l2, dsm;
+                if (NSTG == 2) { l2 = l4[e]; dsm = d4[e]; }
+                else {
+                    l2 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(sidx + 4 * cpos, __builtin_bit_cast(int, statv)));
+                    dsm = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(sidx + 4 * (32 + cpos), __builtin_bit_cast(int, statv)));
+                }
                 float pr = fast_exp2(fmaf(s_acc[r], c, -l2));
                 float dsr = pr * (dp_acc[r] - dsm);
                 if (need_mask && (empty || (uint32_t)(cpos - lo_t) > width)) { pr = 0.f; dsr = 0.f; }
@@ -933,6 +953,7 @@ __global__ void __launch_bounds__(BWD_THREADS, 2) fa_bwd_dkdv2_kernel(const KArg
                 dk_acc[d] = E::mfma(bfr, dsf[t], dk_acc[d]);
             }
         }
+        publish_stats();
     }
 
     if (my_key < sg.seqlen_k) {
