@@ -738,7 +738,7 @@ __global__ void __launch_bounds__(BWD_THREADS, 2) fa_bwd_dkdv2_kernel(const KArg
 #pragma unroll
     for (int i = 0; i < K_INSTS; ++i) {
         const int row = (wave * K_INSTS + i) * ROWS_PI + lane / CPR;
-        const int cbs = swz_row_off<D>(row, (lane % CPR) * 16) - row * D * 2;
+        const int cbs = swzt_row_off<D>(row, (lane % CPR) * 16) - row * D * 2;
         k_voff[i] = cbs < dv * 2 ? (uint32_t)(row * p.k_row_stride * 2 + cbs) : kOobVoff;
         v_voff[i] = cbs < dv * 2 ? (uint32_t)(row * p.v_row_stride * 2 + cbs) : kOobVoff;
     }
@@ -762,12 +762,11 @@ __global__ void __launch_bounds__(BWD_THREADS, 2) fa_bwd_dkdv2_kernel(const KArg
     const __amdgpu_buffer_rsrc_t k_rsrc = make_rsrc(k_head, p.k_row_stride, sg.seqlen_k, dv);
     const __amdgpu_buffer_rsrc_t v_rsrc = make_rsrc(v_head, p.v_row_stride, sg.seqlen_k, dv);
     // lane-constant LDS read offsets
-    int a_rd[KSTEPS], kv_rd[KSTEPS];
+    // (the K / V tiles use the same swizzle as the stages, so a key-row read is a_rd + a wave-uniform offset)
+    int a_rd[KSTEPS];
 #pragma unroll
-    for (int ks = 0; ks < KSTEPS; ++ks) {
-        a_rd[ks] = swzt_row_off<D>(l31, 32 * ks + 16 * g);
-        kv_rd[ks] = swz_row_off<D>(wave * 32 + l31, 32 * ks + 16 * g);
-    }
+    for (int ks = 0; ks < KSTEPS; ++ks) a_rd[ks] = swzt_row_off<D>(l31, 32 * ks + 16 * g);
+    const int kv_row0 = wave * 32 * D * 2;
     const int rr = (lane & 15) >> 2;
     const int cb = (((lane >> 4) & 1) << 5) + ((lane & 3) << 3);
     const u32x4 alibi_a = alibi_pos_operand<T>(lane);
@@ -836,9 +835,7 @@ __global__ void __launch_bounds__(BWD_THREADS, 2) fa_bwd_dkdv2_kernel(const KArg
 
     // stage `it` lives in buffer it % NSTG.  Two buffers: the DMA of stage it+1 is issued right after the
     // barrier that opens stage it and lands behind its compute (one barrier per stage).
-    auto issue_stage = [&](int it, float& stat_out) {
-        const int gq = it / n_tiles;
-        const int q0 = (mt0 + it - gq * n_tiles) * DKV2_BQ;
+    auto issue_stage = [&](int it, int gq, int q0, float& stat_out) {
         const int h = hk * group + gq;
         char* qd = stg_base + (it % NSTG) * STG;
         const __amdgpu_buffer_rsrc_t q_rsrc = make_rsrc(q_base + (int64_t)h * p.q_head_stride, p.q_row_stride, sg.seqlen_q, dv);
@@ -856,22 +853,25 @@ __global__ void __launch_bounds__(BWD_THREADS, 2) fa_bwd_dkdv2_kernel(const KArg
     };
     float statv = 0.f, stat_next = 0.f;
     (void)statv;
+    int gq = 0, mt = mt0;                                 // stage it = (q-head gq of the group, 32-row tile mt)
+    int gq_n = 0, mt_n = mt0;                             // the same for the stage being prefetched
+    auto advance = [&](int& gq_x, int& mt_x) { if (++mt_x == mt1) { mt_x = mt0; ++gq_x; } };
     if (NSTG == 2 && n_iter > 0) {
-        issue_stage(0, stat_next);
+        issue_stage(0, gq_n, mt_n * DKV2_BQ, stat_next);
         if (wave == 0) reinterpret_cast<float*>(stg_base + 2 * QT)[lane] = stat_next;     // stage 0's statistics
     }
 #pragma unroll 1
-    for (int it = 0; it < n_iter; ++it) {
-        const int gq = it / n_tiles;
-        const int q0 = (mt0 + it - gq * n_tiles) * DKV2_BQ;
+    for (int it = 0; it < n_iter; ++it, advance(gq, mt)) {
+        const int q0 = mt * DKV2_BQ;
         const int h = hk * group + gq;
         if (NSTG == 1) {
             if (it > 0) __syncthreads();                     // everyone is done reading the previous stage
-            issue_stage(it, statv);
+            issue_stage(it, gq, q0, statv);
             __syncthreads();                                 // (hipcc waits for the DMA in front of the barrier)
         } else {
             __syncthreads();                                 // stage it landed (vmcnt(0) before the barrier) and
-            if (it + 1 < n_iter) issue_stage(it + 1, stat_next);   // everyone left stage it-1: its buffer is re-filled
+            advance(gq_n, mt_n);                             // everyone left stage it-1: its buffer is re-filled
+            if (it + 1 < n_iter) issue_stage(it + 1, gq_n, mt_n * DKV2_BQ, stat_next);
         }
         const char* qs = stg_base + (it % NSTG) * STG;
         const char* dos = qs + QT;
@@ -894,10 +894,10 @@ __global__ void __launch_bounds__(BWD_THREADS, 2) fa_bwd_dkdv2_kernel(const KArg
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks) {
             const u32x4 qa = lds_read_b128(qs + a_rd[ks]);
-            const u32x4 kb2 = lds_read_b128(ks_base + kv_rd[ks]);
+            const u32x4 kb2 = lds_read_b128(ks_base + kv_row0 + a_rd[ks]);
             const u32x4 da = lds_read_b128(dos + a_rd[ks]);
             u32x4 vb2;
-            if (VREG) vb2 = vf[ks]; else vb2 = lds_read_b128(vs_base + kv_rd[ks]);
+            if (VREG) vb2 = vf[ks]; else vb2 = lds_read_b128(vs_base + kv_row0 + a_rd[ks]);
             s_acc = E::mfma(qa, kb2, s_acc);
             dp_acc = E::mfma(da, vb2, dp_acc);
         }
