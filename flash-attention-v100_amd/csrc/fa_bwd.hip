@@ -908,9 +908,10 @@ __global__ void __launch_bounds__(BWD_THREADS, 2) fa_bwd_dkdv2_kernel(const KArg
         const bool empty = qhi < qlo;
         u32x4 pf[2], dsf[2];
         const int sidx = 16 * g;                             // byte index of lane 4 g for ds_bpermute
+        (void)sidx;
+        float pv[16], dsv[16];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            float pv[4], dsv[4];
             f32x4 l4 = {0, 0, 0, 0}, d4 = {0, 0, 0, 0};
             if (NSTG == 2) {
                 const float* st = reinterpret_cast<const float*>(qs + 2 * QT);
@@ -927,16 +928,25 @@ __global__ void __launch_bounds__(BWD_THREADS, 2) fa_bwd_dkdv2_kernel(const KArg
                     l2 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(sidx + 4 * cpos, __builtin_bit_cast(int, statv)));
                     dsm = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(sidx + 4 * (32 + cpos), __builtin_bit_cast(int, statv)));
                 }
-                float pr = fast_exp2(fmaf(s_acc[r], c, -l2));
-                float dsr = pr * (dp_acc[r] - dsm);
-                if (need_mask && (empty || (uint32_t)(cpos - lo_t) > width)) { pr = 0.f; dsr = 0.f; }
-                pv[e] = pr; dsv[e] = dsr;
+                const float pr = fast_exp2(fmaf(s_acc[r], c, -l2));
+                pv[r] = pr;
+                dsv[r] = pr * (dp_acc[r] - dsm);
             }
-            pf[i >> 1][2 * (i & 1)] = E::pack2(pv[0], pv[1]);
-            pf[i >> 1][2 * (i & 1) + 1] = E::pack2(pv[2], pv[3]);
-            dsf[i >> 1][2 * (i & 1)] = E::pack2(dsv[0], dsv[1]);
-            dsf[i >> 1][2 * (i & 1) + 1] = E::pack2(dsv[2], dsv[3]);
         }
+        if (need_mask) {                                     // wave-uniform branch: interior tiles skip all of it
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int cpos = (r & 3) + 8 * (r >> 2);
+                if (empty || (uint32_t)(cpos - lo_t) > width) { pv[r] = 0.f; dsv[r] = 0.f; }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int w2 = 0; w2 < 4; ++w2) {
+                pf[t][w2] = E::pack2(pv[8 * t + 2 * w2], pv[8 * t + 2 * w2 + 1]);
+                dsf[t][w2] = E::pack2(dsv[8 * t + 2 * w2], dsv[8 * t + 2 * w2 + 1]);
+            }
         // ---- dV^T += dO^T P,  dK^T += Q^T dS ----
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
