@@ -947,6 +947,18 @@ __global__ void __launch_bounds__(BWD_THREADS, 2) fa_bwd_dkdv2_kernel(const KArg
                 pf[t][w2] = E::pack2(pv[8 * t + 2 * w2], pv[8 * t + 2 * w2 + 1]);
                 dsf[t][w2] = E::pack2(dsv[8 * t + 2 * w2], dsv[8 * t + 2 * w2 + 1]);
             }
+        if (a.ds_ws) {
+            // dS hand-off to the one-GEMM dQ kernel (see fa_bwd_dkdv_kernel): two coalesced 1-KiB stores
+            char* tile = reinterpret_cast<char*>(a.ds_ws) +
+                         ((((int64_t)b * p.nheads_q + h) * a.ds_nqb + (q0 >> 5)) * a.ds_nkb + (kw0 >> 5)) * 2048 + l31 * 32 + g * 16;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                uint32_t x0 = dsf[t][0], x1 = dsf[t][1], y0 = dsf[t][2], y1 = dsf[t][3];
+                permlane32_swap(x0, y0);
+                permlane32_swap(x1, y1);
+                *reinterpret_cast<u32x4*>(tile + t * 1024) = u32x4{x0, x1, y0, y1};
+            }
+        }
         // ---- dV^T += dO^T P,  dK^T += Q^T dS ----
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -1484,7 +1496,7 @@ static int launch_bwd_td(const KArgs& a, hipStream_t stream) {
         static const bool dkv2_env = getenv("FA_DKDV1") == nullptr;
         bool done = false;
         if constexpr (D <= 128) {
-            if (dkv2_env && !drop && !a.ds_ws && (!a.has_bias || lin_alibi) && grid > 0) {
+            if (dkv2_env && !drop && (!a.has_bias || lin_alibi) && grid > 0) {
                 const size_t smem2 = Dkv2Smem<D>::TOTAL;
                 if (a.has_bias) {
                     auto kern = fa_bwd_dkdv2_kernel<T, D, 2>;
