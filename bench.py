@@ -223,7 +223,7 @@ def main():
         kernels["bwd_all"] = {"ms": round(kern["bwd_all"], 4),
                               "achieved": round(2.5 * ff / (kern["bwd_all"] * 1e-3) / 1e12, 1)}
         dom = max(("fwd", "bwd_dkdv", "bwd_dq"), key=lambda n: dur[n])
-        roofline = {"bound": "mfma", "kernel": {"fwd": "fa_fwd_kernel", "bwd_dkdv": "fa_bwd_dkdv_kernel",
+        roofline = {"bound": "mfma", "kernel": {"fwd": "fa_fwd_kernel", "bwd_dkdv": "fa_bwd_dkdv2_kernel",
                                                   "bwd_dq": "fa_bwd_dq_kernel"}[dom],
                     "achieved": kernels[dom]["achieved"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                     "frac": kernels[dom]["frac"], "traffic": None}
