@@ -666,6 +666,9 @@ __global__ void __launch_bounds__(BWD_THREADS, 1) fa_bwd_dkdv_kernel(const KArgs
 //   * the 32 row statistics of a stage sit in one register per lane (lanes 0..31 lse2, 32..63 D) and are
 //     gathered per accumulator register with ds_bpermute_b32 (crossbar only, no LDS space: there is
 //     none left - 2 x 81920 B is exactly the CU's 160 KiB).
+#ifndef FA_DKV2_OCC64
+#define FA_DKV2_OCC64 3
+#endif
 constexpr int DKV2_BQ = 32;
 template <int D> struct Dkv2Smem {
     static constexpr int KT = DKV_BN * D * 2;            // K (or V) tile
@@ -682,7 +685,7 @@ template <int D> struct Dkv2Smem {
 };
 
 template <typename T, int D, int BIAS>
-__global__ void __launch_bounds__(BWD_THREADS, 2) fa_bwd_dkdv2_kernel(const KArgs a) {
+__global__ void __launch_bounds__(BWD_THREADS, D <= 64 ? FA_DKV2_OCC64 : 2) fa_bwd_dkdv2_kernel(const KArgs a) {
     using E = Elem<T>;
     constexpr int KSTEPS = D / 16;
     constexpr int DBLKS = D / 32;
