@@ -354,6 +354,33 @@ __global__ void __launch_bounds__(BWD_THREADS, 1) fa_bwd_dkdv_kernel(const KArgs
         }
         }
     };
+    // Dropout keep bits of this lane's 16 accumulator registers.  The four lanes of a quad hold four
+    // consecutive keys = ONE Philox counter per query row (include/softmax.h:97-104), so each lane draws the
+    // rows r = 4 i + (lane & 3) only (keep bits of all four keys) and the quad exchanges them with DPP:
+    // 4 Philox calls per lane and sub-tile instead of 16.  Returns bit r = keep(register r).
+    auto drop_bits = [&](int q0) -> uint32_t {
+        uint32_t mine = 0;
+        const int lq = lane & 3;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int qi = q0 + lq + 8 * i + 4 * g;          // register r = 4 i + lq
+            mine |= dropout_keep4(dc, (uint64_t)(sg.q_row0 + qi) * drop_n_glob + (uint64_t)(my_key & ~3)) << (4 * i);
+        }
+        const int kq = my_key & 3;
+        uint32_t bits = 0;
+        const uint32_t a0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine, 0x00, 0xf, 0xf, false);   // quad_perm [0,0,0,0]
+        const uint32_t a1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine, 0x55, 0xf, 0xf, false);   // [1,1,1,1]
+        const uint32_t a2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine, 0xaa, 0xf, 0xf, false);   // [2,2,2,2]
+        const uint32_t a3 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine, 0xff, 0xf, 0xf, false);   // [3,3,3,3]
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            bits |= ((a0 >> (4 * i + kq)) & 1u) << (4 * i + 0);
+            bits |= ((a1 >> (4 * i + kq)) & 1u) << (4 * i + 1);
+            bits |= ((a2 >> (4 * i + kq)) & 1u) << (4 * i + 2);
+            bits |= ((a3 >> (4 * i + kq)) & 1u) << (4 * i + 3);
+        }
+        return bits;
+    };
     // row statistics for q = q0 + 8 i + 4 g + (0..3)
     auto sm_stats = [&](const float* st, int sub, f32x4 (&lse2)[4], f32x4 (&dsum)[4]) {
 #pragma unroll
@@ -366,6 +393,7 @@ __global__ void __launch_bounds__(BWD_THREADS, 1) fa_bwd_dkdv_kernel(const KArgs
     auto sm = [&](int q0, bool need_mask, const f32x4 (&lse2)[4], const f32x4 (&dsum)[4],
                   const f32x16& s_acc, const f32x16& dp_acc, u32x4 (&pf)[2], u32x4 (&dsf)[2]) {
         float pv[16], dsv[16];
+        const uint32_t kbits = DROPOUT ? drop_bits(q0) : 0xffffu;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const float l2 = lse2[r >> 2][r & 3];
@@ -374,7 +402,7 @@ __global__ void __launch_bounds__(BWD_THREADS, 1) fa_bwd_dkdv_kernel(const KArgs
             bool keep = true;
             if (DROPOUT) {
                 // dS = P (keep rp dP - D); dV accumulates keep P (rp applied in the epilogue)
-                keep = dropout_keep1(dc, (uint64_t)(sg.q_row0 + qi) * drop_n_glob + (uint64_t)my_key);
+                keep = (kbits >> r) & 1u;
                 dpe = keep ? dpe * a.rp_dropout : 0.f;
             }
             float pr, dsr;
@@ -416,6 +444,7 @@ __global__ void __launch_bounds__(BWD_THREADS, 1) fa_bwd_dkdv_kernel(const KArgs
             }
     };
     // sm for ONE group of four accumulator registers (rows 8 i + 4 g + 0..3): the register-lean form
+    uint32_t kbits_rows = 0xffffu;                         // set per sub-tile by the caller when DROPOUT
     auto sm_rows = [&](int i, int q0, bool need_mask, const f32x4& l2v, const f32x4& dsm, const f32x16& s_acc,
                        const f32x16& dp_acc, u32x4 (&pf)[2], u32x4 (&dsf)[2]) {
         float pv[4], dsv[4];
@@ -426,7 +455,7 @@ __global__ void __launch_bounds__(BWD_THREADS, 1) fa_bwd_dkdv_kernel(const KArgs
             float dpe = dp_acc[r];
             bool keep = true;
             if (DROPOUT) {
-                keep = dropout_keep1(dc, (uint64_t)(sg.q_row0 + qi) * drop_n_glob + (uint64_t)my_key);
+                keep = (kbits_rows >> r) & 1u;
                 dpe = keep ? dpe * a.rp_dropout : 0.f;
             }
             float pr, dsr;
@@ -550,6 +579,7 @@ __global__ void __launch_bounds__(BWD_THREADS, 1) fa_bwd_dkdv_kernel(const KArgs
             } else {
                 // D = 256 is register-starved: one row group's statistics at a time
                 const bool nm = needs_mask(q0);
+                if (DROPOUT) kbits_rows = drop_bits(q0);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     f32x4 l4[4], d4[4];
@@ -1536,7 +1566,8 @@ static int launch_bwd_td(const KArgs& a, hipStream_t stream) {
         constexpr int OCC = (D > 128) ? 1 : 2;
 #define FA_LAUNCH_DQ(BIAS, DROP)                                                                                  \
         do {                                                                                                      \
-            auto kern = fa_bwd_dq_kernel<T, D, BIAS, OCC, DROP>;                                                  \
+            /* dropout needs the Philox registers: two waves per SIMD spill 84 of them (4.0 ms), one wave none */ \
+            auto kern = fa_bwd_dq_kernel<T, D, BIAS, (DROP) ? 1 : OCC, DROP>;                                     \
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
             hipLaunchKernelGGL(kern, dim3(grid), dim3(BWD_THREADS), smem, stream, a);                             \
         } while (0)
