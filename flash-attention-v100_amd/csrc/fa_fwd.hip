@@ -24,7 +24,14 @@
 namespace fa {
 
 constexpr int FWD_BM = 128;
-constexpr int FWD_BN = 64;
+#ifndef FA_FWD_BN
+#define FA_FWD_BN 64
+#endif
+#ifndef FA_FWD_OCC
+#define FA_FWD_OCC 2
+#endif
+constexpr int FWD_BN = FA_FWD_BN;
+constexpr int FWD_NKB = FWD_BN / 32;               // 32-key blocks per tile
 constexpr int FWD_THREADS = 256;
 constexpr float FWD_RESCALE_THR = 8.0f;                // log2 units
 
@@ -36,7 +43,7 @@ template <int D> struct FwdSmem {
 
 // BIAS: 0 none, 1 general (ALiBi and/or softcap per element), 2 causal ALiBi through the matrix pipe
 template <typename T, int D, int BIAS, bool PAGED, bool DROPOUT>
-__global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : 2)) fa_fwd_kernel(const KArgs a) {
+__global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : FA_FWD_OCC)) fa_fwd_kernel(const KArgs a) {
     using E = Elem<T>;
     constexpr int KSTEPS = D / 16;
     constexpr int DBLKS = D / 32;
@@ -273,18 +280,21 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : 2)) fa_fwd_kernel(
         const int n0 = nb * FWD_BN;
         const char* sbase = smem + stage * STAGE;
         // ---- S^T = K Q^T : sacc[kb][r] = S[my_row][n0 + 32 kb + row(r, g)] ----
-        f32x16 sacc[2];
+        f32x16 sacc[FWD_NKB];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { sacc[0][r] = 0.f; sacc[1][r] = 0.f; }
+        for (int kb = 0; kb < FWD_NKB; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
 #ifndef FA_NO_SETPRIO
         __builtin_amdgcn_s_setprio(1);
 #endif
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks) {
-            const u32x4 k0 = lds_read_b128(sbase + k_rd[ks]);
-            const u32x4 k1 = lds_read_b128(sbase + k_rd[ks] + 32 * D * 2);
-            sacc[0] = E::mfma(k0, qf[ks], sacc[0]);
-            sacc[1] = E::mfma(k1, qf[ks], sacc[1]);
+            u32x4 kk[FWD_NKB];
+#pragma unroll
+            for (int kb = 0; kb < FWD_NKB; ++kb) kk[kb] = lds_read_b128(sbase + k_rd[ks] + kb * 32 * D * 2);
+#pragma unroll
+            for (int kb = 0; kb < FWD_NKB; ++kb) sacc[kb] = E::mfma(kk[kb], qf[ks], sacc[kb]);
         }
 #ifndef FA_NO_SETPRIO
         __builtin_amdgcn_s_setprio(0);
@@ -292,15 +302,15 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : 2)) fa_fwd_kernel(
         // ---- bias / softcap (rare variants), then masking on edge tiles ----
         float shift = 0.f;
         if (BIAS && lin) {
-            sacc[0] = E::mfma(pos_a[0], slope_b, sacc[0]);
-            sacc[1] = E::mfma(pos_a[1], slope_b, sacc[1]);
+#pragma unroll
+            for (int kb = 0; kb < FWD_NKB; ++kb) sacc[kb] = E::mfma(pos_a[kb], slope_b, sacc[kb]);
             shift = slope2 * (float)(n0 - my_row - off);
         }
         if (BIAS && !lin) {
             const float cap = p.softcap;
             const float rcap = cap > 0.f ? 1.0f / cap : 0.f;
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
+            for (int kb = 0; kb < FWD_NKB; ++kb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int j = n0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
@@ -319,7 +329,7 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : 2)) fa_fwd_kernel(
             const uint32_t width = (uint32_t)(hi - lo);                    // hi < lo (empty row) -> huge: see below
             const bool empty = hi < lo;
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
+            for (int kb = 0; kb < FWD_NKB; ++kb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int cpos = kb * 32 + (r & 3) + 8 * (r >> 2);
@@ -331,7 +341,9 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : 2)) fa_fwd_kernel(
 #pragma unroll
         for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sacc[0][r]);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[1][r]);
+        for (int kb = 1; kb < FWD_NKB; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[kb][r]);
         mx = xhalf_max(mx) * c;
         if (BIAS) mx += shift;
         // keep the old max unless some row of the wave would exceed it by > 2^THR
@@ -351,7 +363,7 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : 2)) fa_fwd_kernel(
         const float ms = BIAS ? m_use - shift : m_use;
         float psum = 0.f;
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+        for (int kb = 0; kb < FWD_NKB; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float e = fast_exp2(fmaf(sacc[kb][r], c, -ms));
@@ -369,7 +381,7 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : 2)) fa_fwd_kernel(
             }
             const uint16_t one = std::is_same<T, bf16_tag>::value ? 0x3F80 : 0x3C00;
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
+            for (int kb = 0; kb < FWD_NKB; ++kb)
 #pragma unroll
                 for (int rg = 0; rg < 4; ++rg) {
                     const int j4 = n0 + kb * 32 + 8 * rg + 4 * g;
@@ -385,7 +397,7 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : 2)) fa_fwd_kernel(
 
         // ---- O^T += V^T P^T : k-step t covers C-layout regs 8 (t&1) .. +7 of sacc[t>>1] ----
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
+        for (int t = 0; t < 2 * FWD_NKB; ++t) {
             const int kb = t >> 1, ks2 = t & 1;
             u32x4 pf;
             pf[0] = E::pack2(sacc[kb][8 * ks2 + 0], sacc[kb][8 * ks2 + 1]);
