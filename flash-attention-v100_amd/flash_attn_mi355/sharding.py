@@ -33,3 +33,27 @@ def shard_alibi(alibi_slopes, q_heads: slice, batch: slice):
     if alibi_slopes.dim() == 1:
         return alibi_slopes[q_heads].contiguous()
     return alibi_slopes[batch, q_heads].contiguous()
+
+
+def merge_attention_shards(outs, lses):
+    """Combine attention computed over DISJOINT key shards into attention over their union.
+
+    outs[s]: (B, Sq, H, D) output of flash_attn_func(q, k_s, v_s, ..., return_attn_probs=True)
+    lses[s]: (B, H, Sq) fp32 log-sum-exp of the same call (natural log; -inf for rows that saw no key).
+    Returns (out, lse):  LSE = logsumexp_s(lse_s),  out = sum_s exp(lse_s - LSE) out_s  (fp32 math, out in
+    outs[0].dtype).  This is the per-step reduction of context / ring parallelism (SURVEY.md section 8(f)
+    row 4): every rank attends its local K/V shard and the partial results are merged with the returned LSE;
+    the exchange itself (all-gather or ring send/recv of K/V or of (out, lse)) belongs to the caller - the
+    attention path of this package has no collective.
+    """
+    import torch
+    lse = torch.stack([l.float() for l in lses], 0)                       # [n, B, H, Sq]
+    m = lse.max(0).values
+    m_safe = torch.where(torch.isfinite(m), m, torch.zeros_like(m))
+    w = torch.exp(lse - m_safe)                                           # -inf -> 0
+    den = w.sum(0)
+    tot = torch.where(den > 0, m_safe + torch.log(torch.where(den > 0, den, torch.ones_like(den))),
+                      torch.full_like(den, float("-inf")))
+    w = w / torch.where(den > 0, den, torch.ones_like(den))
+    out = sum(o.float() * w[i].transpose(1, 2).unsqueeze(-1) for i, o in enumerate(outs))
+    return out.to(outs[0].dtype), tot

@@ -125,3 +125,28 @@ def test_torch_ops_kvcache_mutates_cache():
                                                return_softmax_lse=True)
     assert torch.equal(out, out2) and torch.equal(lse, lse2)
     assert torch.equal(kc, kc2) and torch.equal(kc[0, 100], kn[0, 0]) and torch.equal(vc[1, 333], vn[1, 0])
+
+
+def test_context_parallel_merge_with_kernel_lse():
+    """Keys split in two shards (what two context-parallel ranks would hold): merging the kernels' (out, lse)
+    pairs reproduces attention over all keys - causal included (shard 2 is a bottom-right aligned causal
+    problem; shard 1 is square-causal for the first half of the rows and unmasked for the second)."""
+    from flash_attn_mi355.sharding import merge_attention_shards
+    torch.manual_seed(421)
+    B, S, H, D = 2, 384, 4, 128
+    q, k, v = (torch.randn(B, S, H, D, device="cuda", dtype=torch.bfloat16) for _ in range(3))
+    fa = _fa()
+    h = S // 2
+    for causal in (False, True):
+        full, lse_full, _ = fa.flash_attn_func(q, k, v, causal=causal, return_attn_probs=True)
+        if causal:
+            o1a, l1a, _ = fa.flash_attn_func(q[:, :h], k[:, :h], v[:, :h], causal=True, return_attn_probs=True)
+            o1b, l1b, _ = fa.flash_attn_func(q[:, h:], k[:, :h], v[:, :h], return_attn_probs=True)
+            o1, l1 = torch.cat([o1a, o1b], 1), torch.cat([l1a, l1b], 2)
+            o2, l2, _ = fa.flash_attn_func(q, k[:, h:], v[:, h:], causal=True, return_attn_probs=True)
+        else:
+            o1, l1, _ = fa.flash_attn_func(q, k[:, :h], v[:, :h], return_attn_probs=True)
+            o2, l2, _ = fa.flash_attn_func(q, k[:, h:], v[:, h:], return_attn_probs=True)
+        out, lse = merge_attention_shards([o1, o2], [l1, l2])
+        assert torch.allclose(out.float(), full.float(), atol=2e-2, rtol=2e-2), causal
+        assert torch.allclose(lse, lse_full, atol=2e-3), causal

@@ -70,3 +70,24 @@ def test_two_rank_sharded_attention_matches_unsharded(tmp_path):
     o_ref, _, _ = oracle.attn_fwd(t(q), t(k), t(v), D ** -0.5, causal=True, alibi_slopes=slopes.numpy())
     assert np.allclose(res["out"].numpy().transpose(0, 2, 1, 3), o_ref, atol=1e-12)
     assert float(res["tmax"]) == float(world)
+
+
+def test_merge_attention_shards_matches_full_attention():
+    """LSE merge of attention over disjoint key shards == attention over all keys (oracle on CPU)."""
+    import numpy as np
+    import torch
+    import oracle
+    from flash_attn_mi355.sharding import merge_attention_shards
+    rng = np.random.default_rng(421)
+    B, H, Sq, Sk, D = 2, 3, 17, 40, 16
+    q = rng.standard_normal((B, H, Sq, D)); k = rng.standard_normal((B, H, Sk, D)); v = rng.standard_normal((B, H, Sk, D))
+    o_ref, lse_ref, _ = oracle.attn_fwd(q, k, v, D ** -0.5)
+    cuts = [0, 13, 13, 29, 40]                                     # includes an EMPTY shard
+    outs, lses = [], []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        o, l, _ = oracle.attn_fwd(q, k[:, :, a:b], v[:, :, a:b], D ** -0.5)
+        outs.append(torch.from_numpy(o).permute(0, 2, 1, 3))           # (B, Sq, H, D)
+        lses.append(torch.from_numpy(l))
+    out, lse = merge_attention_shards(outs, lses)
+    assert np.allclose(out.permute(0, 2, 1, 3).numpy(), o_ref, atol=1e-5)
+    assert np.allclose(lse.numpy(), lse_ref, atol=1e-5)

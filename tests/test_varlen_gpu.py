@@ -110,3 +110,35 @@ def test_config3_shape_properties():
                                       f64(k[s0:s1, hs]).transpose(1, 0, 2)[None],
                                       f64(v[s0:s1, hs]).transpose(1, 0, 2)[None], D ** -0.5, window=(512, 0))
         assert_close(f64(o1[s0:s1, hs]).transpose(1, 0, 2)[None], o_ref, "fp16", f"seq {b}")
+
+
+def test_varlen_with_empty_sequences():
+    """cu_seqlens with zero-length entries (query-side, key-side and both): no crash, rows of the other
+    sequences unaffected, empty-key rows give O = 0 / LSE = -inf, gradients finite."""
+    import flash_attn
+    torch.manual_seed(421)
+    H, D = 4, 64
+    lens_q = [50, 0, 33, 7]
+    lens_k = [50, 20, 0, 130]
+    cu_q = torch.tensor([0] + list(np.cumsum(lens_q)), dtype=torch.int32, device="cuda")
+    cu_k = torch.tensor([0] + list(np.cumsum(lens_k)), dtype=torch.int32, device="cuda")
+    q = torch.randn(sum(lens_q), H, D, device="cuda", dtype=torch.float16, requires_grad=True)
+    k = torch.randn(sum(lens_k), H, D, device="cuda", dtype=torch.float16, requires_grad=True)
+    v = torch.randn(sum(lens_k), H, D, device="cuda", dtype=torch.float16, requires_grad=True)
+    out, lse, _ = flash_attn.flash_attn_varlen_func(q, k, v, cu_q, cu_k, max(lens_q), max(lens_k), causal=False,
+                                                    return_attn_probs=True)
+    dq, dk, dv = torch.autograd.grad(out, (q, k, v), torch.randn_like(out))
+    for t in (out, dq, dk, dv):
+        assert torch.isfinite(t.float()).all()
+    # sequence 2 has no keys: its 33 query rows
+    r0 = lens_q[0] + lens_q[1]
+    assert (out[r0:r0 + 33] == 0).all() and torch.isneginf(lse[:, r0:r0 + 33]).all()
+    assert (dq[r0:r0 + 33] == 0).all()
+    # sequence 1 has keys but no queries: zero dk/dv there
+    k0 = lens_k[0]
+    assert (dk[k0:k0 + 20] == 0).all() and (dv[k0:k0 + 20] == 0).all()
+    # the ordinary sequences match a per-sequence dense call
+    for b in (0, 3):
+        qs, qe = int(cu_q[b]), int(cu_q[b + 1]); ks, ke = int(cu_k[b]), int(cu_k[b + 1])
+        ref = flash_attn.flash_attn_func(q[qs:qe][None], k[ks:ke][None], v[ks:ke][None])
+        assert torch.allclose(out[qs:qe].float(), ref[0].float(), atol=2e-3, rtol=2e-3)
