@@ -714,7 +714,7 @@ template <int D> struct Dkv2Smem {
 #endif
 };
 
-template <typename T, int D, int BIAS>
+template <typename T, int D, int BIAS, bool DROPOUT>
 __global__ void __launch_bounds__(BWD_THREADS, D <= 64 ? FA_DKV2_OCC64 : 2) fa_bwd_dkdv2_kernel(const KArgs a) {
     using E = Elem<T>;
     constexpr int KSTEPS = D / 16;
@@ -764,6 +764,12 @@ __global__ void __launch_bounds__(BWD_THREADS, D <= 64 ? FA_DKV2_OCC64 : 2) fa_b
     const int wr = p.is_causal ? 0 : p.window_right;
     const float c = a.scale_log2e;
     const int dv = valid_cols(p);
+    DropCtx dc = {0, 0, 0, 0};
+    if (DROPOUT) {
+        dc.k0 = (uint32_t)p.philox_seed; dc.k1 = (uint32_t)(p.philox_seed >> 32);
+        dc.thr = a.drop_thr; dc.offset = p.philox_offset;
+    }
+    const uint64_t drop_n_glob = (uint64_t)p.seqlen_k;
 
     // DMA geometry: instruction `inst` covers ROWS_PI rows; lane -> (row, physical 16-byte slot); the source
     // offset carries the swizzle (and the out-of-range trick for columns past head_dim_v)
@@ -943,6 +949,29 @@ __global__ void __launch_bounds__(BWD_THREADS, D <= 64 ? FA_DKV2_OCC64 : 2) fa_b
         const int sidx = 16 * g;                             // byte index of lane 4 g for ds_bpermute
         (void)sidx;
         float pv[16], dsv[16];
+        uint32_t kbits = 0xffffu;
+        if (DROPOUT) {
+            // the quad (4 consecutive keys = one Philox counter per row) draws each row once: see drop_bits
+            // in fa_bwd_dkdv_kernel
+            uint32_t mine = 0;
+            const int lq = lane & 3;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                mine |= dropout_keep4(dc, (uint64_t)(sg.q_row0 + q0 + lq + 8 * i + 4 * g) * drop_n_glob + (uint64_t)(my_key & ~3)) << (4 * i);
+            const int kq = my_key & 3;
+            const uint32_t a0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine, 0x00, 0xf, 0xf, false);
+            const uint32_t a1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine, 0x55, 0xf, 0xf, false);
+            const uint32_t a2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine, 0xaa, 0xf, 0xf, false);
+            const uint32_t a3 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine, 0xff, 0xf, 0xf, false);
+            kbits = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                kbits |= ((a0 >> (4 * i + kq)) & 1u) << (4 * i + 0);
+                kbits |= ((a1 >> (4 * i + kq)) & 1u) << (4 * i + 1);
+                kbits |= ((a2 >> (4 * i + kq)) & 1u) << (4 * i + 2);
+                kbits |= ((a3 >> (4 * i + kq)) & 1u) << (4 * i + 3);
+            }
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             f32x4 l4 = {0, 0, 0, 0}, d4 = {0, 0, 0, 0};
@@ -962,8 +991,14 @@ __global__ void __launch_bounds__(BWD_THREADS, D <= 64 ? FA_DKV2_OCC64 : 2) fa_b
                     dsm = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(sidx + 4 * (32 + cpos), __builtin_bit_cast(int, statv)));
                 }
                 const float pr = fast_exp2(fmaf(s_acc[r], c, -l2));
-                pv[r] = pr;
-                dsv[r] = pr * (dp_acc[r] - dsm);
+                if (DROPOUT) {       // dS = P (keep rp dP - D); dV accumulates keep P (rp applied in the epilogue)
+                    const bool keep = (kbits >> r) & 1u;
+                    pv[r] = keep ? pr : 0.f;
+                    dsv[r] = pr * ((keep ? dp_acc[r] * a.rp_dropout : 0.f) - dsm);
+                } else {
+                    pv[r] = pr;
+                    dsv[r] = pr * (dp_acc[r] - dsm);
+                }
             }
         }
         if (need_mask) {                                     // wave-uniform branch: interior tiles skip all of it
@@ -1024,8 +1059,9 @@ __global__ void __launch_bounds__(BWD_THREADS, D <= 64 ? FA_DKV2_OCC64 : 2) fa_b
                 u32x2 k2, v2;
                 k2[0] = E::pack2(dk_acc[d][4 * rq + 0] * sc, dk_acc[d][4 * rq + 1] * sc);
                 k2[1] = E::pack2(dk_acc[d][4 * rq + 2] * sc, dk_acc[d][4 * rq + 3] * sc);
-                v2[0] = E::pack2(dv_acc[d][4 * rq + 0], dv_acc[d][4 * rq + 1]);
-                v2[1] = E::pack2(dv_acc[d][4 * rq + 2], dv_acc[d][4 * rq + 3]);
+                const float rp = DROPOUT ? a.rp_dropout : 1.0f;
+                v2[0] = E::pack2(dv_acc[d][4 * rq + 0] * rp, dv_acc[d][4 * rq + 1] * rp);
+                v2[1] = E::pack2(dv_acc[d][4 * rq + 2] * rp, dv_acc[d][4 * rq + 3] * rp);
                 if (d * 32 + 8 * rq + 4 * g < dv) {
                     *reinterpret_cast<u32x2*>(dkp + d * 32 + 8 * rq + 4 * g) = k2;
                     *reinterpret_cast<u32x2*>(dvp + d * 32 + 8 * rq + 4 * g) = v2;
@@ -1529,17 +1565,18 @@ static int launch_bwd_td(const KArgs& a, hipStream_t stream) {
         static const bool dkv2_env = getenv("FA_DKDV1") == nullptr;
         bool done = false;
         if constexpr (D <= 128) {
-            if (dkv2_env && !drop && (!a.has_bias || lin_alibi) && grid > 0) {
+            if (dkv2_env && (!a.has_bias || (lin_alibi && !drop)) && grid > 0) {
                 const size_t smem2 = Dkv2Smem<D>::TOTAL;
-                if (a.has_bias) {
-                    auto kern = fa_bwd_dkdv2_kernel<T, D, 2>;
-                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2);
-                    hipLaunchKernelGGL(kern, dim3(grid), dim3(BWD_THREADS), smem2, stream, a);
-                } else {
-                    auto kern = fa_bwd_dkdv2_kernel<T, D, 0>;
-                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2);
-                    hipLaunchKernelGGL(kern, dim3(grid), dim3(BWD_THREADS), smem2, stream, a);
-                }
+#define FA_LAUNCH_DKV2(BIAS, DROP)                                                                                \
+                do {                                                                                              \
+                    auto kern = fa_bwd_dkdv2_kernel<T, D, BIAS, DROP>;                                            \
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2); \
+                    hipLaunchKernelGGL(kern, dim3(grid), dim3(BWD_THREADS), smem2, stream, a);                    \
+                } while (0)
+                if (a.has_bias) FA_LAUNCH_DKV2(2, false);
+                else if (drop) FA_LAUNCH_DKV2(0, true);
+                else FA_LAUNCH_DKV2(0, false);
+#undef FA_LAUNCH_DKV2
                 done = true;
             }
         }
