@@ -190,6 +190,23 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : FA_FWD_OCC)) fa_fw
             v_lds[i] = TILE + inst * 1024;
         }
     }
+    // Paged K/V, aligned case (a 64-key tile never straddles a page: page % 64 == 0 by contract and the left
+    // pad is a multiple of 64): the same LDS-DMA as the contiguous path through a per-tile descriptor built
+    // from ONE block-table lookup; otherwise the per-row register path.
+    const bool paged_dma = PAGED && (k_row0 % FWD_BN == 0) && (p.page_block_size % FWD_BN == 0);
+    uint32_t pk_voff[PAGED ? CHUNKS : 1], pv_voff[PAGED ? CHUNKS : 1];
+    if (PAGED) {
+#pragma unroll
+        for (int i = 0; i < CHUNKS; ++i) {
+            const int inst = wave * CHUNKS + i;
+            const int row = inst * ROWS_PI + lane / CPR;
+            const int slot = lane % CPR;
+            const int k_cb = swz_row_off<D>(row, slot * 16) - row * D * 2;
+            const int v_cb = swzt_row_off<D>(row, slot * 16) - row * D * 2;
+            pk_voff[i] = k_cb < dv * 2 ? (uint32_t)(row * p.k_row_stride * 2 + k_cb) : kOobVoff;
+            pv_voff[i] = v_cb < dv * 2 ? (uint32_t)(row * p.v_row_stride * 2 + v_cb) : kOobVoff;
+        }
+    }
     const __amdgpu_buffer_rsrc_t k_rsrc = make_rsrc(kp, p.k_row_stride, PAGED ? 0 : seqlen_k, dv);
     const __amdgpu_buffer_rsrc_t v_rsrc = make_rsrc(vp, p.v_row_stride, PAGED ? 0 : seqlen_k, dv);
     const uint32_t k_tile_bytes = (uint32_t)(FWD_BN * p.k_row_stride * 2);
@@ -198,7 +215,22 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : FA_FWD_OCC)) fa_fw
     // issue the loads of tile nb; for the DMA path they land directly in LDS stage `stage`
     auto load_tile = [&](int nb, auto stage_c) {
         constexpr int stage = decltype(stage_c)::value;
-        if (PAGED) {
+        if (PAGED && paged_dma) {
+            const int n0 = nb * FWD_BN;
+            const int pos0 = n0 + (int)k_row0;
+            const int pg = pos0 / p.page_block_size;
+            const int pr = pos0 - pg * p.page_block_size;
+            const int64_t phys = btab[pg];
+            int rows = seqlen_k - n0;
+            rows = rows < 0 ? 0 : (rows > FWD_BN ? FWD_BN : rows);
+            const __amdgpu_buffer_rsrc_t kr = make_rsrc(kp + phys * p.k_batch_stride + (int64_t)pr * p.k_row_stride, p.k_row_stride, rows, dv);
+            const __amdgpu_buffer_rsrc_t vr = make_rsrc(vp + phys * p.v_batch_stride + (int64_t)pr * p.v_row_stride, p.v_row_stride, rows, dv);
+            char* base = smem + stage * STAGE;
+#pragma unroll
+            for (int i = 0; i < CHUNKS; ++i) buf_load_lds_b128(kr, base + (wave * CHUNKS + i) * 1024, pk_voff[i], 0);
+#pragma unroll
+            for (int i = 0; i < CHUNKS; ++i) buf_load_lds_b128(vr, base + TILE + (wave * CHUNKS + i) * 1024, pv_voff[i], 0);
+        } else if (PAGED) {
             const int n0 = nb * FWD_BN;
 #pragma unroll
             for (int i = 0; i < CHUNKS; ++i) {
@@ -228,7 +260,7 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : FA_FWD_OCC)) fa_fw
     };
     auto store_tile = [&](auto stage_c) {
         constexpr int stage = decltype(stage_c)::value;
-        if (PAGED) {
+        if (PAGED && !paged_dma) {
             char* base = smem + stage * STAGE;
 #pragma unroll
             for (int i = 0; i < CHUNKS; ++i) {

@@ -215,3 +215,32 @@ def test_full_size_config4_decode_paged_rotary_fp8():
         got_k = kc[phys, L % page].float().double().cpu().numpy()
         assert (np.abs(got_k - kref[L // page, L % page]) <= 0.13 * np.maximum(np.abs(kref[L // page, L % page]), 2.0 ** -6)).all()
         assert np.array_equal(vc[phys, L % page].float().double().cpu().numpy(), vref[L // page, L % page])
+
+
+@pytest.mark.parametrize("lp_kind", ["unaligned", "aligned", "none"])
+def test_kvcache_paged_chunk_prefill_general_path(lp_kind):
+    """A 40-token chunk against a paged cache runs the general forward kernel (T_q * G > 32): aligned left pads
+    (multiples of 64) and no pad take the LDS-DMA paged path (one block-table lookup per tile), an unaligned
+    pad the per-row path."""
+    B, Tq, Hq, Hk, D, page, dt = 3, 40, 4, 2, 128, 128, "bf16"
+    pages_per_seq = 8
+    nblk = B * pages_per_seq + 3
+    kc = rand16((nblk, page, Hk, D), dt, 2)
+    vc = rand16((nblk, page, Hk, D), dt, 3)
+    perm = torch.randperm(nblk, generator=torch.Generator().manual_seed(5))[: B * pages_per_seq]
+    bt = perm.reshape(B, pages_per_seq).to(torch.int32)
+    q = rand16((B, Tq, Hq, D), dt, 1)
+    knew = rand16((B, Tq, Hk, D), dt, 4); vnew = rand16((B, Tq, Hk, D), dt, 5)
+    seqlens = torch.tensor([700, 64, 333], dtype=torch.int32)
+    lp = {"unaligned": torch.tensor([5, 17, 70], dtype=torch.int32),
+          "aligned": torch.tensor([64, 0, 128], dtype=torch.int32), "none": None}[lp_kind]
+    kc_ref, vc_ref = f64(kc).copy(), f64(vc).copy()
+    out, lse = _fa().flash_attn_with_kvcache(q, kc, vc, k=knew, v=vnew, cache_seqlens=seqlens.cuda(),
+                                             cache_leftpad=None if lp is None else lp.cuda(),
+                                             block_table=bt.cuda(), causal=True, return_softmax_lse=True)
+    o_ref, lse_ref = oracle.kvcache_fwd(f64(q), kc_ref, vc_ref, k=f64(knew), v=f64(vnew), cache_seqlens=seqlens.numpy(),
+                                        cache_leftpad=None if lp is None else lp.numpy(), block_table=bt.numpy(),
+                                        causal=True, io_dtype=dt)
+    assert np.array_equal(f64(kc), kc_ref) and np.array_equal(f64(vc), vc_ref)
+    assert_close(f64(out), o_ref, dt, "out", mult=1.5)
+    assert_lse_close(f64(lse), lse_ref, "lse", atol=2e-2)
