@@ -1,0 +1,20 @@
+"""softcap (Gemma-2 style) vs plain causal: forward and backward kernels (bf16 B8 H16 S4096 D128)."""
+import os, sys
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, os.path.join(ROOT, "flash-attention-v100_amd")); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import torch, flash_attn
+from flash_attn_mi355 import _lib
+from bench_configs import timeit
+B, S, H, D = 8, 4096, 16, 128
+q, k, v = (torch.randn(B, S, H, D, device="cuda", dtype=torch.bfloat16, requires_grad=True) for _ in range(3))
+do = torch.randn(B, S, H, D, device="cuda", dtype=torch.bfloat16)
+for cap in (0.0, 0.0, 50.0):
+    with torch.no_grad():
+        tf = timeit(lambda: flash_attn.flash_attn_func(q, k, v, causal=True, softcap=cap))
+    o = flash_attn.flash_attn_func(q, k, v, causal=True, softcap=cap)
+    res = {}
+    for nm, mask in (("dkdv", 2), ("dq", 4), ("all", 7)):
+        _lib.lib.fa_debug_set_bwd_phases(mask)
+        res[nm] = timeit(lambda: torch.autograd.grad(o, (q, k, v), do, retain_graph=True), iters=5)
+    _lib.lib.fa_debug_set_bwd_phases(7)
+    print(f"softcap={cap}: fwd {tf:.3f} | dkdv {res['dkdv']:.3f} dq {res['dq']:.3f} bwd {res['all']:.3f} ms", flush=True)
