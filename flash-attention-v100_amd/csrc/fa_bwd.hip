@@ -140,6 +140,9 @@ __global__ void __launch_bounds__(BWD_THREADS, 1) fa_bwd_dkdv_kernel(const KArgs
     const int wl = p.window_left;
     const int wr = p.is_causal ? 0 : p.window_right;
     const float c = a.scale_log2e;
+    // softcap-only variant (BIAS == 3): cap tanh(s scale / cap) = cap (1 - 2 / (1 + exp2(s k1))), log2 units
+    const float cap_k1 = p.softcap > 0.f ? 2.0f * a.scale_log2e / p.softcap : 0.f, cap_c2 = p.softcap * kLog2e;
+    (void)cap_k1; (void)cap_c2;
     DropCtx dc = {0, 0, 0, 0};
     if (DROPOUT) {
         dc.k0 = (uint32_t)p.philox_seed; dc.k1 = (uint32_t)(p.philox_seed >> 32);
@@ -417,6 +420,11 @@ __global__ void __launch_bounds__(BWD_THREADS, 1) fa_bwd_dkdv_kernel(const KArgs
                 }
                 pr = fast_exp2(fmaf(sv, kLog2e, -l2));
                 dsr = pr * (dpe - dsum[r >> 2][r & 3]) * chain;
+            } else if (BIAS == 3) {
+                const float rr1 = fast_rcp(1.0f + fast_exp2(s_acc[r] * cap_k1));
+                const float t = fmaf(rr1, -2.0f, 1.0f);                      // tanh(s scale / cap)
+                pr = fast_exp2(fmaf(rr1, -2.0f * cap_c2, cap_c2) - l2);
+                dsr = pr * (dpe - dsum[r >> 2][r & 3]) * fmaf(-t, t, 1.0f);
             } else {
                 pr = fast_exp2(fmaf(s_acc[r], c, -l2));
                 dsr = pr * (dpe - dsum[r >> 2][r & 3]);
@@ -470,6 +478,11 @@ __global__ void __launch_bounds__(BWD_THREADS, 1) fa_bwd_dkdv_kernel(const KArgs
                 }
                 pr = fast_exp2(fmaf(sv, kLog2e, -l2v[e]));
                 dsr = pr * (dpe - dsm[e]) * chain;
+            } else if (BIAS == 3) {
+                const float rr1 = fast_rcp(1.0f + fast_exp2(s_acc[r] * cap_k1));
+                const float t = fmaf(rr1, -2.0f, 1.0f);
+                pr = fast_exp2(fmaf(rr1, -2.0f * cap_c2, cap_c2) - l2v[e]);
+                dsr = pr * (dpe - dsm[e]) * fmaf(-t, t, 1.0f);
             } else {
                 pr = fast_exp2(fmaf(s_acc[r], c, -l2v[e]));
                 dsr = pr * (dpe - dsm[e]);
@@ -763,6 +776,9 @@ __global__ void __launch_bounds__(BWD_THREADS, D <= 64 ? FA_DKV2_OCC64 : 2) fa_b
     const int wl = p.window_left;
     const int wr = p.is_causal ? 0 : p.window_right;
     const float c = a.scale_log2e;
+    // softcap-only variant (BIAS == 3): cap tanh(s scale / cap) = cap (1 - 2 / (1 + exp2(s k1))), log2 units
+    const float cap_k1 = p.softcap > 0.f ? 2.0f * a.scale_log2e / p.softcap : 0.f, cap_c2 = p.softcap * kLog2e;
+    (void)cap_k1; (void)cap_c2;
     const int dv = valid_cols(p);
     DropCtx dc = {0, 0, 0, 0};
     if (DROPOUT) {
@@ -990,14 +1006,22 @@ __global__ void __launch_bounds__(BWD_THREADS, D <= 64 ? FA_DKV2_OCC64 : 2) fa_b
                     l2 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(sidx + 4 * cpos, __builtin_bit_cast(int, statv)));
                     dsm = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(sidx + 4 * (32 + cpos), __builtin_bit_cast(int, statv)));
                 }
-                const float pr = fast_exp2(fmaf(s_acc[r], c, -l2));
+                float pr, chain = 1.0f;
+                if (BIAS == 3) {
+                    const float rr1 = fast_rcp(1.0f + fast_exp2(s_acc[r] * cap_k1));
+                    const float t = fmaf(rr1, -2.0f, 1.0f);
+                    pr = fast_exp2(fmaf(rr1, -2.0f * cap_c2, cap_c2) - l2);
+                    chain = fmaf(-t, t, 1.0f);
+                } else {
+                    pr = fast_exp2(fmaf(s_acc[r], c, -l2));
+                }
                 if (DROPOUT) {       // dS = P (keep rp dP - D); dV accumulates keep P (rp applied in the epilogue)
                     const bool keep = (kbits >> r) & 1u;
                     pv[r] = keep ? pr : 0.f;
                     dsv[r] = pr * ((keep ? dp_acc[r] * a.rp_dropout : 0.f) - dsm);
                 } else {
                     pv[r] = pr;
-                    dsv[r] = pr * (dp_acc[r] - dsm);
+                    dsv[r] = pr * (dp_acc[r] - dsm) * chain;
                 }
             }
         }
@@ -1104,6 +1128,9 @@ __global__ void __launch_bounds__(BWD_THREADS, OCC) fa_bwd_dq_kernel(const KArgs
     const int wl = p.window_left;
     const int wr = p.is_causal ? 0 : p.window_right;
     const float c = a.scale_log2e;
+    // softcap-only variant (BIAS == 3): cap tanh(s scale / cap) = cap (1 - 2 / (1 + exp2(s k1))), log2 units
+    const float cap_k1 = p.softcap > 0.f ? 2.0f * a.scale_log2e / p.softcap : 0.f, cap_c2 = p.softcap * kLog2e;
+    (void)cap_k1; (void)cap_c2;
 
     const int64_t kb_off = p.cu_seqlens_k ? 0 : (int64_t)w.b * p.k_batch_stride;
     const int64_t vb_off = p.cu_seqlens_k ? 0 : (int64_t)w.b * p.v_batch_stride;
@@ -1273,6 +1300,11 @@ __global__ void __launch_bounds__(BWD_THREADS, OCC) fa_bwd_dq_kernel(const KArgs
                     }
                     pr = fast_exp2(fmaf(s, kLog2e, -lse2));
                     dsr = pr * (dpe - dsum) * chain;
+                } else if (BIAS == 3) {
+                    const float rr1 = fast_rcp(1.0f + fast_exp2(s_acc[r] * cap_k1));
+                    const float t = fmaf(rr1, -2.0f, 1.0f);
+                    pr = fast_exp2(fmaf(rr1, -2.0f * cap_c2, cap_c2) - lse2);
+                    dsr = pr * (dpe - dsum) * fmaf(-t, t, 1.0f);
                 } else {
                     pr = fast_exp2(fmaf(s_acc[r], c, -lse2));
                     dsr = pr * (dpe - dsum);
@@ -1565,7 +1597,8 @@ static int launch_bwd_td(const KArgs& a, hipStream_t stream) {
         static const bool dkv2_env = getenv("FA_DKDV1") == nullptr;
         bool done = false;
         if constexpr (D <= 128) {
-            if (dkv2_env && (!a.has_bias || (lin_alibi && !drop)) && grid > 0) {
+            const bool cap_only = p.softcap > 0.f && !p.alibi_slopes;
+            if (dkv2_env && (!a.has_bias || ((lin_alibi || cap_only) && !drop)) && grid > 0) {
                 const size_t smem2 = Dkv2Smem<D>::TOTAL;
 #define FA_LAUNCH_DKV2(BIAS, DROP)                                                                                \
                 do {                                                                                              \
@@ -1573,7 +1606,8 @@ static int launch_bwd_td(const KArgs& a, hipStream_t stream) {
                     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2); \
                     hipLaunchKernelGGL(kern, dim3(grid), dim3(BWD_THREADS), smem2, stream, a);                    \
                 } while (0)
-                if (a.has_bias) FA_LAUNCH_DKV2(2, false);
+                if (a.has_bias && lin_alibi) FA_LAUNCH_DKV2(2, false);
+                else if (a.has_bias) FA_LAUNCH_DKV2(3, false);
                 else if (drop) FA_LAUNCH_DKV2(0, true);
                 else FA_LAUNCH_DKV2(0, false);
 #undef FA_LAUNCH_DKV2
@@ -1610,7 +1644,11 @@ static int launch_bwd_td(const KArgs& a, hipStream_t stream) {
         } while (0)
         if (grid > 0) {
             if (drop) { if (a.has_bias) FA_LAUNCH_DQ(1, true); else FA_LAUNCH_DQ(0, true); }
-            else if (a.has_bias) { if (lin_alibi) FA_LAUNCH_DQ(2, false); else FA_LAUNCH_DQ(1, false); }
+            else if (a.has_bias) {
+                if (lin_alibi) FA_LAUNCH_DQ(2, false);
+                else if (!p.alibi_slopes) FA_LAUNCH_DQ(3, false);            // softcap only
+                else FA_LAUNCH_DQ(1, false);
+            }
             else      FA_LAUNCH_DQ(0, false);
         }
 #undef FA_LAUNCH_DQ

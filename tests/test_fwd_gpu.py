@@ -61,6 +61,9 @@ CASES = [
     (1, 4, 4, 640, 640, 128, "bf16", False, (200, 0), 0.0, True),     # fast path via window_right == 0
     (1, 4, 4, 320, 320, 128, "bf16", False, (-1, -1), 0.0, True),     # general path (keys right of the diagonal)
     (1, 4, 4, 320, 320, 64, "fp16", False, (64, 32), 0.0, True),      # general path, two-sided window
+    # softcap only (constants-folded variant; Gemma-2 style)
+    (2, 8, 2, 333, 333, 128, "bf16", True, (-1, -1), 50.0, False),
+    (1, 4, 4, 200, 450, 64, "fp16", True, (128, 0), 20.0, False),
 ]
 
 
