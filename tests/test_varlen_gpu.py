@@ -61,10 +61,10 @@ def test_varlen_fwd_bwd_vs_oracle(case):
     assert_close(f64(dv), dv_r, dt, "dv", mult=2.0)
 
 
-@pytest.mark.parametrize("page", [64, 256])
-def test_varlen_paged_kv(page):
+@pytest.mark.parametrize("page,D", [(64, 128), (256, 128), (128, 96), (64, 64)])
+def test_varlen_paged_kv(page, D):
     lens_q, lens_k = [70, 1, 300], [200, 513, 300]
-    Hq, Hk, D, dt = 4, 2, 128, "fp16"
+    Hq, Hk, dt = 4, 2, "fp16"
     B = len(lens_q)
     nblk_per_seq = [(l + page - 1) // page for l in lens_k]
     max_blocks = max(nblk_per_seq)
