@@ -163,8 +163,9 @@ def _dense_forward(q, k, v, dropout_p, softmax_scale, causal, window_size, softc
     if return_softmax and dropout_p > 0.0:
         dmask = torch.zeros((B, H_Q, M, N), dtype=q.dtype, device=q.device)
         p.dmask = _ptr(dmask)
-    with torch.cuda.device(q.device):
-        _lib.call("fa_fwd", p, _stream(q.device))
+    if q_.numel() > 0:                                   # (an empty query block is a no-op)
+        with torch.cuda.device(q.device):
+            _lib.call("fa_fwd", p, _stream(q.device))
     out = out_ if dpad == head_size_og else out_[..., :head_size_og].contiguous()
     return out, lse, dmask, (q_, k_, v_, out_), rng, softmax_scale
 
@@ -176,6 +177,9 @@ def _dense_backward(dout, q_, k_, v_, out_, lse, alibi_slopes, dropout_p, softma
     N, H_K = k_.shape[1], k_.shape[2]
     dout_ = _prep(dout, dpad)
     softmax_d = torch.empty((B, H_Q, M), dtype=torch.float32, device=q_.device)
+    if q_.numel() == 0:                                  # no queries: nothing flows into K / V
+        dk_.zero_(); dv_.zero_()
+        return softmax_d
     p = _base_params(q_, q_.dtype, softmax_scale, causal, window_size, softcap)
     p.q, p.k, p.v, p.o, p.lse = _ptr(q_), _ptr(k_), _ptr(v_), _ptr(out_), _ptr(lse)
     p.dout, p.dq, p.dk, p.dv, p.softmax_d = _ptr(dout_), _ptr(dq_), _ptr(dk_), _ptr(dv_), _ptr(softmax_d)
@@ -369,8 +373,9 @@ def _varlen_forward(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqle
     if return_attn_probs and dropout_p > 0.0:
         dmask = torch.zeros((T_Q, H_Q, max_seqlen_k), dtype=q.dtype, device=q.device)
         p.dmask = _ptr(dmask)
-    with torch.cuda.device(q.device):
-        _lib.call("fa_varlen_fwd", p, _stream(q.device))
+    if q_.numel() > 0:
+        with torch.cuda.device(q.device):
+            _lib.call("fa_varlen_fwd", p, _stream(q.device))
     out = out_ if dpad == head_size_og else out_[..., :head_size_og].contiguous()
     return out, lse, dmask, (q_, k_, v_, out_, cu_seqlens_q, cu_seqlens_k), rng, softmax_scale
 
@@ -383,6 +388,9 @@ def _varlen_backward(dout, q_, k_, v_, out_, lse, cu_seqlens_q, cu_seqlens_k, al
     B = cu_seqlens_q.numel() - 1
     dout_ = _prep(dout, dpad)
     softmax_d = torch.empty((H_Q, T_Q), dtype=torch.float32, device=q_.device)
+    if q_.numel() == 0:
+        dk_.zero_(); dv_.zero_()
+        return softmax_d
     p = _base_params(q_, q_.dtype, softmax_scale, causal, window_size, softcap)
     p.q, p.k, p.v, p.o, p.lse = _ptr(q_), _ptr(k_), _ptr(v_), _ptr(out_), _ptr(lse)
     p.dout, p.dq, p.dk, p.dv, p.softmax_d = _ptr(dout_), _ptr(dq_), _ptr(dk_), _ptr(dv_), _ptr(softmax_d)

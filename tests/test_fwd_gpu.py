@@ -165,3 +165,25 @@ def test_full_size_property_config5_shard():
                                             alibi_slopes=f64(slopes[h:h + 1]))
         assert_close(f64(out[b, i, h]), o_ref[0, 0, 0], dt, f"row {b},{h},{i}", mult=2.0)
         assert abs(float(lse[b, h, i]) - float(lse_ref[0, 0, 0])) < 3e-3
+
+
+def test_degenerate_shapes():
+    """Empty query block (no-op, zero dK/dV), stride-0 expanded K/V heads == MQA, 1 x 1, and a 64K-token row."""
+    fa = _fa()
+    q = torch.randn(2, 0, 4, 64, device="cuda", dtype=torch.float16, requires_grad=True)
+    k = torch.randn(2, 50, 4, 64, device="cuda", dtype=torch.float16, requires_grad=True)
+    o = fa.flash_attn_func(q, k, k, causal=True)
+    assert o.shape == (2, 0, 4, 64)
+    dq, dk = torch.autograd.grad(o, (q, k), torch.zeros_like(o))
+    assert dq.shape == q.shape and (dk == 0).all()
+    q = torch.randn(1, 100, 8, 128, device="cuda", dtype=torch.bfloat16)
+    k1 = torch.randn(1, 100, 1, 128, device="cuda", dtype=torch.bfloat16)
+    a = fa.flash_attn_func(q, k1.expand(-1, -1, 8, -1), k1.expand(-1, -1, 8, -1), causal=True)
+    assert torch.equal(a, fa.flash_attn_func(q, k1, k1, causal=True))
+    o = fa.flash_attn_func(q[:, :1], k1[:, :1], k1[:, :1])
+    assert torch.allclose(o.float(), k1[:, :1].expand(-1, -1, 8, -1).float(), atol=1e-2)
+    q = torch.randn(1, 65536, 1, 64, device="cuda", dtype=torch.float16)
+    o, lse, _ = fa.flash_attn_func(q, q, q, causal=True, return_attn_probs=True)
+    assert torch.isfinite(o).all() and torch.isfinite(lse).all()
+    # row 0 of causal attention is v[0]
+    assert torch.allclose(o[0, 0].float(), q[0, 0].float(), atol=1e-3)
