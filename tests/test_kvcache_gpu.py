@@ -244,3 +244,34 @@ def test_kvcache_paged_chunk_prefill_general_path(lp_kind):
     assert np.array_equal(f64(kc), kc_ref) and np.array_equal(f64(vc), vc_ref)
     assert_close(f64(out), o_ref, dt, "out", mult=1.5)
     assert_lse_close(f64(lse), lse_ref, "lse", atol=2e-2)
+
+
+def test_kvcache_edge_cases():
+    """Empty cache (no keys: O = 0, LSE = -inf), append to an empty cache (O = v_new), mixed lengths with more
+    splits requested than tiles, and a sliding window on decode."""
+    dev = "cuda"
+    torch.manual_seed(0)
+    B, H, Hk, D, cap = 3, 8, 2, 128, 256
+    q = torch.randn(B, 1, H, D, device=dev, dtype=torch.float16)
+    kc = torch.randn(B, cap, Hk, D, device=dev, dtype=torch.float16); vc = torch.randn_like(kc)
+    fa = _fa()
+    sl = torch.zeros(B, dtype=torch.int32, device=dev)
+    o, lse = fa.flash_attn_with_kvcache(q, kc, vc, cache_seqlens=sl, causal=True, return_softmax_lse=True)
+    assert (o == 0).all() and torch.isneginf(lse).all()
+    kn = torch.randn(B, 1, Hk, D, device=dev, dtype=torch.float16); vn = torch.randn_like(kn)
+    o = fa.flash_attn_with_kvcache(q, kc.clone(), vc.clone(), k=kn, v=vn, cache_seqlens=sl, causal=True)
+    assert torch.allclose(o.float(), vn.repeat_interleave(H // Hk, dim=2).float(), atol=2e-3)
+    sl = torch.tensor([0, 5, cap - 1], dtype=torch.int32, device=dev)
+    o, lse = fa.flash_attn_with_kvcache(q, kc.clone(), vc.clone(), k=kn, v=vn, cache_seqlens=sl, causal=True,
+                                        num_splits=16, return_softmax_lse=True)
+    kr, vr = f64(kc).copy(), f64(vc).copy()
+    o_ref, lse_ref = oracle.kvcache_fwd(f64(q), kr, vr, k=f64(kn), v=f64(vn), cache_seqlens=sl.cpu().numpy(),
+                                        causal=True, io_dtype="fp16")
+    assert_close(f64(o), o_ref, "fp16", "out")
+    assert_lse_close(f64(lse), lse_ref, "lse")
+    lens = np.array([200, 100, 255], dtype=np.int32)
+    o = fa.flash_attn_with_kvcache(q, kc.clone(), vc.clone(), cache_seqlens=torch.from_numpy(lens).cuda(),
+                                   window_size=(31, 0))
+    kr, vr = f64(kc).copy(), f64(vc).copy()
+    o_ref, _ = oracle.kvcache_fwd(f64(q), kr, vr, cache_seqlens=lens, window=(31, 0), io_dtype="fp16")
+    assert_close(f64(o), o_ref, "fp16", "out")
