@@ -27,6 +27,12 @@ constexpr int FWD_BM = 128;
 #ifndef FA_FWD_BN
 #define FA_FWD_BN 64
 #endif
+#ifndef FA_FWD_PFK
+#define FA_FWD_PFK 4                                   // K fragments in flight ahead of their MFMA (0: compiler's order)
+#endif
+#ifndef FA_FWD_PFV
+#define FA_FWD_PFV 3                                   // V fragments (two transposing reads each) in flight
+#endif
 #ifndef FA_FWD_OCC
 #define FA_FWD_OCC 2
 #endif
@@ -321,6 +327,24 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : FA_FWD_OCC)) fa_fw
 #ifndef FA_NO_SETPRIO
         __builtin_amdgcn_s_setprio(1);
 #endif
+#if FA_FWD_PFK > 0
+        {
+            // hipcc's scheduler, left alone, serialises read -> wait -> MFMA through ONE temporary (every
+            // MFMA eats a full LDS round trip).  Fences pin the K fragment of MFMA i + PFK ahead of MFMA i.
+            constexpr int NQK = KSTEPS * FWD_NKB;
+            u32x4 kk[NQK];
+            auto kread = [&](int i) { return lds_read_b128(sbase + k_rd[i / FWD_NKB] + (i % FWD_NKB) * 32 * D * 2); };
+#pragma unroll
+            for (int i = 0; i < FA_FWD_PFK && i < NQK; ++i) kk[i] = kread(i);
+#pragma unroll
+            for (int i = 0; i < NQK; ++i) {
+                if (i + FA_FWD_PFK < NQK) kk[i + FA_FWD_PFK] = kread(i + FA_FWD_PFK);
+                __builtin_amdgcn_sched_barrier(0);
+                sacc[i % FWD_NKB] = E::mfma(kk[i], qf[i / FWD_NKB], sacc[i % FWD_NKB]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#else
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks) {
             u32x4 kk[FWD_NKB];
@@ -329,6 +353,7 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : FA_FWD_OCC)) fa_fw
 #pragma unroll
             for (int kb = 0; kb < FWD_NKB; ++kb) sacc[kb] = E::mfma(kk[kb], qf[ks], sacc[kb]);
         }
+#endif
 #ifndef FA_NO_SETPRIO
         __builtin_amdgcn_s_setprio(0);
 #endif
@@ -440,6 +465,36 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : FA_FWD_OCC)) fa_fw
         }
 
         // ---- O^T += V^T P^T : k-step t covers C-layout regs 8 (t&1) .. +7 of sacc[t>>1] ----
+#if FA_FWD_PFV > 0
+        {
+            constexpr int NT = 2 * FWD_NKB, NPV = NT * DBLKS;
+            u32x4 pf[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int kb = t >> 1, ks2 = t & 1;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pf[t][e] = E::pack2(sacc[kb][8 * ks2 + 2 * e], sacc[kb][8 * ks2 + 2 * e + 1]);
+            }
+            // rows kb*32 + 16 ks2 + 8 hf + 4 g + (0..3) = 16 t + ..., 64-byte column block d
+            auto vread = [&](int i) {
+                const int t = i / DBLKS, d = i % DBLKS;
+                const int row_a = 16 * t + 4 * g + v_rr;
+                const u32x2 v0 = lds_read_tr16(sbase + TILE + swzt_row_off<D>(row_a, d * 64 + v_cb));
+                const u32x2 v1 = lds_read_tr16(sbase + TILE + swzt_row_off<D>(row_a + 8, d * 64 + v_cb));
+                return u32x4{v0[0], v0[1], v1[0], v1[1]};
+            };
+            u32x4 vf[NPV];
+#pragma unroll
+            for (int i = 0; i < FA_FWD_PFV && i < NPV; ++i) vf[i] = vread(i);
+#pragma unroll
+            for (int i = 0; i < NPV; ++i) {
+                if (i + FA_FWD_PFV < NPV) vf[i + FA_FWD_PFV] = vread(i + FA_FWD_PFV);
+                __builtin_amdgcn_sched_barrier(0);
+                oacc[i % DBLKS] = E::mfma(vf[i], pf[i / DBLKS], oacc[i % DBLKS]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#else
 #pragma unroll
         for (int t = 0; t < 2 * FWD_NKB; ++t) {
             const int kb = t >> 1, ks2 = t & 1;
@@ -458,6 +513,7 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : FA_FWD_OCC)) fa_fw
                 oacc[d] = E::mfma(vf, pf, oacc[d]);
             }
         }
+#endif
     };
 
     auto tile_step = [&](auto stage_c, int nb) {
