@@ -727,6 +727,9 @@ template <int D> struct Dkv2Smem {
 #endif
 };
 
+#ifndef FA_DKV2_PF
+#define FA_DKV2_PF 3                                    // transposed dO / Q fragments in flight ahead of their MFMA
+#endif
 template <typename T, int D, int BIAS, bool DROPOUT>
 __global__ void __launch_bounds__(BWD_THREADS, D <= 64 ? FA_DKV2_OCC64 : 2) fa_bwd_dkdv2_kernel(const KArgs a) {
     using E = Elem<T>;
@@ -1052,6 +1055,34 @@ __global__ void __launch_bounds__(BWD_THREADS, D <= 64 ? FA_DKV2_OCC64 : 2) fa_b
             }
         }
         // ---- dV^T += dO^T P,  dK^T += Q^T dS ----
+#if FA_DKV2_PF > 0
+        {
+            // MFMA i = (t, d, dO | Q); fences keep the transposed operand of MFMA i + PF in flight ahead of MFMA i
+            // (S / dP are dead here, so the extra fragments cost no registers; hipcc alone serialises
+            // read -> wait -> MFMA through one temporary)
+            constexpr int NBK = 4 * DBLKS;
+            auto tread = [&](int i) {
+                const int t = i / (2 * DBLKS), d = (i >> 1) % DBLKS;
+                const char* src = (i & 1) ? qs : dos;
+                const int row_a = 16 * t + 4 * g + rr;
+                const u32x2 a0 = lds_read_tr16(src + swzt_row_off<D>(row_a, d * 64 + cb));
+                const u32x2 a1 = lds_read_tr16(src + swzt_row_off<D>(row_a + 8, d * 64 + cb));
+                return u32x4{a0[0], a0[1], a1[0], a1[1]};
+            };
+            u32x4 tf[NBK];
+#pragma unroll
+            for (int i = 0; i < FA_DKV2_PF && i < NBK; ++i) tf[i] = tread(i);
+#pragma unroll
+            for (int i = 0; i < NBK; ++i) {
+                if (i + FA_DKV2_PF < NBK) tf[i + FA_DKV2_PF] = tread(i + FA_DKV2_PF);
+                __builtin_amdgcn_sched_barrier(0);
+                const int t = i / (2 * DBLKS), d = (i >> 1) % DBLKS;
+                if (i & 1) dk_acc[d] = E::mfma(tf[i], dsf[t], dk_acc[d]);
+                else dv_acc[d] = E::mfma(tf[i], pf[t], dv_acc[d]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#else
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const int row_a = 16 * t + 4 * g + rr;
@@ -1067,6 +1098,7 @@ __global__ void __launch_bounds__(BWD_THREADS, D <= 64 ? FA_DKV2_OCC64 : 2) fa_b
                 dk_acc[d] = E::mfma(bfr, dsf[t], dk_acc[d]);
             }
         }
+#endif
         publish_stats();
     }
 
@@ -1098,6 +1130,12 @@ __global__ void __launch_bounds__(BWD_THREADS, D <= 64 ? FA_DKV2_OCC64 : 2) fa_b
 // ---------------------------------------------------------------------------------------------
 // 3. dQ
 // ---------------------------------------------------------------------------------------------
+#ifndef FA_DQ_PFS
+#define FA_DQ_PFS 2                                     // K / V fragments in flight ahead of their S / dP MFMA
+#endif
+#ifndef FA_DQ_PFT
+#define FA_DQ_PFT 2                                     // transposed K fragments in flight ahead of their dQ MFMA
+#endif
 constexpr int DQ_BM = 128;
 constexpr int DQ_BN = 64;
 
@@ -1265,6 +1303,25 @@ __global__ void __launch_bounds__(BWD_THREADS, OCC) fa_bwd_dq_kernel(const KArgs
                                                        (float)(n0 + kb * 32 - off - wave_row0));
                 s_acc = E::mfma(alibi_a, ab, s_acc);
             }
+#if FA_DQ_PFS > 0
+            {
+                // two alternating accumulator chains; fences keep the K / V fragment of MFMA i + PFS in flight ahead of
+                // MFMA i (hipcc alone serialises read -> wait -> MFMA through one temporary)
+                constexpr int NSD = 2 * KSTEPS;
+                auto fread = [&](int i) { return lds_read_b128(sbase + ((i & 1) ? v_rd[i >> 1] : k_rd[i >> 1]) + kb * 32 * D * 2); };
+                u32x4 fr[NSD];
+#pragma unroll
+                for (int i = 0; i < FA_DQ_PFS && i < NSD; ++i) fr[i] = fread(i);
+#pragma unroll
+                for (int i = 0; i < NSD; ++i) {
+                    if (i + FA_DQ_PFS < NSD) fr[i + FA_DQ_PFS] = fread(i + FA_DQ_PFS);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (i & 1) dp_acc = E::mfma(fr[i], dof[i >> 1], dp_acc);
+                    else s_acc = E::mfma(fr[i], qf[i >> 1], s_acc);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+#else
 #pragma unroll
             for (int ks = 0; ks < KSTEPS; ++ks) {                // two alternating accumulator chains
                 const u32x4 ka = lds_read_b128(sbase + k_rd[ks] + kb * 32 * D * 2);
@@ -1272,6 +1329,7 @@ __global__ void __launch_bounds__(BWD_THREADS, OCC) fa_bwd_dq_kernel(const KArgs
                 s_acc = E::mfma(ka, qf[ks], s_acc);
                 dp_acc = E::mfma(va, dof[ks], dp_acc);
             }
+#endif
             float dsv[16];
             uint32_t kbits = 0xffffu;
             if (DROPOUT) {
@@ -1322,6 +1380,33 @@ __global__ void __launch_bounds__(BWD_THREADS, OCC) fa_bwd_dq_kernel(const KArgs
                 }
             }
             // dQ^T += K^T dS^T
+#if FA_DQ_PFT > 0
+            {
+                constexpr int NDQ = 2 * DBLKS;
+                u32x4 dsf[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int w2 = 0; w2 < 4; ++w2) dsf[t][w2] = E::pack2(dsv[8 * t + 2 * w2], dsv[8 * t + 2 * w2 + 1]);
+                auto tread = [&](int i) {
+                    const int t = i / DBLKS, d = i % DBLKS;
+                    const int row_a = kb * 32 + 16 * t + 4 * g + rr;
+                    const u32x2 a0 = lds_read_tr16(sbase + swzt_row_off<D>(row_a, d * 64 + cb));
+                    const u32x2 a1 = lds_read_tr16(sbase + swzt_row_off<D>(row_a + 8, d * 64 + cb));
+                    return u32x4{a0[0], a0[1], a1[0], a1[1]};
+                };
+                u32x4 tf[NDQ];
+#pragma unroll
+                for (int i = 0; i < FA_DQ_PFT && i < NDQ; ++i) tf[i] = tread(i);
+#pragma unroll
+                for (int i = 0; i < NDQ; ++i) {
+                    if (i + FA_DQ_PFT < NDQ) tf[i + FA_DQ_PFT] = tread(i + FA_DQ_PFT);
+                    __builtin_amdgcn_sched_barrier(0);
+                    dq_acc[i % DBLKS] = E::mfma(tf[i], dsf[i / DBLKS], dq_acc[i % DBLKS]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+#else
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 u32x4 dsf;
@@ -1336,6 +1421,7 @@ __global__ void __launch_bounds__(BWD_THREADS, OCC) fa_bwd_dq_kernel(const KArgs
                     dq_acc[d] = E::mfma(af, dsf, dq_acc[d]);
                 }
             }
+#endif
         }
     };
     auto step = [&](auto stage_c, int nb) {
