@@ -1130,6 +1130,9 @@ __global__ void __launch_bounds__(BWD_THREADS, D <= 64 ? FA_DKV2_OCC64 : 2) fa_b
 // ---------------------------------------------------------------------------------------------
 // 3. dQ
 // ---------------------------------------------------------------------------------------------
+#ifndef FA_DQ_OCC64
+#define FA_DQ_OCC64 2                                   // waves per SIMD of the dQ kernel at head dim 64
+#endif
 #ifndef FA_DQ_PFS
 #define FA_DQ_PFS 2                                     // K / V fragments in flight ahead of their S / dP MFMA
 #endif
@@ -1204,6 +1207,20 @@ __global__ void __launch_bounds__(BWD_THREADS, OCC) fa_bwd_dq_kernel(const KArgs
     }
     const int rr = (lane & 15) >> 2;
     const int cb = (((lane >> 4) & 1) << 5) + ((lane & 3) << 3);
+#if FA_DQ_PFS > 0
+    // pinned lane-constant read addresses (stage and key block are immediate offsets): see lds_pin
+    const lds_char* k_ptr[KSTEPS];
+    const lds_char* v_ptr[KSTEPS];
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) { k_ptr[ks] = lds_pin(smem + k_rd[ks]); v_ptr[ks] = lds_pin(smem + v_rd[ks]); }
+#endif
+#if FA_DQ_PFT > 0
+    const lds_char* t_ptr[2][DBLKS];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int d = 0; d < DBLKS; ++d) t_ptr[h][d] = lds_pin(smem + swzt_row_off<D>(4 * g + rr + 8 * h, d * 64 + cb));
+#endif
     float slope = 0.f;
     if (BIAS && p.alibi_slopes) slope = p.alibi_slopes[w.b * p.alibi_batch_stride + w.h];
     const u32x4 alibi_a = alibi_pos_operand<T>(lane);
@@ -1308,7 +1325,7 @@ __global__ void __launch_bounds__(BWD_THREADS, OCC) fa_bwd_dq_kernel(const KArgs
                 // two alternating accumulator chains; fences keep the K / V fragment of MFMA i + PFS in flight ahead of
                 // MFMA i (hipcc alone serialises read -> wait -> MFMA through one temporary)
                 constexpr int NSD = 2 * KSTEPS;
-                auto fread = [&](int i) { return lds_read_b128(sbase + ((i & 1) ? v_rd[i >> 1] : k_rd[i >> 1]) + kb * 32 * D * 2); };
+                auto fread = [&](int i) { return lds_read_b128(((i & 1) ? v_ptr[i >> 1] : k_ptr[i >> 1]) + (stage * STAGE + kb * 32 * D * 2)); };
                 u32x4 fr[NSD];
 #pragma unroll
                 for (int i = 0; i < FA_DQ_PFS && i < NSD; ++i) fr[i] = fread(i);
@@ -1390,9 +1407,8 @@ __global__ void __launch_bounds__(BWD_THREADS, OCC) fa_bwd_dq_kernel(const KArgs
                     for (int w2 = 0; w2 < 4; ++w2) dsf[t][w2] = E::pack2(dsv[8 * t + 2 * w2], dsv[8 * t + 2 * w2 + 1]);
                 auto tread = [&](int i) {
                     const int t = i / DBLKS, d = i % DBLKS;
-                    const int row_a = kb * 32 + 16 * t + 4 * g + rr;
-                    const u32x2 a0 = lds_read_tr16(sbase + swzt_row_off<D>(row_a, d * 64 + cb));
-                    const u32x2 a1 = lds_read_tr16(sbase + swzt_row_off<D>(row_a + 8, d * 64 + cb));
+                    const u32x2 a0 = lds_read_tr16(t_ptr[0][d] + (stage * STAGE + (kb * 32 + 16 * t) * D * 2));
+                    const u32x2 a1 = lds_read_tr16(t_ptr[1][d] + (stage * STAGE + (kb * 32 + 16 * t) * D * 2));
                     return u32x4{a0[0], a0[1], a1[0], a1[1]};
                 };
                 u32x4 tf[NDQ];
@@ -1720,7 +1736,7 @@ static int launch_bwd_td(const KArgs& a, hipStream_t stream) {
         const int grid = work_grid(p.batch, p.nheads_q, p.nheads_k, a.n_qblocks);
         const size_t smem = DqSmem<D>::TOTAL;
         // D = 128: two waves per SIMD spill ~10 registers but measure 11 % faster than one wave
-        constexpr int OCC = (D > 128) ? 1 : 2;
+        constexpr int OCC = (D > 128) ? 1 : (D <= 64 ? FA_DQ_OCC64 : 2);
 #define FA_LAUNCH_DQ(BIAS, DROP)                                                                                  \
         do {                                                                                                      \
             /* dropout needs the Philox registers: two waves per SIMD spill 84 of them (4.0 ms), one wave none */ \

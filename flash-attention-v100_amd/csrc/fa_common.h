@@ -73,6 +73,20 @@ __device__ __forceinline__ u32x2 lds_read_tr16(const char* smem_ptr) {
     return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16(p));
 }
 
+// LDS-space pointers whose VALUE is pinned in a VGPR: hipcc otherwise re-derives "LDS base (0) + lane offset" with a
+// v_add_u32 in front of every read instead of keeping the lane-constant address and using the immediate offset field.
+typedef __attribute__((address_space(3))) char lds_char;
+__device__ __forceinline__ const lds_char* lds_pin(const char* p) {
+    const lds_char* q = (const lds_char*)p;
+    asm volatile("" : "+v"(q));
+    return q;
+}
+__device__ __forceinline__ u32x4 lds_read_b128(const lds_char* p) {
+    return *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(p);
+}
+__device__ __forceinline__ u32x2 lds_read_tr16(const lds_char* p) {
+    return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) lds_i16x4_t*)(p)));
+}
 __device__ __forceinline__ u32x4 lds_read_b128(const char* smem_ptr) {
     return *reinterpret_cast<const u32x4*>(smem_ptr);
 }

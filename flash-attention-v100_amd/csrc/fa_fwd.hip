@@ -292,6 +292,18 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : FA_FWD_OCC)) fa_fw
     for (int ks = 0; ks < KSTEPS; ++ks) k_rd[ks] = swz_row_off<D>(l31, 32 * ks + 16 * g);
     const int v_rr = (lane & 15) >> 2;                                  // row within a 4-row transpose group
     const int v_cb = (((lane >> 4) & 1) << 5) + ((lane & 3) << 3);       // byte column within a 64-byte d-block
+#if FA_FWD_PFK > 0
+    // lane-constant read addresses, pinned (stage, key block and 16-key step are immediate offsets: the swizzles
+    // do not depend on row bits >= 4)
+    const lds_char* k_ptr[KSTEPS];
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) k_ptr[ks] = lds_pin(smem + k_rd[ks]);
+    const lds_char* v_ptr[2][DBLKS];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int d = 0; d < DBLKS; ++d) v_ptr[h][d] = lds_pin(smem + TILE + swzt_row_off<D>(4 * g + v_rr + 8 * h, d * 64 + v_cb));
+#endif
     // ALiBi fast path ("rank-2 update"): when every visible key is at or left of the diagonal
     // (causal / window_right == 0) and there is no softcap, the bias -slope (i + off - j) is linear
     // in the key position j = n0 + pos.  Its row- and tile-constant part slope (n0 - i - off) only
@@ -333,7 +345,7 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : FA_FWD_OCC)) fa_fw
             // MFMA eats a full LDS round trip).  Fences pin the K fragment of MFMA i + PFK ahead of MFMA i.
             constexpr int NQK = KSTEPS * FWD_NKB;
             u32x4 kk[NQK];
-            auto kread = [&](int i) { return lds_read_b128(sbase + k_rd[i / FWD_NKB] + (i % FWD_NKB) * 32 * D * 2); };
+            auto kread = [&](int i) { return lds_read_b128(k_ptr[i / FWD_NKB] + (stage * STAGE + (i % FWD_NKB) * 32 * D * 2)); };
 #pragma unroll
             for (int i = 0; i < FA_FWD_PFK && i < NQK; ++i) kk[i] = kread(i);
 #pragma unroll
@@ -478,9 +490,8 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : FA_FWD_OCC)) fa_fw
             // rows kb*32 + 16 ks2 + 8 hf + 4 g + (0..3) = 16 t + ..., 64-byte column block d
             auto vread = [&](int i) {
                 const int t = i / DBLKS, d = i % DBLKS;
-                const int row_a = 16 * t + 4 * g + v_rr;
-                const u32x2 v0 = lds_read_tr16(sbase + TILE + swzt_row_off<D>(row_a, d * 64 + v_cb));
-                const u32x2 v1 = lds_read_tr16(sbase + TILE + swzt_row_off<D>(row_a + 8, d * 64 + v_cb));
+                const u32x2 v0 = lds_read_tr16(v_ptr[0][d] + (stage * STAGE + 16 * t * D * 2));
+                const u32x2 v1 = lds_read_tr16(v_ptr[1][d] + (stage * STAGE + 16 * t * D * 2));
                 return u32x4{v0[0], v0[1], v1[0], v1[1]};
             };
             u32x4 vf[NPV];
