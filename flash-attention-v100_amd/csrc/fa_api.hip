@@ -7,6 +7,7 @@
 //   backward kernel/fused_mha_backward.cu:577-692, kernel/fused_mha_backward_varlen.cu:636-765
 // Errors never cross the boundary as exceptions: negative status + fa_last_error().
 #include <cstdarg>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -160,6 +161,11 @@ int fa_varlen_fwd(const fa_params* pp, void* stream) {
     normalize(p, false);
     fa::KArgs a = make_args(p, 128);
     a.seqlens_k = p.seqused_k;
+    if (p.total_q > 0 && !getenv("FA_VARLEN_GRID")) {     // flat work list (fa_common.h: decode_work_flat)
+        a.flat_blocks = p.total_q / 128 + p.batch;
+        a.pair_qblocks = 0;
+        a.n_qblocks = a.n_qblocks_total;
+    }
     rc = fa::launch_fwd(a, static_cast<hipStream_t>(stream));
     if (rc) return fail(FA_ERR_UNSUPPORTED, "no varlen forward kernel for this configuration");
     return check_hip("fa_varlen_fwd launch");
@@ -245,6 +251,11 @@ int fa_varlen_bwd(const fa_params* pp, void* stream) {
     if (p.total_q == 0) return FA_OK;
     normalize(p, false);
     fa::KArgs a = make_args(p, 128);
+    if (!getenv("FA_VARLEN_GRID")) {                      // flat work lists (fa_common.h: decode_work_flat)
+        a.flat_blocks = p.total_q / 128 + p.batch;
+        a.pair_qblocks = 0;
+        a.n_qblocks = a.n_qblocks_total;
+    }
     rc = fa::launch_bwd(a, static_cast<hipStream_t>(stream));
     if (rc == -2) return fail(FA_ERR_UNSUPPORTED, "no varlen backward kernel for this configuration");
     if (rc) return rc;

@@ -760,10 +760,17 @@ __global__ void __launch_bounds__(BWD_THREADS, D <= 64 ? FA_DKV2_OCC64 : 2) fa_b
 
     const fa_params& p = a.p;
     const int n_kblocks = (p.seqlen_k + DKV_BN - 1) / DKV_BN;
-    const bool pair = a.pair_qblocks && n_kblocks >= 2;
+    const bool pair = a.pair_qblocks && n_kblocks >= 2 && !a.flat_kblocks;
     const int n_kb_grid = pair ? (n_kblocks + 1) / 2 : n_kblocks;
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, g = lane >> 5;
     int b, hk, nb0;
-    {
+    if (a.flat_kblocks) {
+        // varlen flat work list over key blocks (fa_common.h: flat_owner), early (for causal masks: heavy) blocks first
+        const int id = blockIdx.x;
+        hk = id % p.nheads_k;
+        flat_owner(id / p.nheads_k, DKV_BN, p.batch, p.cu_seqlens_k, lane, b, nb0);
+        if (b < 0) return;
+    } else {
         const int id = blockIdx.x, xcd = id & 7, j = id >> 3;
         const int ul = j / n_kb_grid;
         nb0 = j - ul * n_kb_grid;
@@ -772,7 +779,6 @@ __global__ void __launch_bounds__(BWD_THREADS, D <= 64 ? FA_DKV2_OCC64 : 2) fa_b
         b = unit / p.nheads_k; hk = unit - b * p.nheads_k;
     }
     const SeqGeom sg = seq_geom(p, b);
-    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, g = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int group = p.nheads_q / p.nheads_k;
     const int off = sg.off;
@@ -1160,9 +1166,11 @@ __global__ void __launch_bounds__(BWD_THREADS, OCC) fa_bwd_dq_kernel(const KArgs
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const fa_params& p = a.p;
-    const WorkItem w = decode_work(blockIdx.x, p.batch, p.nheads_q, p.nheads_k, a.n_qblocks);
-    if (!w.valid) return;
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, g = lane >> 5;
+    const WorkItem w = a.flat_blocks
+        ? decode_work_flat(blockIdx.x, a.flat_blocks, DQ_BM, p.batch, p.nheads_q, p.nheads_k, p.cu_seqlens_q, lane)
+        : decode_work(blockIdx.x, p.batch, p.nheads_q, p.nheads_k, a.n_qblocks);
+    if (!w.valid) return;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const SeqGeom sg = seq_geom(p, w.b);
     const int off = sg.off;
@@ -1702,11 +1710,17 @@ static int launch_bwd_td(const KArgs& a, hipStream_t stream) {
             const bool cap_only = p.softcap > 0.f && !p.alibi_slopes;
             if (dkv2_env && (!a.has_bias || ((lin_alibi || cap_only) && !drop)) && grid > 0) {
                 const size_t smem2 = Dkv2Smem<D>::TOTAL;
+                KArgs a2 = a;                     // varlen: flat list of key blocks for this kernel
+                int grid2 = grid;
+                if (a.flat_blocks && p.cu_seqlens_k && p.total_k > 0) {
+                    a2.flat_kblocks = p.total_k / DKV_BN + p.batch;
+                    grid2 = a2.flat_kblocks * p.nheads_k;
+                }
 #define FA_LAUNCH_DKV2(BIAS, DROP)                                                                                \
                 do {                                                                                              \
                     auto kern = fa_bwd_dkdv2_kernel<T, D, BIAS, DROP>;                                            \
                     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2); \
-                    hipLaunchKernelGGL(kern, dim3(grid), dim3(BWD_THREADS), smem2, stream, a);                    \
+                    hipLaunchKernelGGL(kern, dim3(grid2), dim3(BWD_THREADS), smem2, stream, a2);                  \
                 } while (0)
                 if (a.has_bias && lin_alibi) FA_LAUNCH_DKV2(2, false);
                 else if (a.has_bias) FA_LAUNCH_DKV2(3, false);
@@ -1733,7 +1747,7 @@ static int launch_bwd_td(const KArgs& a, hipStream_t stream) {
             if (grid > 0) hipLaunchKernelGGL(kern, dim3(grid), dim3(BWD_THREADS), smem, stream, a);
         }
     } else if (g_bwd_phase_mask & 4) {
-        const int grid = work_grid(p.batch, p.nheads_q, p.nheads_k, a.n_qblocks);
+        const int grid = a.flat_blocks ? a.flat_blocks * p.nheads_q : work_grid(p.batch, p.nheads_q, p.nheads_k, a.n_qblocks);
         const size_t smem = DqSmem<D>::TOTAL;
         // D = 128: two waves per SIMD spill ~10 registers but measure 11 % faster than one wave
         constexpr int OCC = (D > 128) ? 1 : (D <= 64 ? FA_DQ_OCC64 : 2);

@@ -260,6 +260,35 @@ __device__ __forceinline__ WorkItem decode_work(int id, int batch, int nheads_q,
     w.h = w.hk * group + gq;
     return w;
 }
+// Varlen "flat" work list: instead of batch x ceil(max_seqlen / block) q-block slots (half of them empty for a
+// typical length mix, and every empty workgroup still costs a dispatch slot), the grid has
+//     F = floor(total_q / block) + batch
+// slots per head.  Sequence b owns slots [start_b, start_{b+1}) with start_b = floor(cu[b] / block) + b, which is
+// strictly increasing and leaves at least ceil(len_b / block) slots per sequence (at most one spare).  The owner of
+// slot f is found with one vector load of cu_seqlens per 64 sequences + a ballot; slots run from the last one down
+// so that the late (for causal masks: heavy) q-blocks of a sequence start first; id -> (slot, head) keeps a head on
+// one XCD when nheads_q % 8 == 0, so its K/V stay in that XCD's L2 as before.
+__device__ __forceinline__ void flat_owner(int f, int block, int batch, const int32_t* cu, int lane, int& b, int& blk) {
+    int cnt = 0;
+    for (int b0 = 0; b0 < batch; b0 += 64) {
+        const int i = b0 + lane;
+        const bool le = i < batch && (cu[i] / block + i) <= f;
+        cnt += __popcll(__ballot(le));
+    }
+    b = __builtin_amdgcn_readfirstlane(cnt) - 1;
+    const int bb = b >= 0 ? b : 0;
+    blk = f - (cu[bb] / block + bb);
+}
+__device__ __forceinline__ WorkItem decode_work_flat(int id, int flat_blocks, int block_m, int batch, int nheads_q,
+                                                     int nheads_k, const int32_t* cu_seqlens_q, int lane) {
+    WorkItem w;
+    const int f = flat_blocks - 1 - id / nheads_q;
+    w.h = id - (id / nheads_q) * nheads_q;
+    w.hk = w.h / (nheads_q / nheads_k);
+    flat_owner(f, block_m, batch, cu_seqlens_q, lane, w.b, w.qb);
+    w.valid = w.b >= 0;
+    return w;
+}
 static inline int work_grid(int batch, int nheads_q, int nheads_k, int n_qblocks) {
     const int units = batch * nheads_k;
     const int upx = (units + 7) / 8;
@@ -272,6 +301,8 @@ struct KArgs {
     int n_qblocks;         // q-blocks per (batch, head) in the GRID (halved when pairing)
     int n_qblocks_total;   // ceil(seqlen_q / block_m)
     int pair_qblocks;      // causal load balance: a workgroup owns q-blocks (i, total-1-i)
+    int flat_blocks;       // varlen flat work list: slots per head (0: batch x n_qblocks grid), see decode_work_flat
+    int flat_kblocks;      // the same over 128-key blocks (dK/dV kernel)
     int has_bias;          // alibi or softcap
     float scale_log2e;
     uint32_t drop_thr;     // uint32((1 - p) * 4294967295.0f), fp32 arithmetic (include/softmax.h:51)

@@ -61,10 +61,12 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : FA_FWD_OCC)) fa_fw
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const fa_params& p = a.p;
-    const WorkItem w = decode_work(blockIdx.x, p.batch, p.nheads_q, p.nheads_k, a.n_qblocks);
-    if (!w.valid) return;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
+    const WorkItem w = a.flat_blocks
+        ? decode_work_flat(blockIdx.x, a.flat_blocks, FWD_BM, p.batch, p.nheads_q, p.nheads_k, p.cu_seqlens_q, lane)
+        : decode_work(blockIdx.x, p.batch, p.nheads_q, p.nheads_k, a.n_qblocks);
+    if (!w.valid) return;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform
     const int l31 = lane & 31;
     const int g = lane >> 5;
@@ -576,7 +578,8 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : FA_FWD_OCC)) fa_fw
 // ---- host launcher ---------------------------------------------------------------------------
 template <typename T, int D>
 static int launch_fwd_td(const KArgs& a, bool paged, hipStream_t stream) {
-    const int grid = work_grid(a.p.batch, a.p.nheads_q, a.p.nheads_k, a.n_qblocks);   // n_qblocks = grid-level count
+    const int grid = a.flat_blocks ? a.flat_blocks * a.p.nheads_q
+                                   : work_grid(a.p.batch, a.p.nheads_q, a.p.nheads_k, a.n_qblocks);   // n_qblocks = grid-level count
     const size_t smem = FwdSmem<D>::TOTAL;
     if (grid == 0) return 0;
 #define FA_LAUNCH(BIAS, PAGED, DROP)                                                            \

@@ -142,3 +142,42 @@ def test_varlen_with_empty_sequences():
         qs, qe = int(cu_q[b]), int(cu_q[b + 1]); ks, ke = int(cu_k[b]), int(cu_k[b + 1])
         ref = flash_attn.flash_attn_func(q[qs:qe][None], k[ks:ke][None], v[ks:ke][None])
         assert torch.allclose(out[qs:qe].float(), ref[0].float(), atol=2e-3, rtol=2e-3)
+
+
+def test_varlen_flat_work_list_many_sequences(monkeypatch):
+    """More than 64 sequences (the slot owner search runs over several 64-lane chunks), zero-length ones in between,
+    GQA with nheads % 8 != 0: forward and backward against the oracle, and bit-identical to the
+    batch x max_seqlen grid (FA_VARLEN_GRID=1)."""
+    rng = np.random.default_rng(7)
+    B, Hq, Hk, D, dt = 150, 6, 2, 64, "fp16"
+    lens = rng.integers(0, 300, size=B)
+    lens[rng.integers(0, B, size=12)] = 0
+    lens[17] = 700
+    lens = [int(x) for x in lens]
+    T = sum(lens)
+    q = rand16((T, Hq, D), dt, 1).requires_grad_(True)
+    k = rand16((T, Hk, D), dt, 2).requires_grad_(True)
+    v = rand16((T, Hk, D), dt, 3).requires_grad_(True)
+    do = rand16((T, Hq, D), dt, 4)
+    cu = _cu(lens)
+    mx = max(lens)
+
+    def run():
+        out, lse, _ = _fa().flash_attn_varlen_func(q, k, v, cu, cu, mx, mx, causal=True, return_attn_probs=True)
+        return (out, lse) + tuple(torch.autograd.grad(out, (q, k, v), do))
+
+    flat = run()
+    monkeypatch.setenv("FA_VARLEN_GRID", "1")
+    grid = run()
+    monkeypatch.delenv("FA_VARLEN_GRID")
+    for a, b in zip(flat, grid):
+        assert torch.equal(a, b)
+    c = cu.cpu().numpy()
+    o_ref, lse_ref = oracle.varlen_fwd(f64(q), f64(k), f64(v), c, c, mx, mx, D ** -0.5, causal=True)
+    assert_close(f64(flat[0]), o_ref, dt, "out")
+    assert_lse_close(f64(flat[1]), lse_ref, "lse")
+    dq_r, dk_r, dv_r, _ = oracle.varlen_bwd(f64(do), f64(q), f64(k), f64(v), o_ref, lse_ref.astype(np.float64),
+                                            c, c, mx, mx, D ** -0.5, causal=True)
+    assert_close(f64(flat[2]), dq_r, dt, "dq", mult=2.0)
+    assert_close(f64(flat[3]), dk_r, dt, "dk", mult=2.0)
+    assert_close(f64(flat[4]), dv_r, dt, "dv", mult=2.0)

@@ -21,7 +21,7 @@ import flash_attn  # noqa: E402
 PEAK_TF, PEAK_GBS = 2500.0, 8000.0
 
 
-def timeit(fn, iters=10, warm=3):
+def timeit(fn, iters=10, warm=10):
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
