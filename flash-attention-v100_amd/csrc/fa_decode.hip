@@ -21,6 +21,7 @@ namespace fa {
 
 constexpr int DEC_THREADS = 256;
 constexpr int DEC_BN = 32;                     // keys per wave tile
+constexpr float DEC_RESCALE_THR = 8.0f;        // log2 units
 
 template <int D> struct DecSmem {
     static constexpr int TILE = DEC_BN * D * 2;            // one 16-bit K (or V) tile
@@ -278,18 +279,25 @@ __global__ void __launch_bounds__(DEC_THREADS, 1) fa_decode_kernel(const DecArgs
 #pragma unroll
         for (int i = 1; i < 16; ++i) mx = fmaxf(mx, s[i]);
         mx = xhalf_max(mx) * c;
-        const float m_new = fmaxf(m_run, mx);
-        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-        const float alpha = fast_exp2(m_run - m_use);
-        m_run = m_new;
+        // deferred rescale (as in fa_fwd_kernel): the running max is only raised - and the accumulators only
+        // multiplied - when some row of the wave exceeds it by more than 2^DEC_RESCALE_THR
+        // (NaN-safe: -inf - -inf compares false -> takes the rescale path)
+        if (!__all(mx - m_run <= DEC_RESCALE_THR)) {
+            const float m_new = fmaxf(m_run, mx);
+            const float m_nu = (m_new == -INFINITY) ? 0.f : m_new;
+            const float alpha = fast_exp2(m_run - m_nu);
+            m_run = m_new;
+            l_run *= alpha;
+#pragma unroll
+            for (int d = 0; d < DBLKS; ++d)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) oacc[d][i] *= alpha;
+        }
+        const float m_use = (m_run == -INFINITY) ? 0.f : m_run;
         float psum = 0.f;
 #pragma unroll
         for (int i = 0; i < 16; ++i) { s[i] = fast_exp2(fmaf(s[i], c, -m_use)); psum += s[i]; }
-        l_run = fmaf(l_run, alpha, psum);
-#pragma unroll
-        for (int d = 0; d < DBLKS; ++d)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) oacc[d][i] *= alpha;
+        l_run += psum;
 #pragma unroll
         for (int t2 = 0; t2 < 2; ++t2) {
             u32x4 pf;
