@@ -13,7 +13,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 OUT_DIR = os.path.join(HERE, "flash_attn_mi355")
 LIB = os.path.join(OUT_DIR, "libfa_mi355.so")
-SOURCES = ["fa_api.hip", "fa_fwd.hip", "fa_bwd.hip", "fa_kvcache.hip", "fa_decode.hip"]
+SOURCES = ["fa_api.hip", "fa_fwd.hip", "fa_bwd.hip", "fa_kvcache.hip", "fa_decode.hip", "fa_rows.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"),
          "-I" + CSRC, "-Wno-unused-value"]
 

@@ -15,6 +15,10 @@
 
 namespace fa {
 int launch_fwd(const KArgs& a, hipStream_t stream);
+int launch_gather_rows(const void* src, const int64_t* idx, void* dst, int64_t n_idx, int64_t row_bytes,
+                       int64_t src_stride, int64_t n_src_rows, hipStream_t stream);
+int launch_scatter_rows(const void* src, const int64_t* idx, void* dst, int64_t n_idx, int64_t n_dst_rows,
+                        int64_t row_bytes, int sorted_unique, hipStream_t stream);
 int launch_bwd(const KArgs& a, hipStream_t stream);
 size_t bwd_workspace_bytes(const fa_params& p);
 int launch_kvcache_append(const KArgs& a, hipStream_t stream);
@@ -260,6 +264,30 @@ int fa_varlen_bwd(const fa_params* pp, void* stream) {
     if (rc == -2) return fail(FA_ERR_UNSUPPORTED, "no varlen backward kernel for this configuration");
     if (rc) return rc;
     return check_hip("fa_varlen_bwd launch");
+}
+
+int fa_gather_rows(const void* src, const int64_t* indices, void* dst, int64_t n_idx, int64_t row_bytes,
+                   int64_t src_row_stride_bytes, int64_t n_src_rows, void* stream) {
+    FA_CHECK(n_idx >= 0 && row_bytes >= 0 && n_src_rows >= 0, "sizes must be non-negative");
+    if (n_idx == 0 || row_bytes == 0) return FA_OK;
+    FA_CHECK(src && indices && dst, "src, indices and dst must not be NULL");
+    FA_CHECK(row_bytes % 16 == 0 && src_row_stride_bytes % 16 == 0 && src_row_stride_bytes >= row_bytes,
+             "row_bytes and src_row_stride_bytes must be multiples of 16 (stride >= row)");
+    FA_CHECK(((uintptr_t)src % 16 == 0) && ((uintptr_t)dst % 16 == 0), "src and dst must be 16-byte aligned");
+    fa::launch_gather_rows(src, indices, dst, n_idx, row_bytes, src_row_stride_bytes, n_src_rows, static_cast<hipStream_t>(stream));
+    return check_hip("fa_gather_rows launch");
+}
+
+int fa_scatter_rows(const void* src, const int64_t* indices, void* dst, int64_t n_idx, int64_t n_dst_rows,
+                    int64_t row_bytes, int sorted_unique, void* stream) {
+    FA_CHECK(n_idx >= 0 && row_bytes >= 0 && n_dst_rows >= 0, "sizes must be non-negative");
+    if (n_dst_rows == 0 || row_bytes == 0) return FA_OK;
+    FA_CHECK(dst && (n_idx == 0 || (src && indices)), "src, indices and dst must not be NULL");
+    FA_CHECK(row_bytes % 16 == 0, "row_bytes must be a multiple of 16");
+    FA_CHECK(((uintptr_t)src % 16 == 0) && ((uintptr_t)dst % 16 == 0), "src and dst must be 16-byte aligned");
+    if (fa::launch_scatter_rows(src, indices, dst, n_idx, n_dst_rows, row_bytes, sorted_unique, static_cast<hipStream_t>(stream)))
+        return fail(FA_ERR_INVALID_ARGUMENT, "hipMemsetAsync failed");
+    return check_hip("fa_scatter_rows launch");
 }
 
 }  // extern "C"

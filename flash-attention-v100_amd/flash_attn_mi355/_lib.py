@@ -55,7 +55,8 @@ class FaParams(ctypes.Structure):
 
 EXPORTS = ["fa_debug_set_bwd_phases", "fa_abi_version", "fa_params_size", "fa_last_error", "fa_build_info",
            "fa_fwd_workspace_bytes", "fa_bwd_workspace_bytes", "fa_fwd_kvcache_workspace_bytes",
-           "fa_fwd", "fa_bwd", "fa_varlen_fwd", "fa_varlen_bwd", "fa_fwd_kvcache"]
+           "fa_fwd", "fa_bwd", "fa_varlen_fwd", "fa_varlen_bwd", "fa_fwd_kvcache",
+           "fa_gather_rows", "fa_scatter_rows"]
 
 
 def _load():
@@ -80,6 +81,11 @@ def _load():
         fn = getattr(lib, name)
         fn.restype = ctypes.c_int
         fn.argtypes = [ctypes.POINTER(FaParams), ctypes.c_void_p]
+    i64 = ctypes.c_int64
+    lib.fa_gather_rows.restype = ctypes.c_int
+    lib.fa_gather_rows.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, i64, i64, i64, i64, ctypes.c_void_p]
+    lib.fa_scatter_rows.restype = ctypes.c_int
+    lib.fa_scatter_rows.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, i64, i64, i64, ctypes.c_int, ctypes.c_void_p]
     if lib.fa_abi_version() != FA_ABI_VERSION:
         raise ImportError(f"libfa_mi355.so ABI {lib.fa_abi_version()} != binding {FA_ABI_VERSION}")
     if lib.fa_params_size() != ctypes.sizeof(FaParams):
@@ -98,3 +104,10 @@ def call(name, params, stream):
     if rc != 0:
         msg = lib.fa_last_error().decode(errors="replace")
         raise RuntimeError(f"{name} failed ({rc}): {msg}")
+
+
+def call_rows(name, *args):
+    """fa_gather_rows / fa_scatter_rows (plain-argument entry points)."""
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise RuntimeError(f"{name} failed ({rc}): {lib.fa_last_error().decode(errors='replace')}")

@@ -197,6 +197,25 @@ int fa_varlen_bwd(const fa_params* p, void* stream);
  */
 int fa_fwd_kvcache(const fa_params* p, void* stream);
 
+/*
+ * Row gather / scatter for the padding helpers on both sides of the varlen path (HBM-bound byte movement).
+ * Rows are `row_bytes` bytes (a multiple of 16, 16-byte aligned base pointers), indices are int64 on the device
+ * (negative values count from the end, as in torch); no bounds checks beyond that (same contract as the reference's
+ * torch.gather / index assignment, flash_attn/bert_padding.py:9-60).
+ *
+ * fa_gather_rows : dst[i, :] = src[indices[i], :] for i < n_idx.  `src_row_stride_bytes` >= row_bytes lets the
+ *   source be a row-strided view.  Replaces `index_first_axis` forward / `index_put_first_axis` backward
+ *   (bert_padding.py:9-34, :52-60) as used by `unpad_input` (:79-104).
+ * fa_scatter_rows: dst[:] = 0; dst[indices[i], :] = src[i, :].  With `sorted_unique` != 0 (indices ascending
+ *   without repeats - what unpad_input produces) it is one pass over dst; otherwise memset + scatter (repeated
+ *   indices: one of the rows wins, as in the reference).  Replaces `index_put_first_axis` forward /
+ *   `index_first_axis` backward (bert_padding.py:36-50, :22-34) as used by `pad_input` (:135-146).
+ */
+int fa_gather_rows(const void* src, const int64_t* indices, void* dst, int64_t n_idx, int64_t row_bytes,
+                   int64_t src_row_stride_bytes, int64_t n_src_rows, void* stream);
+int fa_scatter_rows(const void* src, const int64_t* indices, void* dst, int64_t n_idx, int64_t n_dst_rows,
+                    int64_t row_bytes, int sorted_unique, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
