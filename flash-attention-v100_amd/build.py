@@ -13,7 +13,8 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 OUT_DIR = os.path.join(HERE, "flash_attn_mi355")
 LIB = os.path.join(OUT_DIR, "libfa_mi355.so")
-SOURCES = ["fa_api.hip", "fa_fwd.hip", "fa_bwd.hip", "fa_kvcache.hip", "fa_decode.hip", "fa_rows.hip"]
+SOURCES = ["fa_api.hip", "fa_fwd.hip", "fa_fwd_asm.hip", "fa_bwd.hip", "fa_kvcache.hip", "fa_decode.hip", "fa_rows.hip"]
+GENERATED = [("gen_fwd_asm.py", "fa_fwd_asm_gen.h")]      # (generator, header): hand-scheduled asm bodies
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"),
          "-I" + CSRC, "-Wno-unused-value"]
 
@@ -34,15 +35,26 @@ def _digest(paths):
     return h.hexdigest()
 
 
+def _generate():
+    """Re-run a kernel-body generator when its header is missing or older than the script."""
+    for gen, hdr in GENERATED:
+        g, h = os.path.join(CSRC, gen), os.path.join(CSRC, hdr)
+        if not os.path.exists(h) or os.path.getmtime(h) < os.path.getmtime(g):
+            txt = subprocess.run([sys.executable, g], check=True, stdout=subprocess.PIPE).stdout
+            with open(h, "wb") as f:
+                f.write(txt)
+
+
 def build(force=False, verbose=False, defines=(), out=None):
     """Compile every HIP source for gfx950 and link libfa_mi355.so. Returns the path.
     `defines` / `out` build an experiment variant next to the product library (A/B runs
     select it with FA_MI355_LIB=<path>)."""
+    _generate()
     if defines or out:
         return _build_variant(list(defines), out, verbose)
     bdir = os.path.join(CSRC, "build")
     os.makedirs(bdir, exist_ok=True)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h", ".py"))]
     deps.append(os.path.join(ROOT, "include", "fa_mi355.h"))
     stamp = os.path.join(bdir, "stamp.txt")
     dig = _digest(deps)

@@ -1,0 +1,727 @@
+#!/usr/bin/env python3
+"""Generator for the hand-scheduled gfx950 forward inner loop (fa_fwd_asm.hip).
+
+Emits fa_fwd_asm_gen.h: one inline-asm body per io type (bf16 / fp16) for
+    D = 128, no bias, no dropout, contiguous K/V  (BASELINE config 2's path)
+replacing the hot loop of kernel/fused_mha_forward.cu:148-209 of the reference.
+
+Structure (one wave per SIMD, 512 registers, 4 waves x 64 query rows = 256-row workgroup):
+  * a wave owns two 32-row q-blocks (qb0, qb1) that run HALF AN ITERATION OUT OF PHASE:
+        phase 1 of iteration j : MFMA  QK1(j+1), PV1(j)     VALU  softmax0(j+1)
+        phase 2 of iteration j : MFMA  QK0(j+2), PV0(j+1)   VALU  softmax1(j+1)
+    so inside a phase the VALU stream (one q-block's whole softmax) is independent of the
+    32 MFMAs issued beside it, and a q-block's O accumulators are idle when its (rare) rescale runs;
+  * K fragments (A operand of S^T = K Q^T) live in a[192:255], Q fragments in a[128:191], O^T in
+    a[0:127]; a K / V fragment register is reloaded from LDS right after its last use by q-block 1
+    and is consumed by q-block 0 half an iteration later;
+  * K/V tiles arrive by LDS-DMA into a ring of three 32 KiB stages (issued two iterations ahead,
+    counted vmcnt, one barrier per tile);
+  * every instruction is placed by this script; a checker pass inserts the s_nop / s_waitcnt the
+    hardware needs (MFMA result hazards, trans forwarding, LDS return order) and reports them.
+
+Run:  python gen_fwd_asm.py  > fa_fwd_asm_gen.h        (the header is committed; build.py re-runs this
+script when it is newer than the header).
+"""
+import sys
+
+# ----------------------------------------------------------------------------- register map
+# VGPR (v0-v15 are left to the compiler)
+V_QOFF = (16, 17)        # in: Q voffset of qb0 / qb1 (prologue only)
+V_OOFF = (18, 19)        # in: O voffset
+V_LSEOFF = (20, 21)      # in: LSE voffset
+V_DMAK, V_DMAV = 22, 23  # in: LDS-DMA source voffsets
+V_KBASE = 24             # in: 8 regs, K fragment read address (stage 0)
+V_VBASE = 32             # in: V fragment read address (stage 0, V region)
+V_LOG = (33, 35)         # in: lo - 4g of the lane's row (qb0, qb1); 0x3fffffff for an empty row
+V_WIDTH = (34, 36)       # in: hi - lo (0 for an empty row)
+V_KADDR = 37             # 8 regs, current K read addresses
+V_VADDR = 45
+V_MRUN = (46, 49)
+V_NEGM = (47, 50)
+V_L = (48, 51)
+V_T = 52                 # temps v52..v79
+NT = 28
+V_S = (80, 112)          # S^T accumulators of qb0 / qb1: 32 regs each (kb0: 16, kb1: 16)
+V_P = (144, 160)         # packed P^T: 16 regs each (4 k-steps x 4)
+V_VF = 176               # V^T fragments: [ks][dblk] x 4 regs = 64
+# AGPR
+A_O = (0, 64)            # O^T accumulators per q-block: [dblk] x 16
+A_Q = (128, 160)         # Q fragments per q-block: [ks] x 4
+A_KF = 192               # K fragments [kb][ks] x 4
+
+# SGPR
+S_QRS, S_KRS, S_VRS, S_ORS, S_LRS = 16, 20, 24, 28, 32
+S_KTILE, S_VTILE, S_K16, S_V16 = 36, 37, 38, 39
+S_C = 40                 # softmax_scale * log2(e)
+S_JIN, S_NMAX, S_WLO, S_WHI = 41, 42, 43, 44
+S_HIMIN = (45, 47)
+S_LOMAX = (46, 48)
+S_W1024 = 49
+# asm-owned
+S_R0, S_R1, S_R2 = 50, 51, 52
+S_OOB = 53
+S_KSOFF, S_VSOFF = 54, 55
+S_TMP = 56               # s56..s59 temps
+S_N0 = 60                # tile start key for the mask routine
+S_SUB = 62               # s[62:63] call target, s[64:65] return address
+S_RET = 64
+S_MASKFN = (66, 68)      # s[66:67] mask0, s[68:69] mask1
+S_RESCFN = (70, 72)      # s[70:71] rescale0, s[72:73] rescale1
+S_J = 74                 # iteration counter (copy of the input s41)
+S_LAST = 74
+
+LDS_STAGE = 16384        # one K (or V) tile
+LDS_VREGION = 3 * LDS_STAGE
+
+
+def vr(b, n=1):
+    return f"v[{b}:{b + n - 1}]" if n > 1 else f"v{b}"
+
+
+def ar(b, n=1):
+    return f"a[{b}:{b + n - 1}]" if n > 1 else f"a{b}"
+
+
+def sr(b, n=1):
+    return f"s[{b}:{b + n - 1}]" if n > 1 else f"s{b}"
+
+
+def rl(p, b, n=1):
+    return [f"{p}{b + i}" for i in range(n)]
+
+
+class Ins:
+    __slots__ = ("txt", "kind", "rd", "wr", "cexact", "w", "aux")
+
+    def __init__(self, txt, kind, rd=(), wr=(), cexact=False, w=1.0):
+        self.txt, self.kind, self.rd, self.wr, self.cexact, self.w = txt, kind, list(rd), list(wr), cexact, w
+        self.aux = None
+
+
+class Gen:
+    def __init__(self, dtype):
+        self.dtype = dtype
+        self.mf = "v_mfma_f32_32x32x16_bf16" if dtype == "bf16" else "v_mfma_f32_32x32x16_f16"
+        self.cvt = "v_cvt_pk_bf16_f32" if dtype == "bf16" else "v_cvt_pk_f16_f32"
+        self.out = []          # final text lines
+        self.stats = {"nop_states": 0, "lgkm_waits": 0}
+        self.reset_state()
+
+    # ------------------------------------------------------------------ hazard / wait tracking
+    def reset_state(self, mfma_age=8):
+        # conservative variant-entry state: every S / O register may have been written by an MFMA
+        # `mfma_age` wait states ago; nothing in flight on the LDS queue.
+        self.now = 0
+        self.last = {}
+        for qb in (0, 1):
+            for r in rl("v", V_S[qb], 32) + rl("a", A_O[qb], 64):
+                self.last[r] = (-mfma_age, "mfma", None)
+        self.lds_q = []        # outstanding LDS reads: list of sets of written regs, in issue order
+        self.srcc_rd = {}      # reg -> state index of the last MFMA reading it as srcC
+
+    def _need(self, ins):
+        need = 0
+        for r in ins.rd:
+            lw = self.last.get(r)
+            if lw is None:
+                continue
+            t, k, tup = lw
+            gap = self.now - t - 1          # wait states already between producer and consumer
+            req = 0
+            if k == "mfma":
+                if ins.kind == "mfma" and ins.cexact and r in ins.wr:
+                    req = 0                 # same accumulator back to back
+                else:
+                    req = 12
+            elif k in ("valu", "trans"):
+                if ins.kind == "mfma":
+                    req = 2
+                elif ins.kind == "swap":
+                    req = 2
+                elif k == "trans" and ins.kind in ("valu", "trans", "swap", "vmem", "dma", "lds"):
+                    req = 1
+                elif ins.kind in ("vmem", "dma") and r.startswith("s"):
+                    req = 5
+                elif ins.kind in ("vmem",) and r.startswith("v"):
+                    req = 0
+            elif k == "salu":
+                if r == "m0" and ins.kind == "dma":
+                    req = 1
+            elif k == "store4":
+                pass
+            need = max(need, req - gap)
+        for r in ins.wr:
+            lw = self.last.get(r)
+            if lw is not None:
+                t, k, tup = lw
+                gap = self.now - t - 1
+                if k == "mfma" and ins.kind != "mfma":
+                    need = max(need, 12 - gap)          # WAW behind an MFMA
+                if k == "store4":
+                    need = max(need, 2 - gap)
+            if ins.kind != "mfma" and r in self.srcc_rd:
+                need = max(need, 16 - (self.now - self.srcc_rd[r] - 1))   # WAR on an MFMA's srcC
+        return max(need, 0)
+
+    def emit(self, ins):
+        if ins.kind == "label" or ins.kind == "raw":
+            self.out.append(ins.txt)
+            return
+        # LDS return order: wait for the youngest outstanding read that produces one of our operands
+        touched = set(ins.rd) | set(ins.wr)
+        idx = -1
+        for i, regs in enumerate(self.lds_q):
+            if regs & touched:
+                idx = i
+        if idx >= 0:
+            n_after = len(self.lds_q) - 1 - idx
+            if n_after < 15:
+                self.out.append(f"s_waitcnt lgkmcnt({n_after})")
+                self.now += 1
+                self.stats["lgkm_waits"] += 1
+            self.lds_q = self.lds_q[idx + 1:]
+        n = self._need(ins)
+        while n > 0:
+            k = min(n, 8)
+            self.out.append(f"s_nop {k - 1}")
+            self.now += k
+            self.stats["nop_states"] += k
+            n -= k
+        self.out.append(ins.txt)
+        kind = {"swap": "valu", "dma": "vmem"}.get(ins.kind, ins.kind)
+        for r in ins.wr:
+            self.last[r] = (self.now, kind, None)
+        if kind == "mfma":
+            for r in ins.rd:
+                if ins.cexact and r in ins.wr:
+                    self.srcc_rd[r] = self.now
+        if kind == "lds":
+            self.lds_q.append(set(ins.wr))
+            if len(self.lds_q) > 15:            # the 4-bit counter stalls issue at 15 outstanding: older ones have returned
+                self.lds_q = self.lds_q[-15:]
+        self.now += 1
+
+    def raw(self, txt):
+        self.out.append(txt)
+        self.now += 1
+
+    def drain_lds(self):
+        if self.lds_q:
+            self.out.append("s_waitcnt lgkmcnt(0)")
+            self.now += 1
+            self.lds_q = []
+
+    # ------------------------------------------------------------------ instruction builders
+    def mfma(self, dpre, dbase, apre, abase, bpre, bbase, first):
+        d = f"{dpre}[{dbase}:{dbase + 15}]"
+        a = f"{apre}[{abase}:{abase + 3}]"
+        b = f"{bpre}[{bbase}:{bbase + 3}]"
+        c = "0" if first else d
+        rd = rl(apre, abase, 4) + rl(bpre, bbase, 4) + ([] if first else rl(dpre, dbase, 16))
+        return Ins(f"{self.mf} {d}, {a}, {b}, {c}", "mfma", rd, rl(dpre, dbase, 16), cexact=not first)
+
+    def qk_mfmas(self, qb):
+        """S^T[kb] (+)= K[kb][ks] Q_qb[ks]^T, ks-major so that consecutive MFMAs alternate accumulators."""
+        out = []
+        for ks in range(8):
+            for kb in range(2):
+                out.append(self.mfma("v", V_S[qb] + 16 * kb, "a", A_KF + (kb * 8 + ks) * 4,
+                                     "a", A_Q[qb] + 4 * ks, ks == 0))
+        return out
+
+    def pv_mfmas(self, qb):
+        """O^T[dblk] += V^T[dblk][ks] P_qb[ks]^T."""
+        out = []
+        for ks in range(4):
+            for d in range(4):
+                out.append(self.mfma("a", A_O[qb] + 16 * d, "v", V_VF + (ks * 4 + d) * 4,
+                                     "v", V_P[qb] + 4 * ks, False))
+        return out
+
+    def k_read(self, kb, ks):
+        b = A_KF + (kb * 8 + ks) * 4
+        return Ins(f"ds_read_b128 {ar(b, 4)}, v{V_KADDR + ks} offset:{kb * 8192}", "lds",
+                   [f"v{V_KADDR + ks}"], rl("a", b, 4))
+
+    def v_reads(self, d, ks):
+        b = V_VF + (ks * 4 + d) * 4
+        off = ks * 4096 + d * 256
+        return [Ins(f"ds_read_b64_tr_b16 {vr(b, 2)}, v{V_VADDR} offset:{off}", "lds", [f"v{V_VADDR}"], rl("v", b, 2)),
+                Ins(f"ds_read_b64_tr_b16 {vr(b + 2, 2)}, v{V_VADDR} offset:{off + 2048}", "lds", [f"v{V_VADDR}"],
+                    rl("v", b + 2, 2))]
+
+    def valu(self, txt, rd, wr, kind="valu", w=1.0):
+        return Ins(txt, kind, rd, wr, w=w)
+
+    def softmax(self, qb):
+        """max -> (rare) rescale call -> exp2 / row sum / pack for one q-block's 64-key tile."""
+        S = V_S[qb]
+        P = V_P[qb]
+        T = V_T
+        out = []
+        s = [f"v{S + i}" for i in range(32)]
+        # ---- row maximum over the lane's 32 keys: max3 tree
+        vals = list(s)
+        tn = 0
+        while len(vals) > 1:
+            nxt = []
+            i = 0
+            while i + 2 < len(vals):
+                t = f"v{T + tn}"
+                tn += 1
+                out.append(self.valu(f"v_max3_f32 {t}, {vals[i]}, {vals[i + 1]}, {vals[i + 2]}",
+                                     [vals[i], vals[i + 1], vals[i + 2]], [t]))
+                nxt.append(t)
+                i += 3
+            rest = vals[i:]
+            if len(rest) == 2 and not nxt:
+                t = f"v{T + tn}"
+                tn += 1
+                out.append(self.valu(f"v_max_f32 {t}, {rest[0]}, {rest[1]}", rest, [t]))
+                nxt.append(t)
+                rest = []
+            vals = nxt + rest
+        mx = vals[0]
+        assert tn <= 20
+        ta, td, tl = f"v{T + 20}", f"v{T + 21}", f"v{T + 22}"
+        out.append(self.valu(f"v_mov_b32 {ta}, {mx}", [mx], [ta]))
+        out.append(Ins(f"v_permlane32_swap_b32 {ta}, {mx}", "swap", [ta, mx], [ta, mx]))
+        mxr = f"v{T + 23 + qb}"                       # raw (unscaled) row max, read by the rescale routine
+        out.append(self.valu(f"v_max_f32 {mxr}, {ta}, {mx}", [ta, mx], [mxr]))
+        out.append(self.valu(f"v_fma_f32 {td}, {mxr}, s{S_C}, -v{V_MRUN[qb]}", [mxr, f"v{V_MRUN[qb]}"], [td]))
+        out.append(self.valu(f"v_cmp_nge_f32 vcc, 0x41000000, {td}", [td], ["vcc"]))
+        call = Ins(f"s_cbranch_vccz L_norescale_{self.uid()}_%=", "call_rescale", ["vcc"], [], w=1.0)
+        call.aux = qb
+        out.append(call)
+        # ---- exp2(s c - m), row sum (two chains), pack
+        negm = f"v{V_NEGM[qb]}"
+        l0, l1 = f"v{V_L[qb]}", tl
+        first_l1 = True
+        step = 2
+        for r0 in range(0, 32, step):
+            rs = list(range(r0, r0 + step))
+            for r in rs:
+                out.append(self.valu(f"v_fma_f32 {s[r]}, {s[r]}, s{S_C}, {negm}", [s[r], negm], [s[r]]))
+            for r in rs:
+                out.append(self.valu(f"v_exp_f32 {s[r]}, {s[r]}", [s[r]], [s[r]], kind="trans", w=1.6))
+            for r in rs:
+                if r % 2 == 0:
+                    out.append(self.valu(f"v_add_f32 {l0}, {l0}, {s[r]}", [l0, s[r]], [l0]))
+                elif first_l1:
+                    out.append(self.valu(f"v_mov_b32 {l1}, {s[r]}", [s[r]], [l1]))
+                    first_l1 = False
+                else:
+                    out.append(self.valu(f"v_add_f32 {l1}, {l1}, {s[r]}", [l1, s[r]], [l1]))
+            # pack completed pairs: P[ks][e] <- (s[8 ks' + 2e], s[.. + 1]) in tile register order
+            for r in rs:
+                if r % 2 == 1:
+                    kb, rr = r // 16, r % 16
+                    ks = 2 * kb + rr // 8
+                    e = (rr % 8) // 2
+                    dst = f"v{P + 4 * ks + e}"
+                    out.append(self.valu(f"{self.cvt} {dst}, {s[r - 1]}, {s[r]}", [s[r - 1], s[r]], [dst]))
+        out.append(self.valu(f"v_add_f32 {l0}, {l0}, {l1}", [l0, l1], [l0]))
+        return out
+
+    _uid = 0
+
+    def uid(self):
+        Gen._uid += 1
+        return Gen._uid
+
+    # ------------------------------------------------------------------ DMA + bookkeeping stream
+    def misc_stream(self):
+        """LDS-DMA of K(j+4) -> slot R0 and V(j+3) -> slot R2, address updates for the next iteration, slot rotation.
+        Returned as groups: (list of Ins, tag)."""
+        g = []
+        t0 = S_TMP
+        offs = []
+        offs.append(Ins(f"s_add_u32 s{t0}, s{S_J}, 4", "salu", [f"s{S_J}"], [f"s{t0}", "scc"], w=0.5))
+        offs.append(Ins(f"s_mul_i32 s{S_KSOFF}, s{t0}, s{S_KTILE}", "salu", [f"s{t0}"], [f"s{S_KSOFF}"], w=0.5))
+        offs.append(Ins(f"s_cmp_lt_i32 s{t0}, s{S_NMAX}", "salu", [f"s{t0}"], ["scc"], w=0.5))
+        offs.append(Ins(f"s_cselect_b32 s{S_KSOFF}, s{S_KSOFF}, s{S_OOB}", "salu", ["scc", f"s{S_KSOFF}"], [f"s{S_KSOFF}"], w=0.5))
+        offs.append(Ins(f"s_add_u32 s{t0}, s{S_J}, 3", "salu", [f"s{S_J}"], [f"s{t0}", "scc"], w=0.5))
+        offs.append(Ins(f"s_mul_i32 s{S_VSOFF}, s{t0}, s{S_VTILE}", "salu", [f"s{t0}"], [f"s{S_VSOFF}"], w=0.5))
+        offs.append(Ins(f"s_cmp_lt_i32 s{t0}, s{S_NMAX}", "salu", [f"s{t0}"], ["scc"], w=0.5))
+        offs.append(Ins(f"s_cselect_b32 s{S_VSOFF}, s{S_VSOFF}, s{S_OOB}", "salu", ["scc", f"s{S_VSOFF}"], [f"s{S_VSOFF}"], w=0.5))
+        offs.append(Ins(f"s_add_u32 s{t0 + 1}, s{S_R0}, s{S_W1024}", "salu", [], [f"s{t0 + 1}", "scc"], w=0.5))
+        offs.append(Ins(f"s_add_u32 s{t0 + 2}, s{S_R2}, s{S_W1024}", "salu", [], [f"s{t0 + 2}", "scc"], w=0.5))
+        g.append((offs, "offs"))
+        for jj in range(4):
+            p = [Ins(f"s_add_u32 m0, s{t0 + 1}, {4096 * jj}", "salu", [f"s{t0 + 1}"], ["m0", "scc"], w=0.5),
+                 Ins(f"buffer_load_dwordx4 v{V_DMAK}, {sr(S_KRS, 4)}, s{S_KSOFF} offen lds", "dma",
+                     ["m0", f"v{V_DMAK}", f"s{S_KSOFF}"], [], w=4.0),
+                 Ins(f"s_add_u32 s{S_KSOFF}, s{S_KSOFF}, s{S_K16}", "salu", [f"s{S_KSOFF}"], [f"s{S_KSOFF}", "scc"], w=0.5)]
+            g.append((p, "dma"))
+        for jj in range(4):
+            p = [Ins(f"s_add_u32 m0, s{t0 + 2}, {LDS_VREGION + 4096 * jj}", "salu", [f"s{t0 + 2}"], ["m0", "scc"], w=0.5),
+                 Ins(f"buffer_load_dwordx4 v{V_DMAV}, {sr(S_VRS, 4)}, s{S_VSOFF} offen lds", "dma",
+                     ["m0", f"v{V_DMAV}", f"s{S_VSOFF}"], [], w=4.0),
+                 Ins(f"s_add_u32 s{S_VSOFF}, s{S_VSOFF}, s{S_V16}", "salu", [f"s{S_VSOFF}"], [f"s{S_VSOFF}", "scc"], w=0.5)]
+            g.append((p, "dma"))
+        return g
+
+    def addr_update(self):
+        """Read addresses of the NEXT iteration: K read slot R1' = R2, V read slot R0' = R1; then rotate."""
+        ka = [Ins(f"v_add_u32 v{V_KADDR + i}, s{S_R2}, v{V_KBASE + i}", "valu", [f"v{V_KBASE + i}"], [f"v{V_KADDR + i}"])
+              for i in range(8)]
+        va = [Ins(f"v_add_u32 v{V_VADDR}, s{S_R1}, v{V_VBASE}", "valu", [f"v{V_VBASE}"], [f"v{V_VADDR}"])]
+        t = S_TMP + 3
+        rot = [Ins(f"s_mov_b32 s{t}, s{S_R0}", "salu", [], [f"s{t}"], w=0.5),
+               Ins(f"s_mov_b32 s{S_R0}, s{S_R1}", "salu", [], [f"s{S_R0}"], w=0.5),
+               Ins(f"s_mov_b32 s{S_R1}, s{S_R2}", "salu", [], [f"s{S_R1}"], w=0.5),
+               Ins(f"s_mov_b32 s{S_R2}, s{t}", "salu", [f"s{t}"], [f"s{S_R2}"], w=0.5)]
+        return ka, va, rot
+
+    # ------------------------------------------------------------------ one iteration
+    def mask_check(self, qb):
+        """SALU: does tile (j+1) need masking for this q-block?  -> call the mask routine."""
+        t = S_TMP
+        u = self.uid()
+        lines = [
+            f"s_add_u32 s{t}, s{S_J}, 1",
+            f"s_lshl_b32 s{S_N0}, s{t}, 6",
+            f"s_add_u32 s{t}, s{S_N0}, 63",
+            f"s_cmp_gt_i32 s{t}, s{S_HIMIN[qb]}",
+            f"s_cbranch_scc1 L_domask_{u}_%=",
+            f"s_cmp_lt_i32 s{S_N0}, s{S_LOMAX[qb]}",
+            f"s_cbranch_scc0 L_nomask_{u}_%=",
+            f"L_domask_{u}_%=:",
+            f"s_swappc_b64 {sr(S_RET, 2)}, {sr(S_MASKFN[qb], 2)}",
+            f"L_nomask_{u}_%=:",
+        ]
+        return lines
+
+    def gen_iteration(self, a0, a1, a2, cfg):
+        """a0/a1/a2: tiles j, j+1, j+2 are active for this wave."""
+        self.reset_state()
+        # ---- streams
+        mf1 = (self.qk_mfmas(1) if a1 else []) + (self.pv_mfmas(1) if a0 else [])
+        mf2 = (self.qk_mfmas(0) if a2 else []) + (self.pv_mfmas(0) if a1 else [])
+        n1_qk = 16 if a1 else 0
+        n2_qk = 16 if a2 else 0
+        # LDS reads: (ready = global MFMA index after which the register is free, deadline = global index of the
+        # first MFMA that consumes it, Ins)
+        lds = []
+        nm1 = len(mf1)
+        if a2:
+            for ks in range(8):
+                for kb in range(2):
+                    p = ks * 2 + kb
+                    ready = p if a1 else -1          # after QK1 MFMA p of phase 1
+                    lds.append([ready, nm1 + p, self.k_read(kb, ks)])
+        if a1:
+            for ks in range(4):
+                for d in range(4):
+                    q = ks * 4 + d
+                    ready = (n1_qk + q) if a0 else -1
+                    for ins in self.v_reads(d, ks):
+                        lds.append([ready, nm1 + n2_qk + q, ins])
+        lds.sort(key=lambda x: (x[1], x[0]))
+        val1 = self.softmax(0) if a1 else []
+        val2 = self.softmax(1) if a1 else []
+        misc = self.misc_stream()
+        ka, va, rot = self.addr_update()
+
+        # ---- phase 1
+        if a1:
+            for l in self.mask_check(0):
+                self.raw(l)
+        self._phase(mf1, val1, lds, 0, cfg, phase=1, misc=misc, extra=[])
+        # ---- phase 2
+        if a1:
+            for l in self.mask_check(1):
+                self.raw(l)
+        base = len(mf1)
+        self._phase(mf2, val2, lds, base, cfg, phase=2, misc=misc, extra=ka + va)
+        assert not lds, "unissued LDS reads"
+        for grp, _ in misc:
+            for ins in grp:
+                self.emit(ins)
+        misc.clear()
+        for ins in rot:
+            self.emit(ins)
+        self.drain_lds()
+
+    def _emit_valu(self, ins):
+        if ins.kind == "call_rescale":
+            qb = ins.aux
+            lab = ins.txt.split()[1]
+            self.emit(Ins(ins.txt, "salu", ["vcc"], []))
+            self.raw(f"s_swappc_b64 {sr(S_RET, 2)}, {sr(S_RESCFN[qb], 2)}")
+            self.out.append(f"{lab}:")
+        else:
+            self.emit(ins)
+
+    def _phase(self, mfs, valu, lds, gbase, cfg, phase, misc, extra):
+        """Interleave: after each MFMA a budget of filler weight is spent on (1) LDS reads whose register
+        is free, (2) DMA / bookkeeping groups at the configured gaps, (3) the VALU stream."""
+        valu = list(valu) + list(extra)
+        M = len(mfs)
+        lead = cfg.get("lds_lead", 3)
+        if M == 0:
+            for it in [x for x in lds if x[0] < gbase]:
+                self.emit(it[2])
+                lds.remove(it)
+            for ins in valu:
+                self._emit_valu(ins)
+            return
+        dma_gaps = cfg["dma_gaps"].get(phase, [])
+        lds_per_gap = cfg.get("lds_per_gap", 1)
+        vi = 0
+        nv = len(valu)
+        for k, m in enumerate(mfs):
+            g = gbase + k
+            assert all(x[1] > g for x in lds), "an LDS read is scheduled after its consumer"
+            self.emit(m)
+            # (1) LDS reads whose register is free (ready <= g), earliest deadline first; the count is the
+            # rate that still meets every deadline `lead` gaps early, at least lds_per_gap
+            rdy = [x for x in lds if x[0] <= g]
+            need = 0
+            for i, x in enumerate(sorted(lds, key=lambda x: x[1])):
+                slack = x[1] - lead - g              # gaps (incl. this one) left to issue reads 0..i
+                need = max(need, -(-(i + 1) // max(1, slack)))
+            n = min(len(rdy), max(need, lds_per_gap))
+            for x in rdy[:n]:
+                self.emit(x[2])
+                lds.remove(x)
+            # (2) DMA / bookkeeping groups
+            if k in dma_gaps and misc:
+                cnt = dma_gaps.count(k)
+                for _ in range(cnt):
+                    if misc:
+                        grp, _tag = misc.pop(0)
+                        for ins in grp:
+                            self.emit(ins)
+            # (3) VALU: spread what is left evenly over the remaining gaps
+            left_gaps = M - k
+            take = -(-(nv - vi) // left_gaps)
+            cap = cfg.get("valu_cap", 99)
+            take = min(take, cap) if k < M - 1 else nv - vi
+            for _ in range(take):
+                if vi < nv:
+                    self._emit_valu(valu[vi])
+                    vi += 1
+        while vi < nv:
+            self._emit_valu(valu[vi])
+            vi += 1
+
+    # ------------------------------------------------------------------ routines
+    def gen_mask_routine(self, qb):
+        o = []
+        S = V_S[qb]
+        T = V_T
+        tlo, tinf = f"v{T}", f"v{T + 1}"
+        o.append(f"v_subrev_u32 {tlo}, s{S_N0}, v{V_LOG[qb]}")          # lo_t = (lo - 4g) - n0
+        o.append(f"v_mov_b32 {tinf}, 0xff800000")
+        o.append("s_nop 0")
+        for kb in range(2):
+            for r in range(16):
+                c = 32 * kb + (r & 3) + 8 * (r >> 2)
+                t = f"v{T + 2 + (r & 3)}"
+                o.append(f"v_sub_u32 {t}, {c}, {tlo}")
+                o.append(f"v_cmp_gt_u32 vcc, {t}, v{V_WIDTH[qb]}")
+                o.append(f"v_cndmask_b32 v{S + 16 * kb + r}, v{S + 16 * kb + r}, {tinf}, vcc")
+        o.append(f"s_setpc_b64 {sr(S_RET, 2)}")
+        return o
+
+    def gen_rescale_routine(self, qb):
+        o = []
+        T = V_T + 8            # temps v60.. : must not collide with the caller's live temps (max tree result is in T+23+qb)
+        mxr = f"v{V_T + 23 + qb}"
+        mrun, negm, l = f"v{V_MRUN[qb]}", f"v{V_NEGM[qb]}", f"v{V_L[qb]}"
+        mxs, mnew, muse, al = f"v{T}", f"v{T + 1}", f"v{T + 2}", f"v{T + 3}"
+        o.append("s_nop 7")
+        o.append("s_nop 7")
+        o.append(f"v_mul_f32 {mxs}, s{S_C}, {mxr}")
+        o.append(f"v_max_f32 {mnew}, {mrun}, {mxs}")
+        o.append(f"v_max_f32 {muse}, 0xff7fffff, {mnew}")
+        o.append(f"v_sub_f32 {al}, {mrun}, {muse}")
+        o.append(f"v_exp_f32 {al}, {al}")
+        o.append(f"v_mov_b32 {mrun}, {mnew}")
+        o.append(f"v_sub_f32 {negm}, 0, {muse}")
+        o.append(f"v_mul_f32 {l}, {l}, {al}")
+        for i in range(0, 64, 4):
+            for e in range(4):
+                o.append(f"v_accvgpr_read_b32 v{T + 4 + e}, a{A_O[qb] + i + e}")
+            for e in range(4):
+                o.append(f"v_mul_f32 v{T + 4 + e}, v{T + 4 + e}, {al}")
+            for e in range(4):
+                o.append(f"v_accvgpr_write_b32 a{A_O[qb] + i + e}, v{T + 4 + e}")
+        o.append("s_nop 1")
+        o.append(f"s_setpc_b64 {sr(S_RET, 2)}")
+        return o
+
+    # ------------------------------------------------------------------ whole body
+    def gen_dma_tile(self, which, tile_s, slot_s, tmp):
+        """prologue LDS-DMA of one K or V tile: tile index in SGPR tile_s, slot offset SGPR slot_s."""
+        o = []
+        rs, tb, s16, vo, reg = ((S_KRS, S_KTILE, S_K16, V_DMAK, 0) if which == "k" else
+                                (S_VRS, S_VTILE, S_V16, V_DMAV, LDS_VREGION))
+        o.append(f"s_mul_i32 s{tmp}, s{tile_s}, s{tb}")
+        o.append(f"s_cmp_lt_i32 s{tile_s}, s{S_NMAX}")
+        o.append(f"s_cselect_b32 s{tmp}, s{tmp}, s{S_OOB}")
+        o.append(f"s_add_u32 s{tmp + 1}, s{slot_s}, s{S_W1024}")
+        for jj in range(4):
+            o.append(f"s_add_u32 m0, s{tmp + 1}, {reg + 4096 * jj}")
+            o.append("s_nop 0")
+            o.append(f"buffer_load_dwordx4 v{vo}, {sr(rs, 4)}, s{tmp} offen lds")
+            o.append(f"s_add_u32 s{tmp}, s{tmp}, s{s16}")
+        return o
+
+    def gen_body(self, cfg):
+        L = []
+        A = L.append
+        A("s_nop 7")
+        # ---- routine addresses
+        A(f"s_getpc_b64 {sr(S_SUB, 2)}")
+        A("L_pc_%=:")
+        for (reg, lab) in ((S_MASKFN[0], "L_mask0"), (S_MASKFN[1], "L_mask1"), (S_RESCFN[0], "L_resc0"), (S_RESCFN[1], "L_resc1")):
+            A(f"s_add_u32 s{reg}, s{S_SUB}, {lab}_%=-L_pc_%=")
+            A(f"s_addc_u32 s{reg + 1}, s{S_SUB + 1}, 0")
+        A(f"s_mov_b32 s{S_J}, s{S_JIN}")
+        A(f"s_mov_b32 s{S_OOB}, 0x80000000")
+        A(f"s_mov_b32 s{S_R0}, 0")
+        A(f"s_mov_b32 s{S_R1}, {LDS_STAGE}")
+        A(f"s_mov_b32 s{S_R2}, {2 * LDS_STAGE}")
+        A("s_barrier")                                   # previous pass: every wave is done with the LDS ring
+        # ---- Q fragments -> AGPRs
+        for qb in range(2):
+            for ks in range(8):
+                A(f"buffer_load_dwordx4 {ar(A_Q[qb] + 4 * ks, 4)}, v{V_QOFF[qb]}, {sr(S_QRS, 4)}, 0 offen offset:{32 * ks}")
+        # ---- first tiles: K(n_min) -> R1, V(n_min) -> R1, K(n_min+1) -> R2      (n_min = j_start + 2)
+        t = S_TMP
+        A(f"s_add_u32 s{t}, s{S_J}, 2")
+        L += self.gen_dma_tile("k", t, S_R1, t + 1)
+        L += self.gen_dma_tile("v", t, S_R1, t + 1)
+        A(f"s_add_u32 s{t}, s{S_J}, 3")
+        L += self.gen_dma_tile("k", t, S_R2, t + 1)
+        # ---- state
+        for i in range(128):
+            A(f"v_accvgpr_write_b32 a{i}, 0")
+        for qb in range(2):
+            A(f"v_mov_b32 v{V_MRUN[qb]}, 0xff800000")
+            A(f"v_mov_b32 v{V_NEGM[qb]}, 0x7f7fffff")
+            A(f"v_mov_b32 v{V_L[qb]}, 0")
+        for i in range(8):
+            A(f"v_add_u32 v{V_KADDR + i}, s{S_R1}, v{V_KBASE + i}")
+        A(f"v_add_u32 v{V_VADDR}, s{S_R0}, v{V_VBASE}")
+        A("s_waitcnt vmcnt(8)")                          # Q and K(n_min) have landed
+
+        # ---- iteration loop + dispatch
+        A("L_top_%=:")
+        A("s_barrier")
+        t1, t2 = S_TMP, S_TMP + 1
+        A(f"s_add_u32 s{t2}, s{S_J}, 2")
+        A(f"s_cmp_ge_i32 s{S_J}, s{S_WLO}")
+        A("s_cbranch_scc0 L_notfull_%=")
+        A(f"s_cmp_lt_i32 s{t2}, s{S_WHI}")
+        A("s_cbranch_scc1 L_v111_%=")
+        A("L_notfull_%=:")
+        # a2 = wlo <= j+2 < whi ; a1 ; a0 -> 3-bit code in s_t1
+        A(f"s_add_u32 s{t1}, s{S_J}, 1")
+        code = S_TMP + 2
+        A(f"s_mov_b32 s{code}, 0")
+        for (reg, bit) in ((S_J, 1), (t1, 2), (t2, 4)):
+            u = self.uid()
+            A(f"s_cmp_ge_i32 s{reg}, s{S_WLO}")
+            A(f"s_cbranch_scc0 L_c{u}_%=")
+            A(f"s_cmp_lt_i32 s{reg}, s{S_WHI}")
+            A(f"s_cbranch_scc0 L_c{u}_%=")
+            A(f"s_or_b32 s{code}, s{code}, {bit}")
+            A(f"L_c{u}_%=:")
+        variants = [(0, 0, 1), (0, 1, 1), (0, 1, 0), (1, 1, 0), (1, 0, 0)]   # (a0, a1, a2); (1,1,1) handled above
+        for (a0, a1, a2) in variants:
+            A(f"s_cmp_eq_u32 s{code}, {a0 + 2 * a1 + 4 * a2}")
+            A(f"s_cbranch_scc1 L_v{a0}{a1}{a2}_%=")
+        A("s_branch L_v000_%=")
+        report = {}
+        for (a0, a1, a2) in [(1, 1, 1)] + variants + [(0, 0, 0)]:
+            A(f"L_v{a0}{a1}{a2}_%=:")
+            self.out = []
+            self.stats = {"nop_states": 0, "lgkm_waits": 0}
+            self.gen_iteration(a0, a1, a2, cfg)
+            report[(a0, a1, a2)] = (dict(self.stats), len(self.out))
+            L += self.out
+            A("s_waitcnt vmcnt(8)")
+            A(f"s_add_u32 s{S_J}, s{S_J}, 1")
+            A(f"s_cmp_lt_i32 s{S_J}, s{S_NMAX}")
+            A("s_cbranch_scc1 L_top_%=")
+            A("s_branch L_done_%=")
+        # ---- routines
+        for qb in range(2):
+            A(f"L_mask{qb}_%=:")
+            L += self.gen_mask_routine(qb)
+            A(f"L_resc{qb}_%=:")
+            L += self.gen_rescale_routine(qb)
+        # ---- epilogue
+        A("L_done_%=:")
+        A("s_waitcnt vmcnt(0)")
+        A("s_nop 7")
+        A("s_nop 7")
+        T = V_T
+        for qb in range(2):
+            l, mrun = f"v{V_L[qb]}", f"v{V_MRUN[qb]}"
+            ta, lt, inv, lse, zero = f"v{T}", f"v{T + 1}", f"v{T + 2}", f"v{T + 3}", f"v{T + 4}"
+            A(f"v_mov_b32 {ta}, {l}")
+            A("s_nop 1")
+            A(f"v_permlane32_swap_b32 {ta}, {l}")
+            A(f"v_add_f32 {lt}, {ta}, {l}")
+            A(f"v_rcp_f32 {inv}, {lt}")
+            A(f"v_log_f32 {lse}, {lt}")
+            A(f"v_mov_b32 {zero}, 0")
+            A(f"v_cmp_lt_f32 vcc, 0, {lt}")
+            A(f"v_cndmask_b32 {inv}, {zero}, {inv}, vcc")
+            A(f"v_add_f32 {lse}, {lse}, {mrun}")
+            A(f"v_mul_f32 {lse}, 0x3f317218, {lse}")
+            A(f"buffer_store_dword {lse}, v{V_LSEOFF[qb]}, {sr(S_LRS, 4)}, 0 offen")
+            for d in range(4):
+                for r4 in range(4):
+                    base = A_O[qb] + 16 * d + 4 * r4
+                    tt = T + 8 + 4 * (r4 & 1)
+                    for e in range(4):
+                        A(f"v_accvgpr_read_b32 v{tt + e}, a{base + e}")
+                    for e in range(4):
+                        A(f"v_mul_f32 v{tt + e}, v{tt + e}, {inv}")
+                    pk = T + 16 + 2 * (r4 & 1)
+                    A(f"{self.cvt} v{pk}, v{tt}, v{tt + 1}")
+                    A(f"{self.cvt} v{pk + 1}, v{tt + 2}, v{tt + 3}")
+                    A(f"buffer_store_dwordx2 {vr(pk, 2)}, v{V_OOFF[qb]}, {sr(S_ORS, 4)}, 0 offen offset:{64 * d + 16 * r4}")
+        A("s_waitcnt vmcnt(0)")
+        return L, report
+
+
+DEFAULT_CFG = {
+    # MFMA index within the phase after which one DMA / bookkeeping group is emitted (9 groups: offsets, 4 K, 4 V)
+    "dma_gaps": {2: [16, 18, 20, 22, 24, 26, 28, 30, 31]},
+    "lds_per_gap": 1,
+}
+
+
+def clobbers():
+    c = ["memory", "vcc", "scc", "m0"]
+    c += [f"v{i}" for i in range(37, 256)]
+    c += [f"a{i}" for i in range(256)]
+    c += [f"s{i}" for i in range(S_R0, S_LAST + 1)]
+    return c
+
+
+def main():
+    cfg = dict(DEFAULT_CFG)
+    print("// GENERATED by gen_fwd_asm.py - do not edit.  See that script for the schedule and the register map.")
+    print("#pragma once")
+    for dt in ("bf16", "f16"):
+        g = Gen(dt)
+        body, report = g.gen_body(cfg)
+        print(f"#define FA_FWD_ASM_BODY_{dt.upper()} \\")
+        for ln in body:
+            print(f'    "{ln}\\n" \\')
+        print('    ""')
+        for k, (st, n) in report.items():
+            print(f"// {dt} variant a0a1a2={k}: {n} lines, nop states {st['nop_states']}, lgkmcnt waits {st['lgkm_waits']}")
+    cl = ", ".join(f'"{c}"' for c in clobbers())
+    print(f"#define FA_FWD_ASM_CLOBBERS {cl}")
+
+
+if __name__ == "__main__":
+    main()
