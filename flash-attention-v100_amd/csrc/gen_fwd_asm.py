@@ -44,6 +44,9 @@ NT = 28
 V_S = (80, 112)          # S^T accumulators of qb0 / qb1: 32 regs each (kb0: 16, kb1: 16)
 V_P = (144, 160)         # packed P^T: 16 regs each (4 k-steps x 4)
 V_VF = 176               # V^T fragments: [ks][dblk] x 4 regs = 64
+V_DMAK_CUR, V_DMAV_CUR = 240, 241   # fast loop: DMA source voffsets of the tiles being fetched (advance by one tile per iteration)
+V_L2 = (242, 243)        # second row-sum chain per q-block
+V_THR = (244, 245)       # rescale threshold in raw score units: (m_run + 8) / c
 # AGPR
 A_O = (0, 64)            # O^T accumulators per q-block: [dblk] x 16
 A_Q = (128, 160)         # Q fragments per q-block: [ks] x 4
@@ -68,7 +71,10 @@ S_RET = 64
 S_MASKFN = (66, 68)      # s[66:67] mask0, s[68:69] mask1
 S_RESCFN = (70, 72)      # s[70:71] rescale0, s[72:73] rescale1
 S_J = 74                 # iteration counter (copy of the input s41)
-S_LAST = 74
+S_KJ = 75                # s75..s77: 1,2,3 x 16 K rows in bytes (fast-loop DMA soffsets)
+S_VJ = 78                # s78..s80
+S_LAST = 80
+S_RC, S_FASTLO, S_FASTEND = 81, 82, 83     # in: 1 / c; fast-loop iteration range [lo, end)
 
 LDS_STAGE = 16384        # one K (or V) tile
 LDS_VREGION = 3 * LDS_STAGE
@@ -163,7 +169,15 @@ class Gen:
                 need = max(need, 16 - (self.now - self.srcc_rd[r] - 1))   # WAR on an MFMA's srcC
         return max(need, 0)
 
+    ko = frozenset()           # timing experiments only (results are wrong): kinds of instructions left out
+
     def emit(self, ins):
+        if self.ko:
+            k = ins.kind
+            if (("dma" in self.ko and k == "dma") or ("lds" in self.ko and k == "lds") or ("mfma" in self.ko and k == "mfma") or
+                    ("valu" in self.ko and k in ("valu", "trans", "swap") and ins.aux != "keep") or
+                    ("salu" in self.ko and k == "salu" and "m0" not in ins.wr and ins.aux != "keep")):
+                return
         if ins.kind == "label" or ins.kind == "raw":
             self.out.append(ins.txt)
             return
@@ -238,16 +252,17 @@ class Gen:
                                      "v", V_P[qb] + 4 * ks, False))
         return out
 
-    def k_read(self, kb, ks):
+    def k_read(self, kb, ks, fast=None):
         b = A_KF + (kb * 8 + ks) * 4
-        return Ins(f"ds_read_b128 {ar(b, 4)}, v{V_KADDR + ks} offset:{kb * 8192}", "lds",
-                   [f"v{V_KADDR + ks}"], rl("a", b, 4))
+        areg, off = (V_KADDR + ks, kb * 8192) if fast is None else (V_KBASE + ks, fast[1] + kb * 8192)
+        return Ins(f"ds_read_b128 {ar(b, 4)}, v{areg} offset:{off}", "lds", [f"v{areg}"], rl("a", b, 4))
 
-    def v_reads(self, d, ks):
+    def v_reads(self, d, ks, fast=None):
         b = V_VF + (ks * 4 + d) * 4
-        off = ks * 4096 + d * 256
-        return [Ins(f"ds_read_b64_tr_b16 {vr(b, 2)}, v{V_VADDR} offset:{off}", "lds", [f"v{V_VADDR}"], rl("v", b, 2)),
-                Ins(f"ds_read_b64_tr_b16 {vr(b + 2, 2)}, v{V_VADDR} offset:{off + 2048}", "lds", [f"v{V_VADDR}"],
+        areg, off = (V_VADDR, ks * 4096 + d * 256) if fast is None else (V_VBASE, fast[0] + ks * 4096 + d * 256)
+        assert off + 2048 < 65536
+        return [Ins(f"ds_read_b64_tr_b16 {vr(b, 2)}, v{areg} offset:{off}", "lds", [f"v{areg}"], rl("v", b, 2)),
+                Ins(f"ds_read_b64_tr_b16 {vr(b + 2, 2)}, v{areg} offset:{off + 2048}", "lds", [f"v{areg}"],
                     rl("v", b + 2, 2))]
 
     def valu(self, txt, rd, wr, kind="valu", w=1.0):
@@ -288,15 +303,13 @@ class Gen:
         out.append(Ins(f"v_permlane32_swap_b32 {ta}, {mx}", "swap", [ta, mx], [ta, mx]))
         mxr = f"v{T + 23 + qb}"                       # raw (unscaled) row max, read by the rescale routine
         out.append(self.valu(f"v_max_f32 {mxr}, {ta}, {mx}", [ta, mx], [mxr]))
-        out.append(self.valu(f"v_fma_f32 {td}, {mxr}, s{S_C}, -v{V_MRUN[qb]}", [mxr, f"v{V_MRUN[qb]}"], [td]))
-        out.append(self.valu(f"v_cmp_nge_f32 vcc, 0x41000000, {td}", [td], ["vcc"]))
+        out.append(self.valu(f"v_cmp_lt_f32 vcc, v{V_THR[qb]}, {mxr}", [mxr, f"v{V_THR[qb]}"], ["vcc"]))
         call = Ins(f"s_cbranch_vccz L_norescale_{self.uid()}_%=", "call_rescale", ["vcc"], [], w=1.0)
         call.aux = qb
         out.append(call)
         # ---- exp2(s c - m), row sum (two chains), pack
         negm = f"v{V_NEGM[qb]}"
-        l0, l1 = f"v{V_L[qb]}", tl
-        first_l1 = True
+        l0, l1 = f"v{V_L[qb]}", f"v{V_L2[qb]}"
         step = 2
         for r0 in range(0, 32, step):
             rs = list(range(r0, r0 + step))
@@ -305,13 +318,8 @@ class Gen:
             for r in rs:
                 out.append(self.valu(f"v_exp_f32 {s[r]}, {s[r]}", [s[r]], [s[r]], kind="trans", w=1.6))
             for r in rs:
-                if r % 2 == 0:
-                    out.append(self.valu(f"v_add_f32 {l0}, {l0}, {s[r]}", [l0, s[r]], [l0]))
-                elif first_l1:
-                    out.append(self.valu(f"v_mov_b32 {l1}, {s[r]}", [s[r]], [l1]))
-                    first_l1 = False
-                else:
-                    out.append(self.valu(f"v_add_f32 {l1}, {l1}, {s[r]}", [l1, s[r]], [l1]))
+                ll = l0 if r % 2 == 0 else l1
+                out.append(self.valu(f"v_add_f32 {ll}, {ll}, {s[r]}", [ll, s[r]], [ll]))
             # pack completed pairs: P[ks][e] <- (s[8 ks' + 2e], s[.. + 1]) in tile register order
             for r in rs:
                 if r % 2 == 1:
@@ -320,7 +328,6 @@ class Gen:
                     e = (rr % 8) // 2
                     dst = f"v{P + 4 * ks + e}"
                     out.append(self.valu(f"{self.cvt} {dst}, {s[r - 1]}, {s[r]}", [s[r - 1], s[r]], [dst]))
-        out.append(self.valu(f"v_add_f32 {l0}, {l0}, {l1}", [l0, l1], [l0]))
         return out
 
     _uid = 0
@@ -361,6 +368,28 @@ class Gen:
             g.append((p, "dma"))
         return g
 
+    def misc_stream_fast(self, fast):
+        """Fast loop: K(j+4) -> slot r0, V(j+3) -> slot r2; the source tile is in the voffset registers."""
+        r0, r1, r2 = fast
+        g = []
+        for jj in range(4):
+            so = "0" if jj == 0 else f"s{S_KJ + jj - 1}"
+            p = [Ins(f"s_add_u32 m0, s{S_W1024}, {r0 + 4096 * jj}", "salu", [], ["m0", "scc"], w=0.5),
+                 Ins(f"buffer_load_dwordx4 v{V_DMAK_CUR}, {sr(S_KRS, 4)}, {so} offen lds", "dma",
+                     ["m0", f"v{V_DMAK_CUR}"], [], w=4.0)]
+            if jj == 3:
+                p.append(Ins(f"v_add_u32 v{V_DMAK_CUR}, s{S_KTILE}, v{V_DMAK_CUR}", "valu", [f"v{V_DMAK_CUR}"], [f"v{V_DMAK_CUR}"]))
+            g.append((p, "dma"))
+        for jj in range(4):
+            so = "0" if jj == 0 else f"s{S_VJ + jj - 1}"
+            p = [Ins(f"s_add_u32 m0, s{S_W1024}, {LDS_VREGION + r2 + 4096 * jj}", "salu", [], ["m0", "scc"], w=0.5),
+                 Ins(f"buffer_load_dwordx4 v{V_DMAV_CUR}, {sr(S_VRS, 4)}, {so} offen lds", "dma",
+                     ["m0", f"v{V_DMAV_CUR}"], [], w=4.0)]
+            if jj == 3:
+                p.append(Ins(f"v_add_u32 v{V_DMAV_CUR}, s{S_VTILE}, v{V_DMAV_CUR}", "valu", [f"v{V_DMAV_CUR}"], [f"v{V_DMAV_CUR}"]))
+            g.append((p, "dma"))
+        return g
+
     def addr_update(self):
         """Read addresses of the NEXT iteration: K read slot R1' = R2, V read slot R0' = R1; then rotate."""
         ka = [Ins(f"v_add_u32 v{V_KADDR + i}, s{S_R2}, v{V_KBASE + i}", "valu", [f"v{V_KBASE + i}"], [f"v{V_KADDR + i}"])
@@ -392,8 +421,9 @@ class Gen:
         ]
         return lines
 
-    def gen_iteration(self, a0, a1, a2, cfg):
-        """a0/a1/a2: tiles j, j+1, j+2 are active for this wave."""
+    def gen_iteration(self, a0, a1, a2, cfg, fast=None):
+        """a0/a1/a2: tiles j, j+1, j+2 are active for this wave.  fast = (r0, r1, r2): the mask-free steady-state copy
+        with the LDS ring slots as immediates (no mask checks, no slot bookkeeping)."""
         self.reset_state()
         # ---- streams
         mf1 = (self.qk_mfmas(1) if a1 else []) + (self.pv_mfmas(1) if a0 else [])
@@ -409,27 +439,31 @@ class Gen:
                 for kb in range(2):
                     p = ks * 2 + kb
                     ready = p if a1 else -1          # after QK1 MFMA p of phase 1
-                    lds.append([ready, nm1 + p, self.k_read(kb, ks)])
+                    lds.append([ready, nm1 + p, self.k_read(kb, ks, fast)])
         if a1:
             for ks in range(4):
                 for d in range(4):
                     q = ks * 4 + d
                     ready = (n1_qk + q) if a0 else -1
-                    for ins in self.v_reads(d, ks):
+                    for ins in self.v_reads(d, ks, fast):
                         lds.append([ready, nm1 + n2_qk + q, ins])
         lds.sort(key=lambda x: (x[1], x[0]))
         val1 = self.softmax(0) if a1 else []
         val2 = self.softmax(1) if a1 else []
-        misc = self.misc_stream()
-        ka, va, rot = self.addr_update()
+        if fast is None:
+            misc = self.misc_stream()
+            ka, va, rot = self.addr_update()
+        else:
+            misc = self.misc_stream_fast(fast)
+            ka, va, rot = [], [], []
 
         # ---- phase 1
-        if a1:
+        if a1 and fast is None and "maskchk" not in self.ko:
             for l in self.mask_check(0):
                 self.raw(l)
         self._phase(mf1, val1, lds, 0, cfg, phase=1, misc=misc, extra=[])
         # ---- phase 2
-        if a1:
+        if a1 and fast is None and "maskchk" not in self.ko:
             for l in self.mask_check(1):
                 self.raw(l)
         base = len(mf1)
@@ -445,6 +479,8 @@ class Gen:
 
     def _emit_valu(self, ins):
         if ins.kind == "call_rescale":
+            if "valu" in self.ko:
+                return
             qb = ins.aux
             lab = ins.txt.split()[1]
             self.emit(Ins(ins.txt, "salu", ["vcc"], []))
@@ -541,6 +577,9 @@ class Gen:
         o.append(f"v_mov_b32 {mrun}, {mnew}")
         o.append(f"v_sub_f32 {negm}, 0, {muse}")
         o.append(f"v_mul_f32 {l}, {l}, {al}")
+        o.append(f"v_mul_f32 v{V_L2[qb]}, v{V_L2[qb]}, {al}")
+        o.append(f"v_add_f32 v{V_THR[qb]}, 0x41000000, {mnew}")               # (m_run + 8) / c
+        o.append(f"v_mul_f32 v{V_THR[qb]}, s{S_RC}, v{V_THR[qb]}")
         for i in range(0, 64, 4):
             for e in range(4):
                 o.append(f"v_accvgpr_read_b32 v{T + 4 + e}, a{A_O[qb] + i + e}")
@@ -584,6 +623,9 @@ class Gen:
         A(f"s_mov_b32 s{S_R0}, 0")
         A(f"s_mov_b32 s{S_R1}, {LDS_STAGE}")
         A(f"s_mov_b32 s{S_R2}, {2 * LDS_STAGE}")
+        for jj in range(1, 4):
+            A(f"s_mul_i32 s{S_KJ + jj - 1}, s{S_K16}, {jj}")
+            A(f"s_mul_i32 s{S_VJ + jj - 1}, s{S_V16}, {jj}")
         A("s_barrier")                                   # previous pass: every wave is done with the LDS ring
         # ---- Q fragments -> AGPRs
         for qb in range(2):
@@ -603,6 +645,8 @@ class Gen:
             A(f"v_mov_b32 v{V_MRUN[qb]}, 0xff800000")
             A(f"v_mov_b32 v{V_NEGM[qb]}, 0x7f7fffff")
             A(f"v_mov_b32 v{V_L[qb]}, 0")
+            A(f"v_mov_b32 v{V_L2[qb]}, 0")
+            A(f"v_mov_b32 v{V_THR[qb]}, 0xff800000")
         for i in range(8):
             A(f"v_add_u32 v{V_KADDR + i}, s{S_R1}, v{V_KBASE + i}")
         A(f"v_add_u32 v{V_VADDR}, s{S_R0}, v{V_VBASE}")
@@ -610,8 +654,28 @@ class Gen:
 
         # ---- iteration loop + dispatch
         A("L_top_%=:")
-        A("s_barrier")
+        if "bar" not in self.ko:
+            A("s_barrier")
         t1, t2 = S_TMP, S_TMP + 1
+        # ---- mask-free steady state: three unrolled copies, LDS ring slots as immediates
+        slots = [(0, LDS_STAGE, 2 * LDS_STAGE), (LDS_STAGE, 2 * LDS_STAGE, 0), (2 * LDS_STAGE, 0, LDS_STAGE)]
+        if cfg.get("fast", True):
+            A(f"s_cmp_ge_i32 s{S_J}, s{S_FASTLO}")
+            A("s_cbranch_scc0 L_generic_%=")
+            A(f"s_cmp_lt_i32 s{S_J}, s{S_FASTEND}")
+            A("s_cbranch_scc0 L_generic_%=")
+            A(f"s_add_u32 s{t1}, s{S_J}, 4")
+            A(f"s_mul_i32 s{t1}, s{t1}, s{S_KTILE}")
+            A(f"v_add_u32 v{V_DMAK_CUR}, s{t1}, v{V_DMAK}")
+            A(f"s_add_u32 s{t1}, s{S_J}, 3")
+            A(f"s_mul_i32 s{t1}, s{t1}, s{S_VTILE}")
+            A(f"v_add_u32 v{V_DMAV_CUR}, s{t1}, v{V_DMAV}")
+            A(f"s_cmp_eq_u32 s{S_R0}, 0")
+            A("s_cbranch_scc1 L_fast0_body_%=")
+            A(f"s_cmp_eq_u32 s{S_R0}, {LDS_STAGE}")
+            A("s_cbranch_scc1 L_fast1_body_%=")
+            A("s_branch L_fast2_body_%=")
+        A("L_generic_%=:")
         A(f"s_add_u32 s{t2}, s{S_J}, 2")
         A(f"s_cmp_ge_i32 s{S_J}, s{S_WLO}")
         A("s_cbranch_scc0 L_notfull_%=")
@@ -648,6 +712,36 @@ class Gen:
             A(f"s_cmp_lt_i32 s{S_J}, s{S_NMAX}")
             A("s_cbranch_scc1 L_top_%=")
             A("s_branch L_done_%=")
+        # ---- fast copies
+        if cfg.get("fast", True):
+            for c, sl in enumerate(slots):
+                A(f"L_fast{c}_%=:")
+                if "bar" not in self.ko:
+                    A("s_barrier")
+                A(f"L_fast{c}_body_%=:")
+                self.out = []
+                self.stats = {"nop_states": 0, "lgkm_waits": 0}
+                self.gen_iteration(1, 1, 1, cfg, fast=sl)
+                report[("fast", c)] = (dict(self.stats), len(self.out))
+                L += self.out
+                A("s_waitcnt vmcnt(8)")
+                A(f"s_add_u32 s{S_J}, s{S_J}, 1")
+                A(f"s_cmp_lt_i32 s{S_J}, s{S_FASTEND}")
+                if c < 2:
+                    A(f"s_cbranch_scc0 L_fastexit{c}_%=")
+                else:
+                    A("s_cbranch_scc1 L_fast0_%=")
+                    A("s_branch L_fastexit2_%=")
+            for c, sl in enumerate(slots):
+                n0, n1, n2 = sl[1], sl[2], sl[0]           # ring state of the iteration after copy c
+                A(f"L_fastexit{c}_%=:")
+                A(f"s_mov_b32 s{S_R0}, {n0}")
+                A(f"s_mov_b32 s{S_R1}, {n1}")
+                A(f"s_mov_b32 s{S_R2}, {n2}")
+                for i in range(8):
+                    A(f"v_add_u32 v{V_KADDR + i}, {n1}, v{V_KBASE + i}")
+                A(f"v_add_u32 v{V_VADDR}, {n0}, v{V_VBASE}")
+                A("s_branch L_top_%=")
         # ---- routines
         for qb in range(2):
             A(f"L_mask{qb}_%=:")
@@ -663,6 +757,7 @@ class Gen:
         for qb in range(2):
             l, mrun = f"v{V_L[qb]}", f"v{V_MRUN[qb]}"
             ta, lt, inv, lse, zero = f"v{T}", f"v{T + 1}", f"v{T + 2}", f"v{T + 3}", f"v{T + 4}"
+            A(f"v_add_f32 {l}, {l}, v{V_L2[qb]}")
             A(f"v_mov_b32 {ta}, {l}")
             A("s_nop 1")
             A(f"v_permlane32_swap_b32 {ta}, {l}")
@@ -708,10 +803,20 @@ def clobbers():
 
 def main():
     cfg = dict(DEFAULT_CFG)
+    ko = frozenset()
+    for a in sys.argv[1:]:
+        if a.startswith("--ko="):
+            ko = frozenset(x for x in a[5:].split(",") if x)
+        elif a.startswith("--cfg="):
+            import json
+            cfg.update(json.loads(a[6:]))
+    if "dma_gaps" in cfg:
+        cfg["dma_gaps"] = {int(k): v for k, v in cfg["dma_gaps"].items()}
     print("// GENERATED by gen_fwd_asm.py - do not edit.  See that script for the schedule and the register map.")
     print("#pragma once")
     for dt in ("bf16", "f16"):
         g = Gen(dt)
+        g.ko = ko
         body, report = g.gen_body(cfg)
         print(f"#define FA_FWD_ASM_BODY_{dt.upper()} \\")
         for ln in body:
