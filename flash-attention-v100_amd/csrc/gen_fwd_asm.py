@@ -175,6 +175,7 @@ class Gen:
         if self.ko:
             k = ins.kind
             if (("dma" in self.ko and k == "dma") or ("lds" in self.ko and k == "lds") or ("mfma" in self.ko and k == "mfma") or
+                    ("ldsk" in self.ko and k == "lds" and "b128" in ins.txt) or ("ldsv" in self.ko and k == "lds" and "tr_b16" in ins.txt) or
                     ("valu" in self.ko and k in ("valu", "trans", "swap") and ins.aux != "keep") or
                     ("salu" in self.ko and k == "salu" and "m0" not in ins.wr and ins.aux != "keep")):
                 return
@@ -591,6 +592,25 @@ class Gen:
         o.append(f"s_setpc_b64 {sr(S_RET, 2)}")
         return o
 
+    def skew(self, cfg):
+        """After a barrier the four waves of the workgroup run the same instruction stream in lock step, so every
+        LDS read and every LDS-DMA issue of a wave collides with the other three at the one LDS / texture-address
+        unit of the CU.  A wave-dependent delay (wave w waits w steps) right behind the barrier staggers them."""
+        n = cfg.get("skew", 0)
+        if n <= 0:
+            return []
+        u = self.uid()
+        o = []
+        for w in range(3):
+            o.append(f"s_cmp_eq_u32 s{S_W1024}, {1024 * w}")
+            o.append(f"s_cbranch_scc1 L_skew{u}_%=")
+            k = n
+            while k > 0:
+                o.append(f"s_nop {min(k, 8) - 1}")
+                k -= min(k, 8)
+        o.append(f"L_skew{u}_%=:")
+        return o
+
     # ------------------------------------------------------------------ whole body
     def gen_dma_tile(self, which, tile_s, slot_s, tmp):
         """prologue LDS-DMA of one K or V tile: tile index in SGPR tile_s, slot offset SGPR slot_s."""
@@ -656,6 +676,7 @@ class Gen:
         A("L_top_%=:")
         if "bar" not in self.ko:
             A("s_barrier")
+        L += self.skew(cfg)
         t1, t2 = S_TMP, S_TMP + 1
         # ---- mask-free steady state: three unrolled copies, LDS ring slots as immediates
         slots = [(0, LDS_STAGE, 2 * LDS_STAGE), (LDS_STAGE, 2 * LDS_STAGE, 0), (2 * LDS_STAGE, 0, LDS_STAGE)]
@@ -718,6 +739,7 @@ class Gen:
                 A(f"L_fast{c}_%=:")
                 if "bar" not in self.ko:
                     A("s_barrier")
+                L += self.skew(cfg)
                 A(f"L_fast{c}_body_%=:")
                 self.out = []
                 self.stats = {"nop_states": 0, "lgkm_waits": 0}
