@@ -605,6 +605,7 @@ static int launch_fwd_td(const KArgs& a, bool paged, hipStream_t stream) {
 
 bool fwd_asm_applicable(const KArgs& a);
 int launch_fwd_asm(const KArgs& a, hipStream_t stream);
+int launch_fwd_ws(const KArgs& a, hipStream_t stream);
 
 // FA_FWD_ASM=0 (read once, at the first call) keeps every shape on fa_fwd_kernel: the A/B switch for the
 // hand-scheduled D = 128 path of fa_fwd_asm.hip.
@@ -613,8 +614,14 @@ static bool fwd_asm_enabled() {
     return on;
 }
 
+// FA_FWD_WS=0: take the one-wave-per-SIMD asm kernel instead of the warp-specialised one (same applicability).
+static bool fwd_ws_enabled() {
+    static const bool on = [] { const char* e = getenv("FA_FWD_WS"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
 int launch_fwd(const KArgs& a, hipStream_t stream) {
-    if (fwd_asm_enabled() && fwd_asm_applicable(a)) return launch_fwd_asm(a, stream);
+    if (fwd_asm_enabled() && fwd_asm_applicable(a)) return fwd_ws_enabled() ? launch_fwd_ws(a, stream) : launch_fwd_asm(a, stream);
     const bool paged = a.p.block_table != nullptr;
     const bool bf = a.p.dtype == FA_BF16;
     switch (a.p.head_dim) {
