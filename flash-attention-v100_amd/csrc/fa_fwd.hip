@@ -614,9 +614,10 @@ static bool fwd_asm_enabled() {
     return on;
 }
 
-// FA_FWD_WS=0: take the one-wave-per-SIMD asm kernel instead of the warp-specialised one (same applicability).
+// FA_FWD_WS=1: take the warp-specialised kernel (fa_fwd_ws.hip; same applicability, currently slower - see DESIGN.md)
+// instead of the one-wave-per-SIMD asm kernel.
 static bool fwd_ws_enabled() {
-    static const bool on = [] { const char* e = getenv("FA_FWD_WS"); return !(e && e[0] == '0'); }();
+    static const bool on = [] { const char* e = getenv("FA_FWD_WS"); return e && e[0] == '1'; }();
     return on;
 }
 

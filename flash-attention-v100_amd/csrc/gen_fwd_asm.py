@@ -174,6 +174,9 @@ class Gen:
     def emit(self, ins):
         if self.ko:
             k = ins.kind
+            role = getattr(self, "role", "")
+            if role and any(x == f"{role}_{kk}" for x in self.ko for kk in ((k,) + (("valu",) if k in ("trans", "swap") else ()))):
+                return
             if (("dma" in self.ko and k == "dma") or ("lds" in self.ko and k == "lds") or ("mfma" in self.ko and k == "mfma") or
                     ("ldsk" in self.ko and k == "lds" and "b128" in ins.txt) or ("ldsv" in self.ko and k == "lds" and "tr_b16" in ins.txt) or
                     ("valu" in self.ko and k in ("valu", "trans", "swap") and ins.aux != "keep") or
@@ -311,24 +314,24 @@ class Gen:
         # ---- exp2(s c - m), row sum (two chains), pack
         negm = f"v{V_NEGM[qb]}"
         l0, l1 = f"v{V_L[qb]}", f"v{V_L2[qb]}"
-        step = 2
-        for r0 in range(0, 32, step):
-            rs = list(range(r0, r0 + step))
-            for r in rs:
+        # software pipeline over the 32 elements: fma(r), exp(r-1), add(r-3), pack(pair) - transcendentals never sit
+        # back to back (v_exp_f32 re-issues after ~8.5 cycles, a plain VALU after ~5: probe_trans_rate)
+        def pack(r):
+            kb, rr = r // 16, r % 16
+            ks, e = 2 * kb + rr // 8, (rr % 8) // 2
+            dst = f"v{P + 4 * ks + e}"
+            return self.valu(f"{self.cvt} {dst}, {s[r - 1]}, {s[r]}", [s[r - 1], s[r]], [dst])
+        for r in range(32 + 3):
+            if r < 32:
                 out.append(self.valu(f"v_fma_f32 {s[r]}, {s[r]}, s{S_C}, {negm}", [s[r], negm], [s[r]]))
-            for r in rs:
-                out.append(self.valu(f"v_exp_f32 {s[r]}, {s[r]}", [s[r]], [s[r]], kind="trans", w=1.6))
-            for r in rs:
-                ll = l0 if r % 2 == 0 else l1
-                out.append(self.valu(f"v_add_f32 {ll}, {ll}, {s[r]}", [ll, s[r]], [ll]))
-            # pack completed pairs: P[ks][e] <- (s[8 ks' + 2e], s[.. + 1]) in tile register order
-            for r in rs:
-                if r % 2 == 1:
-                    kb, rr = r // 16, r % 16
-                    ks = 2 * kb + rr // 8
-                    e = (rr % 8) // 2
-                    dst = f"v{P + 4 * ks + e}"
-                    out.append(self.valu(f"{self.cvt} {dst}, {s[r - 1]}, {s[r]}", [s[r - 1], s[r]], [dst]))
+            if 0 <= r - 1 < 32:
+                out.append(self.valu(f"v_exp_f32 {s[r - 1]}, {s[r - 1]}", [s[r - 1]], [s[r - 1]], kind="trans", w=1.6))
+            if 0 <= r - 3 < 32:
+                q = r - 3
+                ll = l0 if q % 2 == 0 else l1
+                out.append(self.valu(f"v_add_f32 {ll}, {ll}, {s[q]}", [ll, s[q]], [ll]))
+                if q % 2 == 1:
+                    out.append(pack(q))
         return out
 
     _uid = 0

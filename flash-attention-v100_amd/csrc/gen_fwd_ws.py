@@ -63,14 +63,53 @@ SA_Q = (0, 32)
 OV_OOFF = (8, 9)
 OV_DMAK, OV_DMAV, OV_VBASE = 10, 11, 12
 OV_P = 26                      # P fragments [qb][ks] x 4 = 32   (v24 / v25 are the P ring addresses)
-OV_VRING = [58 + 4 * i for i in range(8)]
-OV_T = 144                     # temps v144..v163
-O_ACC = [("a", 16 * i) for i in range(5)] + [("v", 96 + 16 * i) for i in range(3)]      # O^T[qb][d], index qb * 4 + d
+OV_VRING = [58 + 4 * i for i in range(12)]      # v58..v105
+OV_T = 154                     # temps v154..v173
+O_ACC = [("a", 16 * i) for i in range(5)] + [("v", 106 + 16 * i) for i in range(3)]     # O^T[qb][d], index qb * 4 + d
 N_ARCH, N_ACC = 176, 80
 
 
+TM = 76                        # s76..s79: timer accumulators, s80: reference (cfg timers=1, measurement builds only)
+
+
 class WS(Gen):
+    timers = False
+
+    def stamp(self, k):
+        """accumulate (now - previous stamp) into timer k; k < 0: only set the reference"""
+        if not self.timers:
+            return
+        self.drain_lds()
+        self.raw(f"s_memtime {sr(S_SUB, 2)}")
+        self.raw("s_waitcnt lgkmcnt(0)")
+        if k >= 0:
+            self.raw(f"s_sub_u32 s{S_N0}, s{S_SUB}, s{TM + 4}")
+            self.raw(f"s_add_u32 s{TM + k}, s{TM + k}, s{S_N0}")
+        self.raw(f"s_mov_b32 s{TM + 4}, s{S_SUB}")
+
+    def stamp_lines(self, k):
+        save = self.out
+        self.out = []
+        self.stamp(k)
+        r, self.out = self.out, save
+        return r
+
+    def dump_timers(self, base_row, rowreg):
+        o = []
+        if not self.timers:
+            return o
+        o.append(f"v_readfirstlane_b32 s{S_N0}, v{rowreg}")
+        for k in range(4):
+            o.append(f"v_cvt_f32_u32 v{150 + k}, s{TM + k}")
+        o.append(f"v_mov_b32 v149, {4 * base_row}")
+        o.append(f"v_add_u32 v149, s{S_N0}, v149")
+        for k in range(4):
+            o.append(f"buffer_store_dword v{150 + k}, v149, {sr(S_LRS, 4)}, 0 offen offset:{4 * k}")
+        o.append("s_waitcnt vmcnt(0)")
+        return o
+
     def reset_ws(self, role):
+        self.role = role.lower()
         self.now = 0
         self.last = {}
         self.lds_q = []
@@ -181,10 +220,13 @@ class WS(Gen):
     def s_iteration(self, parity, cfg):
         self.reset_ws("S")
         self.raw(f"s_mov_b32 s{S_PSLOT}, {P_SLOT_BYTES * parity}")
+        self.stamp(0)                                   # 0: barrier wait + dispatch
         self.s_qk(parity, cfg)
+        self.stamp(1)                                   # 1: QK phase
         for qb in range(2):
             self.s_mask_check(qb)
             self.s_softmax(qb, parity)
+        self.stamp(2 )                                  # 2: softmax + P writes
         # rescale flags of this tile
         f0, f1 = f"v{SV_T}", f"v{SV_T + 1}"
         self.emit(Ins(f"v_mov_b32 {f0}, s{S_FLAG[0]}", "valu", [], [f0]))
@@ -268,6 +310,7 @@ class WS(Gen):
                     self.emit(ins)
             return
         pslot = P_SLOT_BYTES * tp
+        self.stamp(0)
         # ---- rescale flags of tile i-1
         f = OV_T
         self.emit(Ins(f"ds_read_b64 {vr(f, 2)}, v{V_PBASE} offset:{pslot + P_FLAGS}", "lds", [f"v{V_PBASE}"], rl("v", f, 2)))
@@ -277,8 +320,9 @@ class WS(Gen):
                 b = OV_P + (qb * 4 + ks) * 4
                 self.emit(Ins(f"ds_read_b128 {vr(b, 4)}, v{V_PBASE} offset:{pslot + (qb * 4 + ks) * 1024}", "lds",
                               [f"v{V_PBASE}"], rl("v", b, 4)))
-        # ---- V fragment ring
-        ring = OV_VRING[:cfg.get("vring", 8)]
+        # ---- V fragment ring; the DMA of the next tiles is issued between the first reads, i.e. while the partner
+        # S wave owns the matrix pipe (its QK phase opens the iteration)
+        ring = OV_VRING[:cfg.get("vring", 12)]
         order = [(d, ks) for ks in range(4) for d in range(4)]
         vslot = V_SLOT[tp]
 
@@ -288,25 +332,27 @@ class WS(Gen):
             off = vslot + ks * 4096 + d * 256
             return [Ins(f"ds_read_b64_tr_b16 {vr(b, 2)}, v{OV_VBASE} offset:{off}", "lds", [f"v{OV_VBASE}"], rl("v", b, 2)),
                     Ins(f"ds_read_b64_tr_b16 {vr(b + 2, 2)}, v{OV_VBASE} offset:{off + 2048}", "lds", [f"v{OV_VBASE}"], rl("v", b + 2, 2))]
-        pre = len(ring) - 1
-        first = min(3, pre)
-        for n in range(first):
+        pre = min(len(ring) - 1, 16)
+        dma_first = cfg.get("o_dma_first", True)
+        for n in range(pre):
             for ins in vread(n):
                 self.emit(ins)
-        # flags -> scalar, rare call (15 LDS operations are in flight behind the flag read)
-        self.emit(Ins(f"v_readfirstlane_b32 s{S_T + 4}, v{f}", "valu", [f"v{f}"], [f"s{S_T + 4}"]))
-        self.emit(Ins(f"v_readfirstlane_b32 s{S_T + 5}, v{f + 1}", "valu", [f"v{f + 1}"], [f"s{S_T + 5}"]))
-        u = self.uid()
-        self.raw(f"s_mov_b32 s{S_PSLOT}, {pslot}")
-        self.raw(f"s_or_b32 s{S_T}, s{S_T + 4}, s{S_T + 5}")
-        self.raw(f"s_cmp_eq_u32 s{S_T}, 0")
-        self.raw(f"s_cbranch_scc1 L_onr{u}_%=")
-        self.raw(f"s_swappc_b64 {sr(S_RET, 2)}, {sr(S_ORESC, 2)}")
-        self.out.append(f"L_onr{u}_%=:")
-        for n in range(first, pre):
-            for ins in vread(n):
-                self.emit(ins)
+            if dma_first and dma:
+                for ins in dma.pop(0):
+                    self.emit(ins)
+            if n == 2:
+                # flags -> scalar, rare call (the flag read is the oldest LDS operation in flight)
+                self.emit(Ins(f"v_readfirstlane_b32 s{S_T + 4}, v{f}", "valu", [f"v{f}"], [f"s{S_T + 4}"]))
+                self.emit(Ins(f"v_readfirstlane_b32 s{S_T + 5}, v{f + 1}", "valu", [f"v{f + 1}"], [f"s{S_T + 5}"]))
+                u = self.uid()
+                self.raw(f"s_mov_b32 s{S_PSLOT}, {pslot}")
+                self.raw(f"s_or_b32 s{S_T}, s{S_T + 4}, s{S_T + 5}")
+                self.raw(f"s_cmp_eq_u32 s{S_T}, 0")
+                self.raw(f"s_cbranch_scc1 L_onr{u}_%=")
+                self.raw(f"s_swappc_b64 {sr(S_RET, 2)}, {sr(S_ORESC, 2)}")
+                self.out.append(f"L_onr{u}_%=:")
         nxt = pre
+        self.stamp(1)                                   # 1: P / V reads + DMA issue
         dma_at = cfg.get("o_dma_at", [1, 3, 5, 7, 9, 11, 13, 15])
         for n, (d, ks) in enumerate(order):
             b = ring[n % len(ring)]
@@ -324,6 +370,7 @@ class WS(Gen):
         for grp in dma:
             for ins in grp:
                 self.emit(ins)
+        self.stamp(2)                                   # 2: PV phase
 
     def o_rescale_routine(self):
         """flags in s[S_T+4], s[S_T+5]; O^T[qb] *= alpha[row] for the flagged q-blocks."""
@@ -369,6 +416,10 @@ class WS(Gen):
         A(f"s_mov_b32 s{S_OOB}, 0x80000000")
         A(f"s_mov_b64 {sr(S_FLAG[0], 2)}, 0")
         A("s_barrier")                                     # previous pass is done with LDS
+        if self.timers:
+            for k in range(4):
+                A(f"s_mov_b32 s{TM + k}, 0")
+            L += self.stamp_lines(-1)
         A(f"s_cmp_eq_u32 s{S_ROLE}, 0")
         A("s_cbranch_scc0 L_orole_%=")
 
@@ -404,6 +455,7 @@ class WS(Gen):
         A("L_sidle_%=:")
         A("L_stail_%=:")
         A("s_waitcnt lgkmcnt(0)")
+        L += self.stamp_lines(3)
         A("s_barrier")
         A(f"s_add_u32 s{S_I}, s{S_I}, 1")
         A(f"s_cmp_le_i32 s{S_I}, s{S_NMAX}")
@@ -430,6 +482,7 @@ class WS(Gen):
         A("s_waitcnt lgkmcnt(0)")
         A("s_barrier")
         A("s_waitcnt vmcnt(0)")
+        L += self.dump_timers(0, SV_LSEOFF[0])
         A("s_setprio 0")
         A("s_branch L_end_%=")
 
@@ -480,6 +533,7 @@ class WS(Gen):
                 A("s_branch L_otail_%=")
         A("L_otail_%=:")
         A("s_waitcnt vmcnt(0) lgkmcnt(0)")
+        L += self.stamp_lines(3)
         A("s_barrier")
         A(f"s_add_u32 s{S_I}, s{S_I}, 1")
         A(f"s_cmp_le_i32 s{S_I}, s{S_NMAX}")
@@ -511,6 +565,7 @@ class WS(Gen):
                     A(f"{self.cvt} v{pk + 1}, v{tt + 2}, v{tt + 3}")
                     A(f"buffer_store_dwordx2 {vr(pk, 2)}, v{OV_OOFF[qb]}, {sr(S_ORS, 4)}, 0 offen offset:{64 * d + 16 * r4}")
         A("s_waitcnt vmcnt(0)")
+        L += self.dump_timers(8, 13)
         A("s_branch L_end_%=")
 
         # ================= routines =================
@@ -551,6 +606,7 @@ def main():
     for dt in ("bf16", "f16"):
         g = WS(dt)
         g.ko = ko
+        g.timers = bool(cfg.get("timers", 0))
         body, report = g.gen_body(cfg)
         print(f"#define FA_FWD_WS_BODY_{dt.upper()} \\")
         for ln in body:

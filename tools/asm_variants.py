@@ -17,16 +17,19 @@ def build(specs):
     b.build()
     os.makedirs(OUT, exist_ok=True)
     bdir = os.path.join(CSRC, "build")
-    others = [os.path.join(bdir, s.replace(".hip", ".o")) for s in b.SOURCES if s != "fa_fwd_asm.hip"]
+    which = os.environ.get("VARIANT_KERNEL", "ws")           # ws: fa_fwd_ws.hip / gen_fwd_ws.py ; asm: fa_fwd_asm.hip / gen_fwd_asm.py
+    src, gen, macro = (("fa_fwd_ws.hip", "gen_fwd_ws.py", "FA_FWD_WS_GEN_H") if which == "ws" else
+                       ("fa_fwd_asm.hip", "gen_fwd_asm.py", "FA_FWD_ASM_GEN_H"))
+    others = [os.path.join(bdir, s.replace(".hip", ".o")) for s in b.SOURCES if s != src]
     procs = []
     for spec in specs:
         name, _, args = spec.partition(":")
         hdr = os.path.join(OUT, f"gen_{name}.h")
-        txt = subprocess.run([sys.executable, os.path.join(CSRC, "gen_fwd_asm.py")] + (args.split(" ") if args else []),
-                             check=True, stdout=subprocess.PIPE).stdout
+        txt = subprocess.run([sys.executable, os.path.join(CSRC, gen)] + (args.split(" ") if args else []),
+                             check=True, stdout=subprocess.PIPE, cwd=CSRC).stdout
         open(hdr, "wb").write(txt)
         obj = os.path.join(OUT, f"asm_{name}.o")
-        cmd = [b._hipcc()] + b.FLAGS + [f'-DFA_FWD_ASM_GEN_H="{hdr}"', "-c", os.path.join(CSRC, "fa_fwd_asm.hip"), "-o", obj]
+        cmd = [b._hipcc()] + b.FLAGS + [f'-D{macro}="{hdr}"', "-c", os.path.join(CSRC, src), "-o", obj]
         procs.append((name, obj, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
     for name, obj, pr in procs:
         o, _ = pr.communicate()
@@ -80,5 +83,30 @@ if __name__ == "__main__":
         build(sys.argv[2:])
     elif sys.argv[1] == "one":
         one()
+    elif sys.argv[1] == "timers":
+        pass
     else:
         time_all(sys.argv[2:])
+
+
+def timers():
+    """WS measurement build (cfg timers=1): per-phase cycle sums land in the LSE rows 0..5 (S wave) / 8..13 (O wave)
+    of every 64-row chunk."""
+    import torch
+    import flash_attn
+    torch.manual_seed(421)
+    B, S, H = 2, 4096, 4
+    for causal in (False, True):
+        q, k, v = (torch.randn(B, S, H, 128, device="cuda", dtype=torch.bfloat16) for _ in range(3))
+        o, lse, _ = flash_attn.flash_attn_func(q, k, v, causal=causal, return_attn_probs=True)
+        torch.cuda.synchronize()
+        t = lse[0, 0].view(S // 64, 64).double()
+        nt = 64 if not causal else None
+        for chunk in (0, 1, 2, 3, 32, 63):
+            srow, orow = t[chunk, 0:6].tolist(), t[chunk, 8:14].tolist()
+            print(f"causal={causal} chunk {chunk:2d}: S wave [wait/disp, QK, softmax, tail] = {[int(x) for x in srow[:4]]}  "
+                  f"O wave [start, loads, PV, tail] = {[int(x) for x in orow[:4]]}")
+
+
+if __name__ == "__main__" and sys.argv[1] == "timers":
+    timers()
