@@ -25,7 +25,9 @@ int launch_kvcache_append(const KArgs& a, hipStream_t stream);
 int launch_decode(const KArgs& a, hipStream_t stream);
 size_t decode_workspace_bytes(const fa_params& p);
 bool decode_applicable(const fa_params& p);
+#ifdef FA_MEASURE
 extern int g_bwd_phase_mask;
+#endif
 }  // namespace fa
 
 static thread_local std::string g_last_error;
@@ -49,6 +51,12 @@ static int check_hip(const char* what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(FA_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e));
     return FA_OK;
+}
+
+// Experiment switches, read ONCE (first call): FA_VARLEN_GRID=1 keeps the batch x max_seqlen grid for varlen.
+static bool varlen_grid_env() {
+    static const bool on = getenv("FA_VARLEN_GRID") != nullptr;
+    return on;
 }
 
 static bool supported_head_dim(int d) { return d == 64 || d == 128 || d == 256; }
@@ -127,7 +135,9 @@ const char* fa_build_info(void) {
            "ops fwd/bwd/varlen_fwd/varlen_bwd/fwd_kvcache";
 }
 
-void fa_debug_set_bwd_phases(int mask) { fa::g_bwd_phase_mask = mask; }
+#ifdef FA_MEASURE
+void fa_debug_set_bwd_phases(int mask) { fa::g_bwd_phase_mask = mask; }      // measurement builds only (tools/)
+#endif
 size_t fa_fwd_workspace_bytes(const fa_params*) { return 0; }
 size_t fa_bwd_workspace_bytes(const fa_params* p) { return p ? fa::bwd_workspace_bytes(*p) : 0; }
 size_t fa_fwd_kvcache_workspace_bytes(const fa_params* p) { return p ? fa::decode_workspace_bytes(*p) : 0; }
@@ -165,7 +175,7 @@ int fa_varlen_fwd(const fa_params* pp, void* stream) {
     normalize(p, false);
     fa::KArgs a = make_args(p, 128);
     a.seqlens_k = p.seqused_k;
-    if (p.total_q > 0 && !getenv("FA_VARLEN_GRID")) {     // flat work list (fa_common.h: decode_work_flat)
+    if (p.total_q > 0 && !varlen_grid_env()) {     // flat work list (fa_common.h: decode_work_flat)
         a.flat_blocks = p.total_q / 128 + p.batch;
         a.pair_qblocks = 0;
         a.n_qblocks = a.n_qblocks_total;
@@ -193,6 +203,8 @@ int fa_fwd_kvcache(const fa_params* pp, void* stream) {
         FA_CHECK(p.k_new && p.v_new, "If key is supplied, value must also be passed in");
         FA_CHECK(p.cache_seqlens, "If key is supplied, seqlens_k must also be passed in");
         FA_CHECK(p.seqlen_new > 0, "seqlen_new must be positive when k/v are supplied");
+        FA_CHECK(p.seqlen_new <= p.seqlen_k && p.seqlen_q <= p.seqlen_k,
+                 "new keys / queries do not fit the cache (fused_mha_forward_kvcache.cu: T_Q <= max_seqlen_k)");
     } else {
         p.seqlen_new = 0;
     }
@@ -201,8 +213,8 @@ int fa_fwd_kvcache(const fa_params* pp, void* stream) {
         FA_CHECK(p.rotary_cos && p.rotary_sin, "rotary_cos and rotary_sin must both be given");
         FA_CHECK(p.rotary_dim <= p.head_dim, "rotary_dim must be <= head_dim");
         FA_CHECK(p.rotary_dim % 16 == 0, "rotary_dim must be divisible by 16");
-        FA_CHECK(p.seqlen_ro >= p.seqlen_k + p.seqlen_new || p.seqlen_ro >= p.seqlen_k,
-                 "rotary_cos seqlen too small");
+        // every position the kernels can touch is < the cache capacity (append and rotation are range-guarded)
+        FA_CHECK(p.seqlen_ro >= p.seqlen_k, "rotary_cos / rotary_sin must cover the cache capacity (seqlen_ro >= seqlen_k)");
     }
     if (p.num_splits < 0) return fail(FA_ERR_INVALID_ARGUMENT, "num_splits must be >= 0");
     // reference: fused_mha_forward_kvcache.cu:465-472
@@ -218,6 +230,7 @@ int fa_fwd_kvcache(const fa_params* pp, void* stream) {
     a.seqlen_k_add = p.seqlen_new;
     a.kv_batch_idx = p.cache_batch_idx;
     a.leftpad_k = p.cache_leftpad;
+    a.kv_mode = 1;
     rc = fa::launch_decode(a, s);
     if (rc == -2) return fail(FA_ERR_UNSUPPORTED, "no kvcache kernel for this configuration (fp8 caches need T_q * H_q/H_k <= 32, no ALiBi/softcap)");
     if (rc == -1) return fail(FA_ERR_INVALID_ARGUMENT, "workspace too small: query fa_fwd_kvcache_workspace_bytes()");
@@ -252,10 +265,21 @@ int fa_varlen_bwd(const fa_params* pp, void* stream) {
     FA_CHECK(p.dout && p.dq && p.dk && p.dv && p.softmax_d, "dout, dq, dk, dv, softmax_d must not be NULL");
     FA_CHECK(p.cu_seqlens_q && p.cu_seqlens_k, "cu_seqlens_q and cu_seqlens_k are required");
     FA_CHECK(p.kv_dtype == p.dtype, "k/v must have the same dtype as q");
-    if (p.total_q == 0) return FA_OK;
+    if (p.total_q == 0) {
+        // no query rows: nothing flows into K / V - the gradients are zeros, written here (not left to the caller)
+        const int64_t rows = p.total_k;
+        const size_t width = (size_t)(p.head_dim_v > 0 ? p.head_dim_v : p.head_dim) * 2;
+        hipStream_t s = static_cast<hipStream_t>(stream);
+        for (int h = 0; h < p.nheads_k && rows > 0; ++h) {
+            if (hipMemset2DAsync(reinterpret_cast<uint16_t*>(p.dk) + (int64_t)h * p.dk_head_stride, (size_t)p.dk_row_stride * 2, 0, width, (size_t)rows, s) != hipSuccess ||
+                hipMemset2DAsync(reinterpret_cast<uint16_t*>(p.dv) + (int64_t)h * p.dv_head_stride, (size_t)p.dv_row_stride * 2, 0, width, (size_t)rows, s) != hipSuccess)
+                return fail(FA_ERR_LAUNCH, "hipMemset2DAsync(dk / dv) failed");
+        }
+        return FA_OK;
+    }
     normalize(p, false);
     fa::KArgs a = make_args(p, 128);
-    if (!getenv("FA_VARLEN_GRID")) {                      // flat work lists (fa_common.h: decode_work_flat)
+    if (!varlen_grid_env()) {                      // flat work lists (fa_common.h: decode_work_flat)
         a.flat_blocks = p.total_q / 128 + p.batch;
         a.pair_qblocks = 0;
         a.n_qblocks = a.n_qblocks_total;

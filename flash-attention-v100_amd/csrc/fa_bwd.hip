@@ -1659,7 +1659,11 @@ __global__ void __launch_bounds__(BWD_THREADS, 2) fa_bwd_dq_from_ds_kernel(const
 // the dQ kernel drops from 0.81 to 0.53 ms, but writing the tiles costs the one-wave-per-SIMD dK/dV
 // kernel +0.29 ms (1.55 -> 1.84 ms; store issue is fully exposed there) - a wash that costs 4.3 GB.
 size_t bwd_workspace_bytes(const fa_params& p) {
+#ifdef FA_MEASURE
     static const double max_gb = getenv("FA_BWD_DS_MAX_GB") ? atof(getenv("FA_BWD_DS_MAX_GB")) : 0.0;
+#else
+    constexpr double max_gb = 0.0;                       // the hand-off is a measured net loss: measurement builds only
+#endif
     if (p.head_dim > 128 || max_gb <= 0.0) return 0;
     const int64_t nqb = (p.seqlen_q + 31) / 32, nkb = (p.seqlen_k + 31) / 32;
     const int64_t per_head = nqb * nkb * 2048;
@@ -1673,7 +1677,11 @@ extern "C" int fa_debug_read_timers(unsigned long long* out, int n) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_timers), (size_t)n * 8);
 }
 #endif
-int g_bwd_phase_mask = 7;     // fa_debug_set_bwd_phases(): measurement aid
+#ifdef FA_MEASURE
+int g_bwd_phase_mask = 7;     // fa_debug_set_bwd_phases(): measurement builds only (-DFA_MEASURE)
+#else
+constexpr int g_bwd_phase_mask = 7;
+#endif
 
 template <typename T, int D>
 static int launch_bwd_td(const KArgs& a, hipStream_t stream) {
@@ -1700,11 +1708,15 @@ static int launch_bwd_td(const KArgs& a, hipStream_t stream) {
 #define FA_LAUNCH_DKV(BIAS, DROP)                                                                                 \
         do {                                                                                                      \
             auto kern = fa_bwd_dkdv_kernel<T, D, BIAS, DROP>;                                                     \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
+            FA_SET_LDS_ONCE(kern, smem); \
             hipLaunchKernelGGL(kern, dim3(grid), dim3(BWD_THREADS), smem, stream, a);                             \
         } while (0)
         // two-workgroups-per-CU kernel where it applies (6 % faster at config 2); FA_DKDV1 forces the other one
+#ifdef FA_MEASURE
         static const bool dkv2_env = getenv("FA_DKDV1") == nullptr;
+#else
+        constexpr bool dkv2_env = true;
+#endif
         bool done = false;
         if constexpr (D <= 128) {
             const bool cap_only = p.softcap > 0.f && !p.alibi_slopes;
@@ -1719,7 +1731,7 @@ static int launch_bwd_td(const KArgs& a, hipStream_t stream) {
 #define FA_LAUNCH_DKV2(BIAS, DROP)                                                                                \
                 do {                                                                                              \
                     auto kern = fa_bwd_dkdv2_kernel<T, D, BIAS, DROP>;                                            \
-                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2); \
+                    FA_SET_LDS_ONCE(kern, smem2); \
                     hipLaunchKernelGGL(kern, dim3(grid2), dim3(BWD_THREADS), smem2, stream, a2);                  \
                 } while (0)
                 if (a.has_bias && lin_alibi) FA_LAUNCH_DKV2(2, false);
@@ -1743,7 +1755,7 @@ static int launch_bwd_td(const KArgs& a, hipStream_t stream) {
             const int grid = work_grid(p.batch, p.nheads_q, p.nheads_k, a.n_qblocks);
             const size_t smem = DqdsSmem<D>::TOTAL;
             auto kern = fa_bwd_dq_from_ds_kernel<T, D>;
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            FA_SET_LDS_ONCE(kern, smem);
             if (grid > 0) hipLaunchKernelGGL(kern, dim3(grid), dim3(BWD_THREADS), smem, stream, a);
         }
     } else if (g_bwd_phase_mask & 4) {
@@ -1755,7 +1767,7 @@ static int launch_bwd_td(const KArgs& a, hipStream_t stream) {
         do {                                                                                                      \
             /* dropout needs the Philox registers: two waves per SIMD spill 84 of them (4.0 ms), one wave none */ \
             auto kern = fa_bwd_dq_kernel<T, D, BIAS, (DROP) ? 1 : OCC, DROP>;                                     \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
+            FA_SET_LDS_ONCE(kern, smem); \
             hipLaunchKernelGGL(kern, dim3(grid), dim3(BWD_THREADS), smem, stream, a);                             \
         } while (0)
         if (grid > 0) {

@@ -295,6 +295,17 @@ static inline int work_grid(int batch, int nheads_q, int nheads_k, int n_qblocks
     return 8 * upx * (nheads_q / nheads_k) * n_qblocks;
 }
 
+// Raise a kernel's dynamic-LDS limit ONCE per instantiation (the static lives in the expansion site, which sits in a
+// per-instantiation template function), not on every launch.
+#define FA_SET_LDS_ONCE(kern, bytes)                                                                              \
+    do {                                                                                                          \
+        static bool fa_attr_done_ = false;                                                                        \
+        if (!fa_attr_done_) {                                                                                     \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)); \
+            fa_attr_done_ = true;                                                                                 \
+        }                                                                                                         \
+    } while (0)
+
 // Host-side launch args: the ABI struct plus derived values.
 struct KArgs {
     fa_params p;
@@ -311,6 +322,8 @@ struct KArgs {
     int seqlen_k_add;              // added to seqlens_k[b] (kvcache: T_new)
     const int32_t* kv_batch_idx;   // cache_batch_idx or NULL
     const int32_t* leftpad_k;      // or NULL
+    int kv_mode;                   // kv-cache call: seqlens_k == NULL means "the cache is empty" (keys = the new rows only),
+                                   // as in the reference (fused_mha_forward_kvcache.cu:85) and oracle/kvcache.py
     // backward: dS hand-off from the dK/dV kernel to the dQ kernel (NULL: dQ recomputes S and dP)
     void* ds_ws;                   // [B, Hq, ds_nqb, ds_nkb][2 KiB]: one 32-query x 32-key dS tile each
     int ds_nqb, ds_nkb;            // ceil(seqlen_q / 32), ceil(seqlen_k / 32)
@@ -365,7 +378,7 @@ __device__ __forceinline__ u32x4 alibi_lane_operand(int lane, float sv, float po
 // kOobVoff, an offset the buffer descriptor's range check turns into zeros (slices are < 2 GiB then, so
 // voffset + soffset cannot wrap), and is never stored.
 constexpr uint32_t kOobVoff = 0x80000000u;
-__device__ __forceinline__ int valid_cols(const fa_params& p) { return p.head_dim_v > 0 ? p.head_dim_v : p.head_dim; }
+__host__ __device__ __forceinline__ int valid_cols(const fa_params& p) { return p.head_dim_v > 0 ? p.head_dim_v : p.head_dim; }
 
 // One 32 x 32 (query, key) sub-tile holds at least one visible pair.  The dK/dV kernel writes a dS
 // tile exactly when this is true and the dQ kernel reads exactly those tiles.

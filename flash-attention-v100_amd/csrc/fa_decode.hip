@@ -124,7 +124,7 @@ __global__ void __launch_bounds__(DEC_THREADS, 1) fa_decode_kernel(const DecArgs
             u32x4 x = {0, 0, 0, 0};
             if (row_ok) {
                 x = *reinterpret_cast<const u32x4*>(qrow + d_base);
-                if (p.rotary_dim > 0 && d_base < p.rotary_dim) {
+                if (p.rotary_dim > 0 && d_base < p.rotary_dim && pos >= 0 && pos < p.seqlen_ro) {
                     u32x4 xp = x;
                     if (!p.rotary_interleaved) {
                         const int pd = d_base < half ? d_base + half : d_base - half;
@@ -464,7 +464,7 @@ __global__ void __launch_bounds__(256) decode_combine_kernel(const DecArgs da) {
 bool decode_applicable(const fa_params& p) {
     if (p.alibi_slopes || p.softcap > 0.f) return false;
     const int G = p.nheads_q / p.nheads_k;
-    return p.seqlen_q * G <= 32 && (p.head_dim == 64 || p.head_dim == 128);
+    return p.seqlen_q * G <= 32 && (p.head_dim == 64 || p.head_dim == 128) && p.head_dim_v == 0;
 }
 
 int decode_num_splits(const fa_params& p) {
@@ -493,7 +493,7 @@ static int launch_decode_td(DecArgs& da, hipStream_t stream) {
 #define FA_LAUNCH_DEC(KV8, PAGED)                                                                                   \
     do {                                                                                                            \
         auto kern = fa_decode_kernel<T, D, KV8, PAGED>;                                                             \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
+        FA_SET_LDS_ONCE(kern, smem); \
         hipLaunchKernelGGL(kern, grid, dim3(DEC_THREADS), smem, stream, da);                                        \
     } while (0)
     if (kv8) { if (paged) FA_LAUNCH_DEC(true, true); else FA_LAUNCH_DEC(true, false); }

@@ -88,6 +88,8 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : FA_FWD_OCC)) fa_fw
         const int su = a.seqlens_k[w.b] + a.seqlen_k_add;
         if (p.cu_seqlens_k) seqlen_k = su > 0 ? (su < seqlen_k ? su : seqlen_k) : 0;   // seqused_k
         else seqlen_k = su;                                                             // kv cache
+    } else if (a.kv_mode) {
+        seqlen_k = a.seqlen_k_add;                                                      // kv cache without cache_seqlens
     }
     if (a.kv_batch_idx) kv_b = a.kv_batch_idx[w.b];
     if (a.leftpad_k) k_row0 += a.leftpad_k[w.b];
@@ -585,8 +587,12 @@ static int launch_fwd_td(const KArgs& a, bool paged, hipStream_t stream) {
 #define FA_LAUNCH(BIAS, PAGED, DROP)                                                            \
     do {                                                                                        \
         auto kern = fa_fwd_kernel<T, D, BIAS, PAGED, DROP>;                                     \
-        hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                \
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);             \
+        static bool attr_done = false;             /* once per instantiation */                \
+        if (!attr_done) {                                                                       \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                      \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);   \
+            attr_done = true;                                                                   \
+        }                                                                                       \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(FWD_THREADS), smem, stream, a);               \
     } while (0)
     const bool drop = a.p.p_dropout > 0.f;

@@ -40,7 +40,7 @@ __device__ __forceinline__ u32x2 to_fp8x8(const u32x4& x, float inv_descale) {
 template <typename T, bool KV8>
 __global__ void __launch_bounds__(256) kv_append_kernel(const KArgs a) {
     const fa_params& p = a.p;
-    const int cpr = p.head_dim / 8;
+    const int cpr = valid_cols(p) / 8;
     const int64_t total = (int64_t)p.batch * p.seqlen_new * p.nheads_k * cpr;
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
@@ -52,6 +52,7 @@ __global__ void __launch_bounds__(256) kv_append_kernel(const KArgs a) {
     const int L = p.cache_seqlens ? p.cache_seqlens[b] : 0;
     const int lp = p.cache_leftpad ? p.cache_leftpad[b] : 0;
     const int pos = L + lp + r;
+    if (pos < 0 || pos >= p.seqlen_k) return;           // beyond the cache capacity (dense: S_max, paged: table columns x page)
     const int d_base = cc * 8;
     const uint16_t* kn = reinterpret_cast<const uint16_t*>(p.k_new) + (int64_t)b * p.knew_batch_stride +
                          (int64_t)r * p.knew_row_stride + (int64_t)hk * p.knew_head_stride;
@@ -59,7 +60,7 @@ __global__ void __launch_bounds__(256) kv_append_kernel(const KArgs a) {
                          (int64_t)r * p.vnew_row_stride + (int64_t)hk * p.vnew_head_stride;
     u32x4 kx = *reinterpret_cast<const u32x4*>(kn + d_base);
     const u32x4 vx = *reinterpret_cast<const u32x4*>(vn + d_base);
-    if (p.rotary_dim > 0 && d_base < p.rotary_dim) {
+    if (p.rotary_dim > 0 && d_base < p.rotary_dim && pos < p.seqlen_ro) {
         const int half = p.rotary_dim >> 1;
         u32x4 kp = kx;
         if (!p.rotary_interleaved) {
@@ -96,7 +97,7 @@ __global__ void __launch_bounds__(256) kv_append_kernel(const KArgs a) {
 template <typename T>
 __global__ void __launch_bounds__(256) q_rope_kernel(const KArgs a, uint16_t* out, int local) {
     const fa_params& p = a.p;
-    const int cpr = p.head_dim / 8;
+    const int cpr = valid_cols(p) / 8;
     const int64_t total = (int64_t)p.batch * p.seqlen_q * p.nheads_q * cpr;
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
@@ -112,7 +113,7 @@ __global__ void __launch_bounds__(256) q_rope_kernel(const KArgs a, uint16_t* ou
     const uint16_t* qr = reinterpret_cast<const uint16_t*>(p.q) + (int64_t)b * p.q_batch_stride +
                          (int64_t)i * p.q_row_stride + (int64_t)h * p.q_head_stride;
     u32x4 x = *reinterpret_cast<const u32x4*>(qr + d_base);
-    if (d_base < p.rotary_dim) {
+    if (d_base < p.rotary_dim && pos >= 0 && pos < p.seqlen_ro) {
         const int half = p.rotary_dim >> 1;
         u32x4 xp = x;
         if (!p.rotary_interleaved) {
@@ -129,7 +130,7 @@ __global__ void __launch_bounds__(256) q_rope_kernel(const KArgs a, uint16_t* ou
 size_t decode_workspace_bytes(const fa_params& p) {
     if (decode_applicable(p)) return decode_split_workspace_bytes(p);
     size_t bytes = 0;
-    if (p.rotary_dim > 0) bytes += (size_t)p.batch * p.seqlen_q * p.nheads_q * p.head_dim * 2;
+    if (p.rotary_dim > 0) bytes += (size_t)p.batch * p.seqlen_q * p.nheads_q * valid_cols(p) * 2;
     return bytes;
 }
 
@@ -141,7 +142,7 @@ int launch_decode(const KArgs& a_in, hipStream_t stream) {
     const bool fast = decode_applicable(p);
     if (kv8 && !fast) return -2;                         // fp8 cache is served by the decode kernel only
     if (p.k_new) {
-        const int64_t total = (int64_t)p.batch * p.seqlen_new * p.nheads_k * (p.head_dim / 8);
+        const int64_t total = (int64_t)p.batch * p.seqlen_new * p.nheads_k * (valid_cols(p) / 8);
         const int grid = (int)((total + 255) / 256);
         if (kv8) {
             if (bf) hipLaunchKernelGGL((kv_append_kernel<bf16_tag, true>), dim3(grid), dim3(256), 0, stream, a);
@@ -161,13 +162,13 @@ int launch_decode(const KArgs& a_in, hipStream_t stream) {
         if (!p.workspace || p.workspace_bytes < need) return -1;
         uint16_t* qrot = reinterpret_cast<uint16_t*>(p.workspace);
         const int local = (p.is_causal || p.window_left >= 0 || p.window_right >= 0) ? 1 : 0;
-        const int64_t total = (int64_t)p.batch * p.seqlen_q * p.nheads_q * (p.head_dim / 8);
+        const int64_t total = (int64_t)p.batch * p.seqlen_q * p.nheads_q * (valid_cols(p) / 8);
         const int grid = (int)((total + 255) / 256);
         if (bf) hipLaunchKernelGGL(q_rope_kernel<bf16_tag>, dim3(grid), dim3(256), 0, stream, a, qrot, local);
         else    hipLaunchKernelGGL(q_rope_kernel<fp16_tag>, dim3(grid), dim3(256), 0, stream, a, qrot, local);
         p.q = qrot;
-        p.q_head_stride = p.head_dim;
-        p.q_row_stride = (int64_t)p.nheads_q * p.head_dim;
+        p.q_head_stride = valid_cols(p);
+        p.q_row_stride = (int64_t)p.nheads_q * valid_cols(p);
         p.q_batch_stride = (int64_t)p.seqlen_q * p.q_row_stride;
     }
     return launch_fwd(a, stream);

@@ -65,9 +65,13 @@ def _scatter_rows(values: torch.Tensor, indices: torch.Tensor, n_rows: int, sort
     return out
 
 
-def _is_sorted_unique(indices: torch.Tensor) -> bool:
-    """Indices produced by unpad_input (nonzero of a mask) are ascending without repeats; they carry a marker so that
-    pad_input can take the one-pass scatter without a device synchronisation."""
+def _is_sorted_unique(indices: torch.Tensor, sorted_unique=None) -> bool:
+    """Ascending indices without repeats let pad_input take the one-pass scatter.  The caller can say so explicitly
+    (`sorted_unique=True/False` on pad_input / index_put_first_axis / index_first_axis); with None the marker that
+    unpad_input leaves on the index tensor it returns is consulted - a copy of that tensor (`.to()`, `.clone()`) has no
+    marker and takes the general two-pass path, which is always correct."""
+    if sorted_unique is not None:
+        return bool(sorted_unique)
     return bool(getattr(indices, "_fa_sorted_unique", False))
 
 
@@ -75,36 +79,38 @@ class IndexFirstAxis(torch.autograd.Function):
     """out[i] = input[indices[i]] along the first axis; backward scatters rows back."""
 
     @staticmethod
-    def forward(ctx, input, indices):
+    def forward(ctx, input, indices, sorted_unique=None):
         ctx.save_for_backward(indices)
         ctx.first_axis_dim = input.shape[0]
-        ctx.sorted_unique = _is_sorted_unique(indices)
+        ctx.sorted_unique = _is_sorted_unique(indices, sorted_unique)
         return _gather_rows(input, indices)
 
     @staticmethod
     def backward(ctx, grad_output):
         (indices,) = ctx.saved_tensors
-        return _scatter_rows(grad_output, indices, ctx.first_axis_dim, ctx.sorted_unique), None
+        return _scatter_rows(grad_output, indices, ctx.first_axis_dim, ctx.sorted_unique), None, None
 
 
-index_first_axis = IndexFirstAxis.apply
+def index_first_axis(input, indices, sorted_unique=None):
+    return IndexFirstAxis.apply(input, indices, sorted_unique)
 
 
 class IndexPutFirstAxis(torch.autograd.Function):
     """out = zeros(first_axis_dim, ...); out[indices] = values."""
 
     @staticmethod
-    def forward(ctx, values, indices, first_axis_dim):
+    def forward(ctx, values, indices, first_axis_dim, sorted_unique=None):
         ctx.save_for_backward(indices)
-        return _scatter_rows(values, indices, first_axis_dim, _is_sorted_unique(indices))
+        return _scatter_rows(values, indices, first_axis_dim, _is_sorted_unique(indices, sorted_unique))
 
     @staticmethod
     def backward(ctx, grad_output):
         (indices,) = ctx.saved_tensors
-        return _gather_rows(grad_output, indices), None, None
+        return _gather_rows(grad_output, indices), None, None, None
 
 
-index_put_first_axis = IndexPutFirstAxis.apply
+def index_put_first_axis(values, indices, first_axis_dim, sorted_unique=None):
+    return IndexPutFirstAxis.apply(values, indices, first_axis_dim, sorted_unique)
 
 
 class IndexFirstAxisResidual(torch.autograd.Function):
@@ -157,7 +163,8 @@ def unpad_input_for_concatenated_sequences(hidden_states, attention_mask_in_leng
             int(seqlens.max().item()))
 
 
-def pad_input(hidden_states, indices, batch, seqlen):
-    """(total_nnz, ...) -> (batch, seqlen, ...) with zeros at the padded positions."""
-    out = index_put_first_axis(hidden_states, indices, batch * seqlen)
+def pad_input(hidden_states, indices, batch, seqlen, *, sorted_unique=None):
+    """(total_nnz, ...) -> (batch, seqlen, ...) with zeros at the padded positions.  sorted_unique=True promises
+    ascending indices without repeats (what unpad_input returns) and selects the one-pass kernel."""
+    out = index_put_first_axis(hidden_states, indices, batch * seqlen, sorted_unique)
     return out.reshape(batch, seqlen, *hidden_states.shape[1:])

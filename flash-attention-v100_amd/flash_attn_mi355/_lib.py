@@ -53,7 +53,7 @@ class FaParams(ctypes.Structure):
     ]
 
 
-EXPORTS = ["fa_debug_set_bwd_phases", "fa_abi_version", "fa_params_size", "fa_last_error", "fa_build_info",
+EXPORTS = ["fa_abi_version", "fa_params_size", "fa_last_error", "fa_build_info",
            "fa_fwd_workspace_bytes", "fa_bwd_workspace_bytes", "fa_fwd_kvcache_workspace_bytes",
            "fa_fwd", "fa_bwd", "fa_varlen_fwd", "fa_varlen_bwd", "fa_fwd_kvcache",
            "fa_gather_rows", "fa_scatter_rows"]

@@ -63,6 +63,44 @@ def _check_device(*tensors):
             raise RuntimeError("flash_attn_mi355: tensors must be on the GPU (no CPU fallback)")
 
 
+def _check_shape(t, shape, name):
+    """CHECK_SHAPE of the reference (kernel/fused_mha_forward.cu:324-340, fused_mha_forward_kvcache.cu:488-598):
+    the C ABI only sees pointers and strides, so a mismatched tensor must be rejected here."""
+    if tuple(t.shape) != tuple(shape):
+        raise RuntimeError(f"{name} must have shape {tuple(shape)}, got {tuple(t.shape)}")
+
+
+def _check_qkv(q, k, v):
+    if q.dtype not in _DTYPES:
+        raise RuntimeError("q must be fp16 or bf16")
+    if k.dtype != q.dtype or v.dtype != q.dtype:
+        raise RuntimeError("k/v must have the same dtype as q")
+    if q.dim() != k.dim() or k.dim() != v.dim():
+        raise RuntimeError("q, k, v must have the same number of dimensions")
+    if q.shape[-1] != k.shape[-1] or q.shape[-1] != v.shape[-1]:
+        raise RuntimeError("q, k, v must have the same head dimension")
+    if q.stride(-1) != 1 or k.stride(-1) != 1 or v.stride(-1) != 1:
+        pass                                             # _prep() makes a contiguous copy
+
+
+def _check_out(out, q):
+    """optional caller-allocated output (reference: fused_mha_forward.cu:392-396)"""
+    if out.dtype != q.dtype:
+        raise RuntimeError("out must have the same dtype as q")
+    if not out.is_cuda:
+        raise RuntimeError("out must be on the GPU")
+    if out.stride(-1) != 1:
+        raise RuntimeError("out must have contiguous last dimension")
+    if tuple(out.shape) != tuple(q.shape):
+        raise RuntimeError("out shape must match q shape")
+
+
+def _usable_out(out, dpad, head_size_og):
+    """a caller-allocated out can be written in place when its rows are 16-byte aligned and unpadded"""
+    return (out is not None and dpad == head_size_og and out.data_ptr() % 16 == 0 and
+            all(st % 8 == 0 for st in out.stride()[:-1]))
+
+
 def _stream(device) -> int:
     return torch.cuda.current_stream(device).cuda_stream
 
@@ -134,20 +172,25 @@ def _base_params(q, dtype, scale, causal, window_size, softcap):
 # DENSE ATTENTION (B, M, H, D)
 # ======================================================================================
 def _dense_forward(q, k, v, dropout_p, softmax_scale, causal, window_size, softcap, alibi_slopes,
-                   return_softmax):
+                   return_softmax, out=None):
     """One fa_fwd call on [B, S, H, D] views (any strides with a contiguous last dim)."""
     _check_device(q, k, v)
-    if q.dtype not in _DTYPES:
-        raise RuntimeError("q must be fp16 or bf16")
+    _check_qkv(q, k, v)
+    if q.dim() != 4:
+        raise RuntimeError("q, k, v must be (batch, seqlen, nheads, headdim)")
     B, M, H_Q, head_size_og = q.shape
     N, H_K = k.shape[1], k.shape[2]
+    _check_shape(k, (B, N, H_K, head_size_og), "k")
+    _check_shape(v, (B, N, H_K, head_size_og), "v")
+    if out is not None:
+        _check_out(out, q)
     dpad = (head_size_og + 7) // 8 * 8
     _padded_head_dim(dpad)                                   # raises above 256
     q_, k_, v_ = _prep(q, dpad), _prep(k, dpad), _prep(v, dpad)
     if softmax_scale is None:
         softmax_scale = head_size_og ** -0.5
 
-    out_ = torch.empty((B, M, H_Q, dpad), dtype=q.dtype, device=q.device)
+    out_ = out if _usable_out(out, dpad, head_size_og) else torch.empty((B, M, H_Q, dpad), dtype=q.dtype, device=q.device)
     lse = torch.empty((B, H_Q, M), dtype=torch.float32, device=q.device)
     p = _base_params(q_, q.dtype, softmax_scale, causal, window_size, softcap)
     p.q, p.k, p.v, p.o, p.lse = _ptr(q_), _ptr(k_), _ptr(v_), _ptr(out_), _ptr(lse)
@@ -166,8 +209,12 @@ def _dense_forward(q, k, v, dropout_p, softmax_scale, causal, window_size, softc
     if q_.numel() > 0:                                   # (an empty query block is a no-op)
         with torch.cuda.device(q.device):
             _lib.call("fa_fwd", p, _stream(q.device))
-    out = out_ if dpad == head_size_og else out_[..., :head_size_og].contiguous()
-    return out, lse, dmask, (q_, k_, v_, out_), rng, softmax_scale
+    if out is not None and out_ is not out:              # caller-allocated out the kernel could not write directly
+        out.copy_(out_[..., :head_size_og])
+        res = out
+    else:
+        res = out_ if dpad == head_size_og else out_[..., :head_size_og].contiguous()
+    return res, lse, dmask, (q_, k_, v_, out_), rng, softmax_scale
 
 
 def _dense_backward(dout, q_, k_, v_, out_, lse, alibi_slopes, dropout_p, softmax_scale, causal,
@@ -331,11 +378,41 @@ def flash_attn_func(q, k, v, dropout_p: float = 0.0, softmax_scale: float = None
 # ======================================================================================
 def _varlen_forward(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, dropout_p,
                     softmax_scale, causal, window_size, softcap, alibi_slopes, return_attn_probs,
-                    block_table):
-    """One fa_varlen_fwd call on [T, H, D] tensors (K/V optionally paged [nblk, page, Hk, D])."""
-    _check_device(q, k, v, cu_seqlens_q, cu_seqlens_k)
+                    block_table, seqused_k=None, leftpad_k=None, zero_tensors=False, out=None):
+    """One fa_varlen_fwd call on [T, H, D] tensors (K/V optionally paged [nblk, page, Hk, D]).
+    seqused_k clamps the keys of each sequence (include/template.h:65-68); zero_tensors pre-fills out / lse / dmask
+    (fused_mha_forward_varlen.cu:538-542); leftpad_k is validated and, like in the reference kernel (the pointer is a
+    parameter that is never read, fused_mha_forward_varlen.cu:37), not applied."""
+    _check_device(q, k, v, cu_seqlens_q, cu_seqlens_k, seqused_k, leftpad_k)
     if q.dtype not in _DTYPES:
         raise RuntimeError("q must be fp16 or bf16")
+    if k.dtype != q.dtype or v.dtype != q.dtype:
+        raise RuntimeError("k/v must have the same dtype as q")
+    if q.dim() != 3:
+        raise RuntimeError("q must be (total_q, nheads, headdim)")
+    if block_table is None:
+        if k.dim() != 3 or v.dim() != 3:
+            raise RuntimeError("k, v must be (total_k, nheads_k, headdim)")
+        _check_shape(v, k.shape, "v")
+    else:
+        if k.dim() != 4 or v.dim() != 4:
+            raise RuntimeError("paged k, v must be (num_blocks, page_block_size, nheads_k, headdim)")
+        _check_shape(v, k.shape, "v")
+        if leftpad_k is not None:
+            raise RuntimeError("Paged KV and leftpad_k are not supported simultaneously")
+    if k.shape[-1] != q.shape[-1]:
+        raise RuntimeError("q, k, v must have the same head dimension")
+    if cu_seqlens_q.dim() != 1 or cu_seqlens_k.dim() != 1 or cu_seqlens_q.numel() != cu_seqlens_k.numel():
+        raise RuntimeError("cu_seqlens_q and cu_seqlens_k must be 1-D of size batch + 1")
+    nb = cu_seqlens_q.numel() - 1
+    for name, t in (("seqused_k", seqused_k), ("leftpad_k", leftpad_k)):
+        if t is not None:
+            if t.dtype != torch.int32:
+                raise RuntimeError(f"{name} must have dtype int32")
+            if t.dim() != 1 or t.numel() != nb or not t.is_contiguous():
+                raise RuntimeError(f"{name} must be 1D, contiguous, with size == batch_size")
+    if block_table is not None and block_table.shape[0] != nb:
+        raise RuntimeError("block_table must have one row per sequence")
     cu_seqlens_q = cu_seqlens_q.to(torch.int32).contiguous()
     cu_seqlens_k = cu_seqlens_k.to(torch.int32).contiguous()
     head_size_og = q.size(-1)
@@ -349,10 +426,16 @@ def _varlen_forward(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqle
     B = cu_seqlens_q.numel() - 1
     paged = block_table is not None
 
-    out_ = torch.empty((T_Q, H_Q, dpad), dtype=q.dtype, device=q.device)
+    if out is not None:
+        _check_out(out, q)
+    out_ = out if _usable_out(out, dpad, head_size_og) else torch.empty((T_Q, H_Q, dpad), dtype=q.dtype, device=q.device)
     lse = torch.empty((H_Q, T_Q), dtype=torch.float32, device=q.device)
+    if zero_tensors:
+        out_.zero_()
+        lse.fill_(float("-inf"))
     p = _base_params(q_, q.dtype, softmax_scale, causal, window_size, softcap)
     p.q, p.k, p.v, p.o, p.lse = _ptr(q_), _ptr(k_), _ptr(v_), _ptr(out_), _ptr(lse)
+    p.seqused_k = _ptr(seqused_k)
     _set3(p, "q", q_, "thd"); _set3(p, "o", out_, "thd")
     _set3(p, "k", k_, "pshd" if paged else "thd"); _set3(p, "v", v_, "pshd" if paged else "thd")
     p.lse_batch_stride, p.lse_head_stride = 0, lse.stride(0)
@@ -376,8 +459,12 @@ def _varlen_forward(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqle
     if q_.numel() > 0:
         with torch.cuda.device(q.device):
             _lib.call("fa_varlen_fwd", p, _stream(q.device))
-    out = out_ if dpad == head_size_og else out_[..., :head_size_og].contiguous()
-    return out, lse, dmask, (q_, k_, v_, out_, cu_seqlens_q, cu_seqlens_k), rng, softmax_scale
+    if out is not None and out_ is not out:
+        out.copy_(out_[..., :head_size_og])
+        res = out
+    else:
+        res = out_ if dpad == head_size_og else out_[..., :head_size_og].contiguous()
+    return res, lse, dmask, (q_, k_, v_, out_, cu_seqlens_q, cu_seqlens_k), rng, softmax_scale
 
 
 def _varlen_backward(dout, q_, k_, v_, out_, lse, cu_seqlens_q, cu_seqlens_k, alibi_slopes,
@@ -458,10 +545,19 @@ def flash_attn_varlen_func(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q: in
                            causal: bool = False, window_size: Tuple[int, int] = (-1, -1),
                            softcap: float = 0.0, alibi_slopes: Optional[torch.Tensor] = None,
                            deterministic: bool = False, return_attn_probs: bool = False,
-                           block_table: Optional[torch.Tensor] = None):
-    """Varlen Flash Attention (T, H, D)"""
+                           block_table: Optional[torch.Tensor] = None, *,
+                           seqused_k: Optional[torch.Tensor] = None):
+    """Varlen Flash Attention (T, H, D).  seqused_k ([B] int32, forward only): use only the first seqused_k[b] keys
+    of sequence b (the op-level argument of the reference, include/mha.h:116-139)."""
     deterministic = _warn_deterministic(deterministic)
     try:
+        if seqused_k is not None:
+            if torch.is_grad_enabled() and any(x.requires_grad for x in (q, k, v)):
+                raise RuntimeError("seqused_k is a forward-only argument (the reference's backward op has none)")
+            out, lse, dmask, _, _, _ = _varlen_forward(
+                q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, dropout_p, softmax_scale, causal,
+                window_size, softcap, alibi_slopes, return_attn_probs, block_table, seqused_k=seqused_k)
+            return (out, lse, dmask) if return_attn_probs else out
         return FlashAttnVarlenFunc.apply(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q,
                                          max_seqlen_k, dropout_p, softmax_scale, causal,
                                          window_size, softcap, alibi_slopes, deterministic,
@@ -506,13 +602,41 @@ def flash_attn_with_kvcache(q, k_cache, v_cache, k=None, v=None, rotary_cos=None
                     ("cache_leftpad", cache_leftpad), ("block_table", block_table)):
         if t is not None and t.dtype != torch.int32:
             raise RuntimeError(f"{name} must have dtype int32")
-    if D not in (64, 128, 256):
-        raise RuntimeError(f"kvcache head dimension {D} has no gfx950 kernel in this build (64, 128, 256)")
+    if D % 8 != 0 or D > 256:
+        raise RuntimeError("kvcache head dimension must be a multiple of 8 and <= 256")
     fp8 = k_cache.dtype == torch.float8_e4m3fn
+    if fp8 and v_cache.dtype != k_cache.dtype:
+        raise RuntimeError("kcache and vcache must have the same dtype")
     if not fp8 and (k_cache.dtype != q.dtype or v_cache.dtype != q.dtype):
         raise RuntimeError("kcache/vcache must have the same dtype as q (or float8_e4m3fn)")
+    if fp8 and D not in (64, 128):
+        raise RuntimeError("fp8 KV caches are served by the decode kernel: head dimension 64 or 128")
     paged = block_table is not None
+    if q.dim() != 4 or k_cache.dim() != 4:
+        raise RuntimeError("q must be (B, T, H, D); k_cache / v_cache 4-D")
     H_K = k_cache.shape[2]
+    # reference: fused_mha_forward_kvcache.cu:488-598 (CHECK_SHAPE)
+    _check_shape(v_cache, k_cache.shape, "v_cache")
+    if k_cache.shape[-1] != D:
+        raise RuntimeError(f"k_cache / v_cache head dimension must be {D}")
+    if H_Q % H_K != 0:
+        raise RuntimeError("H_Q must be divisible by H_K for GQA/MQA")
+    if not paged and cache_batch_idx is None and k_cache.shape[0] < B:
+        raise RuntimeError("k_cache batch is smaller than the query batch")
+    if paged:
+        if block_table.dim() != 2 or block_table.shape[0] != B:
+            raise RuntimeError("block_table must be (batch, max_num_blocks_per_seq)")
+    for name, t in (("cache_seqlens", cache_seqlens), ("cache_batch_idx", cache_batch_idx),
+                    ("cache_leftpad", cache_leftpad)):
+        if t is not None and (t.dim() != 1 or t.numel() != B):
+            raise RuntimeError(f"{name} must be 1D with size == batch_size")
+    if k is not None and v is not None:
+        if k.dtype != q.dtype or v.dtype != q.dtype:
+            raise RuntimeError("k/v (new) must have the same dtype as q")
+        _check_shape(k, (B, k.shape[1], H_K, D), "k")
+        _check_shape(v, k.shape, "v")
+    if rotary_cos is not None and rotary_sin is not None and tuple(rotary_sin.shape) != tuple(rotary_cos.shape):
+        raise RuntimeError("rotary_sin must have the same shape as rotary_cos")
 
     out = torch.empty_like(q)
     lse = torch.empty((B, H_Q, T_Q), dtype=torch.float32, device=q.device)
@@ -526,7 +650,8 @@ def flash_attn_with_kvcache(q, k_cache, v_cache, k=None, v=None, rotary_cos=None
     _set3(p, "k", k_cache, "bshd"); _set3(p, "v", v_cache, "bshd")
     p.lse_batch_stride, p.lse_head_stride = lse.stride(0), lse.stride(1)
     p.batch, p.nheads_q, p.nheads_k = B, H_Q, H_K
-    p.seqlen_q, p.head_dim = T_Q, D
+    p.seqlen_q = T_Q
+    _set_head_dim(p, D)                                  # width 64 / 128 / 256; narrower rows read as zeros past D
     if paged:
         p.block_table = _ptr(block_table)
         p.block_table_batch_stride = block_table.stride(0)

@@ -6,8 +6,11 @@ Counterpart of the reference's TorchBind block (kernel/fused_mha_api.cpp:308-358
 the reference schemas (include/mha.h:27-41, :67-87, :116-139, :170-195, :224-245); the tensor
 LAYOUT is the public Python one - (B, S, H, D) / (T, H, D) - because this build takes strides
 and never permutes ("replicate the Python API, not the alias").
-Optional output arguments of the reference (`out`, `dq`, `dk`, `dv`) are dropped: custom ops
-return fresh tensors.  Every op has a fake (meta) implementation so the path is traceable by
+The optional in-place outputs of the reference (`out` of fwd / varlen_fwd, `dq`, `dk`, `dv` of bwd:
+include/mha.h:31,73-75) live in the separate ops `fwd_out`, `varlen_fwd_out` and `bwd_out`, which MUTATE
+caller-allocated tensors (a torch.library op may not return an alias of an input); the plain ops return fresh
+tensors.  `varlen_fwd` carries the reference's op-level extras `seqused_k`, `leftpad_k`, `zero_tensors`,
+`num_splits` (include/mha.h:116-139).  Every op has a fake (meta) implementation so the path is traceable by
 torch.compile / FakeTensorMode, and `fwd` / `varlen_fwd` carry autograd formulas that call the
 `bwd` ops.
 
@@ -115,18 +118,21 @@ def varlen_fwd(q: Tensor, k: Tensor, v: Tensor, cu_seqlens_q: Tensor, cu_seqlens
                block_table: Optional[Tensor], alibi_slopes: Optional[Tensor], max_seqlen_q: int,
                max_seqlen_k: int, p_dropout: float, softmax_scale: float, is_causal: bool,
                window_size_left: int, window_size_right: int, softcap: float,
-               return_softmax: bool) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
+               return_softmax: bool, seqused_k: Optional[Tensor] = None, leftpad_k: Optional[Tensor] = None,
+               zero_tensors: bool = False, num_splits: int = 0) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
+    if num_splits > 1:
+        raise RuntimeError("num_splits > 1 not supported")          # fused_mha_forward_varlen.cu:422
     out, lse, dmask, _, rng, _ = _fi._varlen_forward(
         q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, p_dropout, softmax_scale,
         is_causal, (window_size_left, window_size_right), softcap, alibi_slopes, return_softmax,
-        block_table)
+        block_table, seqused_k=seqused_k, leftpad_k=leftpad_k, zero_tensors=zero_tensors)
     return out, lse, dmask, _rng_tensor(rng, q.device)
 
 
 @varlen_fwd.register_fake
 def _(q, k, v, cu_seqlens_q, cu_seqlens_k, block_table, alibi_slopes, max_seqlen_q, max_seqlen_k,
       p_dropout, softmax_scale, is_causal, window_size_left, window_size_right, softcap,
-      return_softmax):
+      return_softmax, seqused_k=None, leftpad_k=None, zero_tensors=False, num_splits=0):
     T, H, D = q.shape
     dmask = q.new_empty((T, H, max_seqlen_k) if (return_softmax and p_dropout > 0.0) else (0,))
     return (q.new_empty((T, H, D)), q.new_empty((H, T), dtype=torch.float32), dmask,
@@ -167,9 +173,11 @@ def _(dout, q, k, v, out, softmax_lse, cu_seqlens_q, cu_seqlens_k, alibi_slopes,
 
 def _varlen_setup(ctx, inputs, output):
     (q, k, v, cu_q, cu_k, block_table, alibi_slopes, max_q, max_k, p_dropout, softmax_scale,
-     is_causal, wl, wr, softcap, _) = inputs
+     is_causal, wl, wr, softcap, _, seqused_k, _leftpad, _zero, _splits) = inputs
     if block_table is not None:
         raise RuntimeError("backward through paged K/V (block_table) is not supported")
+    if seqused_k is not None:
+        raise RuntimeError("seqused_k is a forward-only argument (the reference's varlen_bwd has none)")
     out, lse, _, rng_state = output
     ctx.save_for_backward(q, k, v, out, lse, cu_q, cu_k, rng_state, alibi_slopes)
     ctx.args = (max_q, max_k, p_dropout, softmax_scale, is_causal, wl, wr, softcap)
@@ -180,10 +188,88 @@ def _varlen_backward_formula(ctx, dout, dlse, ddmask, drng):
     max_q, max_k, p_dropout, softmax_scale, is_causal, wl, wr, softcap = ctx.args
     dq, dk, dv, _ = varlen_bwd(dout, q, k, v, out, lse, cu_q, cu_k, alibi_slopes, max_q, max_k,
                                p_dropout, softmax_scale, is_causal, wl, wr, softcap, False, rng_state)
-    return (dq, dk, dv) + (None,) * 13
+    return (dq, dk, dv) + (None,) * 17
 
 
 varlen_fwd.register_autograd(_varlen_backward_formula, setup_context=_varlen_setup)
+
+
+# ------------------------------------------------------------------------------------------
+# in-place forms: the reference's optional `out` / `dq` / `dk` / `dv` arguments (include/mha.h:31,73-75)
+# ------------------------------------------------------------------------------------------
+@torch.library.custom_op(f"{_NS}::fwd_out", mutates_args=("out",), device_types="cuda")
+def fwd_out(q: Tensor, k: Tensor, v: Tensor, out: Tensor, alibi_slopes: Optional[Tensor], p_dropout: float,
+            softmax_scale: float, is_causal: bool, window_size_left: int, window_size_right: int,
+            softcap: float, return_softmax: bool) -> Tuple[Tensor, Tensor, Tensor]:
+    """writes `out` (shape / dtype of q, contiguous last dim); returns (softmax_lse, dmask, rng_state)"""
+    _, lse, dmask, _, rng, _ = _fi._dense_forward(
+        q, k, v, p_dropout, softmax_scale, is_causal, (window_size_left, window_size_right), softcap,
+        alibi_slopes, return_softmax, out=out)
+    return lse, dmask, _rng_tensor(rng, q.device)
+
+
+@fwd_out.register_fake
+def _(q, k, v, out, alibi_slopes, p_dropout, softmax_scale, is_causal, window_size_left, window_size_right,
+      softcap, return_softmax):
+    B, M, H, _ = q.shape
+    dmask = q.new_empty((B, H, M, k.shape[1]) if (return_softmax and p_dropout > 0.0) else (0,))
+    return q.new_empty((B, H, M), dtype=torch.float32), dmask, q.new_empty((2,), dtype=torch.int64)
+
+
+@torch.library.custom_op(f"{_NS}::varlen_fwd_out", mutates_args=("out",), device_types="cuda")
+def varlen_fwd_out(q: Tensor, k: Tensor, v: Tensor, out: Tensor, cu_seqlens_q: Tensor, cu_seqlens_k: Tensor,
+                   seqused_k: Optional[Tensor], leftpad_k: Optional[Tensor], block_table: Optional[Tensor],
+                   alibi_slopes: Optional[Tensor], max_seqlen_q: int, max_seqlen_k: int, p_dropout: float,
+                   softmax_scale: float, zero_tensors: bool, is_causal: bool, window_size_left: int,
+                   window_size_right: int, softcap: float, return_softmax: bool) -> Tuple[Tensor, Tensor, Tensor]:
+    """the reference's argument order (include/mha.h:116-139) with a caller-allocated `out`"""
+    _, lse, dmask, _, rng, _ = _fi._varlen_forward(
+        q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, p_dropout, softmax_scale,
+        is_causal, (window_size_left, window_size_right), softcap, alibi_slopes, return_softmax,
+        block_table, seqused_k=seqused_k, leftpad_k=leftpad_k, zero_tensors=zero_tensors, out=out)
+    return lse, dmask, _rng_tensor(rng, q.device)
+
+
+@varlen_fwd_out.register_fake
+def _(q, k, v, out, cu_seqlens_q, cu_seqlens_k, seqused_k, leftpad_k, block_table, alibi_slopes, max_seqlen_q,
+      max_seqlen_k, p_dropout, softmax_scale, zero_tensors, is_causal, window_size_left, window_size_right,
+      softcap, return_softmax):
+    T, H, _ = q.shape
+    dmask = q.new_empty((T, H, max_seqlen_k) if (return_softmax and p_dropout > 0.0) else (0,))
+    return q.new_empty((H, T), dtype=torch.float32), dmask, q.new_empty((2,), dtype=torch.int64)
+
+
+@torch.library.custom_op(f"{_NS}::bwd_out", mutates_args=("dq", "dk", "dv"), device_types="cuda")
+def bwd_out(dout: Tensor, q: Tensor, k: Tensor, v: Tensor, out: Tensor, softmax_lse: Tensor,
+            dq: Tensor, dk: Tensor, dv: Tensor, alibi_slopes: Optional[Tensor], p_dropout: float,
+            softmax_scale: float, is_causal: bool, window_size_left: int, window_size_right: int,
+            softcap: float, deterministic: bool, rng_state: Optional[Tensor]) -> Tensor:
+    """writes caller-allocated dq / dk / dv (shapes of q / k / v); returns softmax_d"""
+    d = q.shape[-1]
+    dpad = (d + 7) // 8 * 8
+    for name, g, ref in (("dq", dq, q), ("dk", dk, k), ("dv", dv, v)):
+        if g.dtype != ref.dtype or tuple(g.shape) != tuple(ref.shape) or g.stride(-1) != 1:
+            raise RuntimeError(f"{name} must have the dtype and shape of its input and a contiguous last dimension")
+    q_, k_, v_, out_ = (_fi._prep(t, dpad) for t in (q, k, v, out))
+    direct = dpad == d and all(t.data_ptr() % 16 == 0 and all(st % 8 == 0 for st in t.stride()[:-1]) for t in (dq, dk, dv))
+    if direct:
+        dq_, dk_, dv_ = dq, dk, dv
+    else:
+        dq_, dk_, dv_ = (_fi._prep(torch.empty_like(t), dpad) for t in (q_, k_, v_))
+    softmax_d = _fi._dense_backward(dout, q_, k_, v_, out_, softmax_lse, alibi_slopes, p_dropout,
+                                    softmax_scale, is_causal, (window_size_left, window_size_right),
+                                    softcap, _rng_tuple(rng_state) if p_dropout > 0.0 else (0, 0),
+                                    dq_, dk_, dv_)
+    if not direct:
+        dq.copy_(dq_[..., :d]); dk.copy_(dk_[..., :d]); dv.copy_(dv_[..., :d])
+    return softmax_d
+
+
+@bwd_out.register_fake
+def _(dout, q, k, v, out, softmax_lse, dq, dk, dv, alibi_slopes, p_dropout, softmax_scale, is_causal,
+      window_size_left, window_size_right, softcap, deterministic, rng_state):
+    B, M, H, _ = q.shape
+    return q.new_empty((B, H, M), dtype=torch.float32)
 
 
 # ------------------------------------------------------------------------------------------
@@ -214,4 +300,4 @@ def _(q, kcache, vcache, k, v, seqlens_k, rotary_cos, rotary_sin, cache_batch_id
     return torch.empty_like(q), q.new_empty((B, H, T), dtype=torch.float32)
 
 
-__all__ = ["fwd", "bwd", "varlen_fwd", "varlen_bwd", "fwd_kvcache"]
+__all__ = ["fwd", "bwd", "varlen_fwd", "varlen_bwd", "fwd_kvcache", "fwd_out", "varlen_fwd_out", "bwd_out"]

@@ -152,10 +152,11 @@ size_t      fa_params_size(void);
 const char* fa_last_error(void);
 const char* fa_build_info(void);           /* arch, compiler, kernel variants */
 
-/* Measurement aid (bench.py / rocprof only): select which backward phases fa_bwd /
- * fa_varlen_bwd launch - bit 0 preprocess, bit 1 dK/dV, bit 2 dQ.  Default 7 (all).
- * Process-wide; not part of the operator contract. */
+#ifdef FA_MEASURE
+/* Measurement builds only (-DFA_MEASURE, tools/): select which backward phases fa_bwd / fa_varlen_bwd launch -
+ * bit 0 preprocess, bit 1 dK/dV, bit 2 dQ.  Process-wide; NOT part of the product ABI. */
 void fa_debug_set_bwd_phases(int mask);
+#endif
 
 /* Workspace queries (bytes; 0 = none needed). */
 size_t fa_fwd_workspace_bytes(const fa_params* p);

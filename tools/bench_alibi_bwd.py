@@ -1,4 +1,5 @@
 """Causal ALiBi vs no bias, fwd and bwd kernels (bf16 B8 H16 S4096 D128)."""
+# needs a measurement build of the library: python flash-attention-v100_amd/build.py --variant m.so FA_MEASURE ; FA_MI355_LIB=m.so
 import os, sys
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, os.path.join(ROOT, "flash-attention-v100_amd")); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))

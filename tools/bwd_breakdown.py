@@ -1,4 +1,5 @@
 """Per-kernel backward times for a dense shape: python tools/bwd_breakdown.py B S H D [causal]"""
+# needs a measurement build of the library: python flash-attention-v100_amd/build.py --variant m.so FA_MEASURE ; FA_MI355_LIB=m.so
 import os, sys
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, os.path.join(ROOT, "flash-attention-v100_amd")); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))

@@ -1,4 +1,5 @@
 """Per-kernel times of BASELINE config 3 (varlen, window (512,0), D 64) + dense equivalents for comparison."""
+# needs a measurement build of the library: python flash-attention-v100_amd/build.py --variant m.so FA_MEASURE ; FA_MI355_LIB=m.so
 import os, sys
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, os.path.join(ROOT, "flash-attention-v100_amd")); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
