@@ -11,16 +11,21 @@ convention: fwd = 4*B*H*S*S*D/2 (causal), bwd = 2.5 x fwd.
   python bench.py --gpus N --steps K --warmup W
 N > 1 is launched by the driver through torch.distributed.run (one rank per GPU); the
 path shards batch x heads with no collective, so every rank runs the full per-GPU workload
-(weak scaling) and the only distributed calls are the timing barrier and a MAX over ranks.
+(weak scaling, `value`) and the only distributed calls are the timing barrier and a MAX over ranks.
 
 Besides the contract fields the JSON line carries
-  roofline      - the dominant kernel of the step (by measured launch duration), its
-                  ALGORITHMIC FLOPs per launch / that duration vs the 2.5 PFLOP/s dense
-                  bf16 MFMA peak; durations measured here with HIP events on the stream the
-                  kernels run on (torch's current stream);
-  kernels       - the same for every kernel of the step (fwd, bwd dK/dV, bwd dQ, preprocess);
-  cpu_baseline  - the oracle (numpy fp64 restatement of the reference algorithm) on the host
-                  cores (rank 0, N = 1 only), bounded sample of the same workload.
+  roofline        - the dominant kernel of the step (by measured launch duration), its ALGORITHMIC FLOPs per launch /
+                    that duration vs the 2.5 PFLOP/s dense bf16 MFMA peak; durations measured here with HIP events on
+                    the stream the kernels run on (torch's current stream).  `traffic` is NOT measured in this run: it
+                    is the HBM byte count of the committed rocprofv3 PMC passes (`traffic_source` names the file);
+  kernels         - the same for every kernel of the step (fwd, bwd dK/dV, bwd dQ, preprocess);
+  other_configs   - BASELINE configs 3, 4 (fp8 and fp16 KV) and the config-5 shard, measured in the same run (rank 0);
+  strong_scaling_config5 - BASELINE configs[4]: dense fwd bf16 causal + ALiBi, B64 H32 S8192 D128 with the 32 heads
+                    sharded over the N ranks (flash_attn_mi355.sharding.shard_units / shard_alibi): total TFLOP/s at
+                    this N - the 1/2/4/8 curve north_star asks for comes from the driver's runs at each N;
+  cpu_baseline    - the reference's CPU comparator, PyTorch SDPA on the host cores of this box
+                    (rank 0, N = 1 only), on the largest batch x heads sample of config 2 that fits ~12 s; the numpy fp64
+                    oracle port is timed next to it (`oracle_port_tflops`).
 """
 import argparse
 import json
@@ -36,6 +41,7 @@ for _p in (ROOT, os.path.join(ROOT, "flash-attention-v100_amd")):
 import torch  # noqa: E402
 
 PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (MI355X_MICROARCH.md: ~2.5 PF dense)
+PEAK_HBM_GBS = 8000.0
 CFG = dict(batch=8, nheads=16, nheads_k=16, seqlen=4096, head_dim=128, causal=True)
 
 
@@ -44,11 +50,12 @@ def fwd_flops(c):
     return f * (0.5 if c["causal"] else 1.0)
 
 
-def event_time_ms(fn, iters):
+def event_time_ms(fn, iters, warm=1):
     """Average duration of `fn` (kernel launches only) over `iters` back-to-back calls."""
     s = torch.cuda.Event(enable_timing=True)
     e = torch.cuda.Event(enable_timing=True)
-    fn()
+    for _ in range(warm):
+        fn()
     torch.cuda.synchronize()
     s.record()
     for _ in range(iters):
@@ -58,22 +65,14 @@ def event_time_ms(fn, iters):
     return s.elapsed_time(e) / iters
 
 
-def cpu_baseline(c, budget_s=15.0):
-    """The oracle (oracle/attention.py: the numpy fp64 restatement of the reference algorithm,
-    fwd + bwd) timed on the host cores on a bounded sample of the workload: 1 batch x 1 head
-    of S4096 D128 causal per repetition, for ~budget_s seconds.  numpy's BLAS supplies the
-    threading.  The torch-SDPA CPU path (bf16) is timed next to it for orientation."""
+# ------------------------------------------------------------------------------------------------ CPU baseline
+def _oracle_port_tflops(c, budget_s):
     import numpy as np
     from oracle import attention as oa
     B, H, S, D = 1, 1, c["seqlen"], c["head_dim"]
     rng = np.random.default_rng(421)
     q, k, v, do = (rng.standard_normal((B, H, S, D)) for _ in range(4))
     scale = D ** -0.5
-    try:
-        from threadpoolctl import threadpool_info
-        cores = max([i.get("num_threads", 1) for i in threadpool_info()] or [1])
-    except Exception:
-        cores = os.cpu_count() or 1
 
     def ostep():
         o, lse, _ = oa.attn_fwd(q, k, v, scale, causal=True)
@@ -88,32 +87,60 @@ def cpu_baseline(c, budget_s=15.0):
         el = time.perf_counter() - t0
         if el > budget_s or n >= 50:
             break
-    flops = 3.5 * 4.0 * B * H * S * S * D * 0.5
-    res = {"value": round(flops * n / el / 1e12, 5), "unit": "TFLOP/s", "cores": cores, "kind": "port",
-           "sample": f"oracle (numpy fp64) fwd+bwd causal B{B} H{H} S{S} D{D}, {n} reps in {el:.1f}s"}
+    return 3.5 * 4.0 * B * H * S * S * D * 0.5 * n / el / 1e12, f"oracle (numpy fp64) fwd+bwd causal B{B} H{H} S{S} D{D}, {n} reps in {el:.1f}s"
 
-    # orientation only: PyTorch's own CPU attention in bf16 on the same shape family
-    Bt, Ht = 1, 2
-    g = torch.Generator().manual_seed(421)
-    tq, tk, tv, tdo = (torch.randn(Bt, Ht, S, D, generator=g).to(torch.bfloat16) for _ in range(4))
-    tq.requires_grad_(True); tk.requires_grad_(True); tv.requires_grad_(True)
 
-    def tstep():
-        o = torch.nn.functional.scaled_dot_product_attention(tq, tk, tv, is_causal=True)
-        o.backward(tdo)
-        tq.grad = tk.grad = tv.grad = None
+def cpu_baseline(c, budget_s=12.0):
+    """PyTorch SDPA on the host cores (the reference's CPU comparator): bf16 fwd+bwd causal at
+    config 2's S / D, batch x heads grown from B1 H2 until one step takes ~budget_s / 3 (at most the full B8 H16)."""
+    S, D = c["seqlen"], c["head_dim"]
+    threads = torch.get_num_threads()
 
-    tstep()
+    def make(B, H):
+        g = torch.Generator().manual_seed(421)
+        t = [torch.randn(B, H, S, D, generator=g).to(torch.bfloat16) for _ in range(4)]
+        for x in t[:3]:
+            x.requires_grad_(True)
+        return t
+
+    def step(t):
+        o = torch.nn.functional.scaled_dot_product_attention(t[0], t[1], t[2], is_causal=True)
+        o.backward(t[3])
+        t[0].grad = t[1].grad = t[2].grad = None
+
+    B, H = 1, 2
+    t = make(B, H)
+    step(t)
+    t0 = time.perf_counter()
+    step(t)
+    one = time.perf_counter() - t0
+    # grow the sample (heads first, then batch) while a step stays under budget_s / 3
+    while True:
+        nb, nh = (B, H * 2) if H < c["nheads"] else (B * 2, H)
+        if nb > c["batch"] or one * (nb * nh) / (B * H) > budget_s / 3:
+            break
+        B, H = nb, nh
+        t = make(B, H)
+        t0 = time.perf_counter()
+        step(t)
+        one = time.perf_counter() - t0
     t0 = time.perf_counter()
     n = 0
     while True:
-        tstep()
+        step(t)
         n += 1
         el = time.perf_counter() - t0
-        if el > budget_s / 3 or n >= 100:
+        if el > budget_s * 0.6 or n >= 100:
             break
-    res["torch_sdpa_cpu_tflops"] = round(3.5 * 4.0 * Bt * Ht * S * S * D * 0.5 * n / el / 1e12, 4)
-    res["torch_sdpa_cpu_threads"] = torch.get_num_threads()
+    flops = 3.5 * 4.0 * B * H * S * S * D * 0.5
+    full = (B == c["batch"] and H == c["nheads"])
+    res = {"value": round(flops * n / el / 1e12, 4), "unit": "TFLOP/s", "cores": threads, "kind": "reference",
+           "sample": f"torch.nn.functional.scaled_dot_product_attention on CPU, bf16 fwd+bwd causal B{B} H{H} S{S} D{D} "
+                     f"({'the full config-2 batch' if full else 'a batch x heads sample of config 2'}), {n} steps in {el:.1f}s, "
+                     f"{threads} threads of {os.cpu_count()} logical cores"}
+    op, sample = _oracle_port_tflops(c, budget_s * 0.25)
+    res["oracle_port_tflops"] = round(op, 5)
+    res["oracle_port_sample"] = sample
     return res
 
 
@@ -133,12 +160,97 @@ def measured_traffic(kernel):
     return best
 
 
+# ------------------------------------------------------------------------------------------------ other configs
+def config3(flash_attn, dev):
+    """varlen fp16, B64 mixed seqlens (max 2048), H32 D64, window (512, 0)"""
+    g = torch.Generator().manual_seed(421)
+    B, H, D, W = 64, 32, 64, 512
+    lens = torch.randint(64, 2049, (B,), generator=g)
+    lens[0] = 2048
+    cu = torch.zeros(B + 1, dtype=torch.int32)
+    cu[1:] = lens.cumsum(0)
+    T = int(cu[-1])
+    cu = cu.to(dev)
+    gq = torch.Generator().manual_seed(422)
+    q, k, v, do = (torch.randn(T, H, D, generator=gq).to(torch.float16).to(dev) for _ in range(4))
+    q.requires_grad_(True); k.requires_grad_(True); v.requires_grad_(True)
+
+    def pairs(L):
+        return L * (L + 1) // 2 if L <= W + 1 else (W + 1) * (W + 2) // 2 + (L - W - 1) * (W + 1)
+
+    flops = 4.0 * D * H * sum(pairs(int(L)) for L in lens)
+    fwd = lambda: flash_attn.flash_attn_varlen_func(q, k, v, cu, cu, 2048, 2048, causal=True, window_size=(W, 0))
+
+    def fb():
+        o = fwd()
+        o.backward(do)
+        q.grad = k.grad = v.grad = None
+
+    with torch.no_grad():
+        t_f = event_time_ms(fwd, 10, warm=3)
+    t_fb = event_time_ms(fb, 10, warm=3)
+    return {"workload": "varlen fp16 B64 mixed seqlens (max 2048) H32 D64 window (512,0)", "total_tokens": T,
+            "fwd_ms": round(t_f, 4), "fwd_tflops": round(flops / t_f / 1e9, 1),
+            "fwd_frac_of_mfma_peak": round(flops / t_f / 1e9 / PEAK_BF16_TFLOPS, 4),
+            "fwd_bwd_ms": round(t_fb, 4), "fwd_bwd_tflops": round(3.5 * flops / t_fb / 1e9, 1)}
+
+
+def config4(flash_attn, dev, kv_dtype):
+    """decode B128 H32 D128 cache 8192 paged(256) + rotary; K+V bytes read once / time"""
+    B, H, Hk, D, L, page = 128, 32, 32, 128, 8192, 256
+    dt = torch.float16
+    g = torch.Generator().manual_seed(421)
+    pps = (L + 1 + page - 1) // page
+    nblk = B * pps
+    mk = lambda *s: torch.randn(*s, generator=g, dtype=torch.float32)
+    if kv_dtype == torch.float8_e4m3fn:
+        kc = (torch.randn(nblk, page, Hk, D, device=dev, dtype=dt) * 0.5).to(kv_dtype)
+        vc = (torch.randn(nblk, page, Hk, D, device=dev, dtype=dt) * 0.5).to(kv_dtype)
+        kw = dict(k_descale=1.0, v_descale=1.0)
+    else:
+        kc = torch.randn(nblk, page, Hk, D, device=dev, dtype=dt)
+        vc = torch.randn(nblk, page, Hk, D, device=dev, dtype=dt)
+        kw = {}
+    bt = torch.randperm(nblk, device=dev).reshape(B, pps).to(torch.int32)
+    q, kn, vn = mk(B, 1, H, D).to(dt).to(dev), mk(B, 1, Hk, D).to(dt).to(dev), mk(B, 1, Hk, D).to(dt).to(dev)
+    seqlens = torch.full((B,), L, dtype=torch.int32, device=dev)
+    ang = torch.arange(pps * page + 8, device=dev)[:, None] * (1.0 / 10000 ** (torch.arange(0, D, 2, device=dev) / D))[None]
+    cos, sin = torch.cos(ang).to(dt), torch.sin(ang).to(dt)
+    fn = lambda: flash_attn.flash_attn_with_kvcache(q, kc, vc, k=kn, v=vn, rotary_cos=cos, rotary_sin=sin,
+                                                    cache_seqlens=seqlens, block_table=bt, causal=True,
+                                                    rotary_interleaved=False, **kw)
+    ms = event_time_ms(fn, 10, warm=3)
+    nbytes = 2.0 * B * (L + 1) * Hk * D * kc.element_size()
+    return {"workload": f"decode B128 H32 D128 cache 8192 paged(256)+rotary, KV {'fp8-e4m3' if kc.element_size() == 1 else 'fp16'}",
+            "ms": round(ms, 4), "kv_bytes": int(nbytes), "achieved_gbs": round(nbytes / ms / 1e6, 1),
+            "frac_of_hbm_peak": round(nbytes / ms / 1e6 / PEAK_HBM_GBS, 4)}
+
+
+def config5(flash_attn, dev, world, rank, iters=3, warm=2):
+    """dense fwd bf16 causal + ALiBi, B64 S8192 D128, 32 heads sharded over `world` ranks (this rank's heads)"""
+    from flash_attn_mi355.sharding import shard_alibi, shard_units
+    B, Htot, S, D = 64, 32, 8192, 128
+    bs, qh, kh = shard_units(B, Htot, Htot, world, rank)
+    slopes_all = torch.tensor([2.0 ** (-8.0 * (h + 1) / Htot) for h in range(Htot)], dtype=torch.float32, device=dev)
+    sl = shard_alibi(slopes_all, qh, bs)
+    Bs, Hs = bs.stop - bs.start, qh.stop - qh.start
+    g = torch.Generator(device="cpu").manual_seed(421 + rank)
+    mk = lambda: torch.randn(Bs, S, Hs, D, generator=g, dtype=torch.float32).to(torch.bfloat16).to(dev)
+    q, k, v = mk(), mk(), mk()
+    fn = lambda: flash_attn.flash_attn_func(q, k, v, causal=True, alibi_slopes=sl)
+    with torch.no_grad():
+        ms = event_time_ms(fn, iters, warm=warm)
+    flops = 4.0 * Bs * Hs * S * S * D / 2
+    return ms, flops, Bs, Hs
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -155,7 +267,7 @@ def main():
     dev = torch.device("cuda", local_rank if world > 1 else 0)
 
     import flash_attn
-    from flash_attn_mi355 import _lib
+    from flash_attn_mi355 import flash_attn_interface as fi
 
     c = CFG
     B, H, Hk, S, D = c["batch"], c["nheads"], c["nheads_k"], c["seqlen"], c["head_dim"]
@@ -193,6 +305,25 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = world * step_flops / (elapsed / args.steps) / 1e12
 
+    # ---- strong scaling, BASELINE configs[4]: every rank takes 32 / N heads of all 64 batches ----------------------
+    strong = None
+    if not args.no_other_configs:
+        del q, k, v, do
+        torch.cuda.empty_cache()
+        ms5, fl5, Bs, Hs = config5(flash_attn, dev, world, rank)
+        barrier()
+        t5 = torch.tensor([ms5], device=dev, dtype=torch.float64)
+        if dist is not None:
+            dist.all_reduce(t5, op=dist.ReduceOp.MAX)
+        ms5max = float(t5.item())
+        total5 = 4.0 * 64 * 32 * 8192 * 8192 * 128 / 2
+        strong = {"workload": "dense fwd bf16 causal + ALiBi B64 H32 S8192 D128, heads sharded over the ranks (BASELINE configs[4])",
+                  "n_gpus": world, "batch_per_gpu": Bs, "heads_per_gpu": Hs, "ms": round(ms5max, 4),
+                  "tflops_total": round(total5 / ms5max / 1e9, 1),
+                  "frac_of_mfma_peak": round(total5 / ms5max / 1e9 / (world * PEAK_BF16_TFLOPS), 4), "scaling": "strong"}
+        q, k, v, do = mk(H), mk(Hk), mk(Hk), mk(H)
+        q.requires_grad_(True); k.requires_grad_(True); v.requires_grad_(True)
+
     out = None
     if rank == 0:
         # ---- per-kernel durations (HIP events on the launch stream) --------------------
@@ -206,9 +337,8 @@ def main():
 
         kern = {}
         for name, mask in (("bwd_preprocess", 1), ("bwd_dkdv", 2), ("bwd_dq", 4), ("bwd_all", 7)):
-            _lib.lib.fa_debug_set_bwd_phases(mask)
-            kern[name] = event_time_ms(bwd_only, it)
-        _lib.lib.fa_debug_set_bwd_phases(7)
+            with fi.bwd_phases(mask):               # per call, through fa_params::bwd_phases
+                kern[name] = event_time_ms(bwd_only, it)
         pairs_flops = ff / 2.0            # one GEMM over the visible pairs = 2*D*pairs
         # algorithmic FLOPs: fwd 2 GEMMs; bwd 5 GEMMs split as dK/dV kernel 4 (S, dP, dV, dK)
         # and dQ kernel 1 (its S/dP recomputation is overhead, not algorithmic work).
@@ -223,7 +353,8 @@ def main():
         kernels["bwd_all"] = {"ms": round(kern["bwd_all"], 4),
                               "achieved": round(2.5 * ff / (kern["bwd_all"] * 1e-3) / 1e12, 1)}
         dom = max(("fwd", "bwd_dkdv", "bwd_dq"), key=lambda n: dur[n])
-        roofline = {"bound": "mfma", "kernel": {"fwd": "fa_fwd_kernel", "bwd_dkdv": "fa_bwd_dkdv2_kernel",
+        fwd_kernel = "fa_fwd_ws_kernel" if os.environ.get("FA_FWD_WS") == "1" else "fa_fwd_asm_kernel"
+        roofline = {"bound": "mfma", "kernel": {"fwd": fwd_kernel, "bwd_dkdv": "fa_bwd_dkdv2_kernel",
                                                   "bwd_dq": "fa_bwd_dq_kernel"}[dom],
                     "achieved": kernels[dom]["achieved"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                     "frac": kernels[dom]["frac"], "traffic": None}
@@ -231,7 +362,7 @@ def main():
         if tr:
             roofline["traffic"] = tr[0]
             roofline["traffic_unit"] = "bytes of HBM per launch (FETCH_SIZE x2 + WRITE_SIZE)"
-            roofline["traffic_source"] = tr[1]
+            roofline["traffic_source"] = f"NOT measured in this run: committed rocprofv3 PMC passes, {tr[1]}"
         out = {
             "metric": "attention TFLOPS fwd+bwd (seqlen 4096, hd128, causal)",
             "value": round(value, 2), "unit": "TFLOP/s", "n_gpus": world, "steps": args.steps,
@@ -244,6 +375,23 @@ def main():
             "fwd_tflops": kernels["fwd"]["achieved"], "fwd_frac_of_mfma_peak": kernels["fwd"]["frac"],
             "roofline": roofline, "kernels": kernels,
         }
+        if strong is not None:
+            out["strong_scaling_config5"] = strong
+        if not args.no_other_configs:
+            del q, k, v, do, o
+            torch.cuda.empty_cache()
+            oc = {"config3": config3(flash_attn, dev)}
+            torch.cuda.empty_cache()
+            oc["config4_fp8_kv"] = config4(flash_attn, dev, torch.float8_e4m3fn)
+            torch.cuda.empty_cache()
+            oc["config4_fp16_kv"] = config4(flash_attn, dev, torch.float16)
+            torch.cuda.empty_cache()
+            if world == 1:
+                ms, fl, Bs, Hs = config5(flash_attn, dev, 8, 0)
+                oc["config5_shard_1_of_8"] = {"workload": "dense fwd bf16 causal + ALiBi, one GPU's shard of 8: B64 H4 (of 32) S8192 D128",
+                                              "ms": round(ms, 4), "tflops": round(fl / ms / 1e9, 1),
+                                              "frac_of_mfma_peak": round(fl / ms / 1e9 / PEAK_BF16_TFLOPS, 4)}
+            out["other_configs"] = oc
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(c)
     if dist is not None:

@@ -25,9 +25,6 @@ int launch_kvcache_append(const KArgs& a, hipStream_t stream);
 int launch_decode(const KArgs& a, hipStream_t stream);
 size_t decode_workspace_bytes(const fa_params& p);
 bool decode_applicable(const fa_params& p);
-#ifdef FA_MEASURE
-extern int g_bwd_phase_mask;
-#endif
 }  // namespace fa
 
 static thread_local std::string g_last_error;
@@ -135,9 +132,7 @@ const char* fa_build_info(void) {
            "ops fwd/bwd/varlen_fwd/varlen_bwd/fwd_kvcache";
 }
 
-#ifdef FA_MEASURE
-void fa_debug_set_bwd_phases(int mask) { fa::g_bwd_phase_mask = mask; }      // measurement builds only (tools/)
-#endif
+
 size_t fa_fwd_workspace_bytes(const fa_params*) { return 0; }
 size_t fa_bwd_workspace_bytes(const fa_params* p) { return p ? fa::bwd_workspace_bytes(*p) : 0; }
 size_t fa_fwd_kvcache_workspace_bytes(const fa_params* p) { return p ? fa::decode_workspace_bytes(*p) : 0; }

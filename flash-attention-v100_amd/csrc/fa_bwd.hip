@@ -1677,15 +1677,12 @@ extern "C" int fa_debug_read_timers(unsigned long long* out, int n) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_timers), (size_t)n * 8);
 }
 #endif
-#ifdef FA_MEASURE
-int g_bwd_phase_mask = 7;     // fa_debug_set_bwd_phases(): measurement builds only (-DFA_MEASURE)
-#else
-constexpr int g_bwd_phase_mask = 7;
-#endif
+
 
 template <typename T, int D>
 static int launch_bwd_td(const KArgs& a, hipStream_t stream) {
     const fa_params& p = a.p;
+    const int g_bwd_phase_mask = p.bwd_phases ? p.bwd_phases : 7;      // per call (fa_params::bwd_phases)
     // 1. preprocess
     if (g_bwd_phase_mask & 1) {
         const int cpr = D / 8, rows_per_block = 256 / cpr;

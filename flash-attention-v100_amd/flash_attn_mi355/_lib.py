@@ -48,7 +48,7 @@ class FaParams(ctypes.Structure):
         ("rotary_cos", _ptr), ("rotary_sin", _ptr),
         ("rotary_interleaved", _i32), ("seqlen_ro", _i32),
         ("k_descale", _f32), ("v_descale", _f32),
-        ("num_splits", _i32), ("_pad1", _i32),
+        ("num_splits", _i32), ("bwd_phases", _i32),
         ("workspace", _ptr), ("workspace_bytes", ctypes.c_size_t),
     ]
 

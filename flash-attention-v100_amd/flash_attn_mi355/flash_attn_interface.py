@@ -25,6 +25,28 @@ from ._lib import FaParams
 
 _DTYPES = {torch.float16: _lib.FA_FP16, torch.bfloat16: _lib.FA_BF16}
 
+import contextlib
+
+
+class _Measure:
+    bwd_phases = 0          # process-wide on the PYTHON side only (autograd runs backward on its own thread);
+                            # the library itself takes the mask per call (fa_params::bwd_phases)
+
+
+_TLS = _Measure
+
+
+@contextlib.contextmanager
+def bwd_phases(mask: int):
+    """Measurement aid (bench.py, tools/): inside the block the backward ops launch only the selected kernels
+    (bit 0 preprocess, bit 1 dK/dV, bit 2 dQ)."""
+    old = _Measure.bwd_phases
+    _Measure.bwd_phases = int(mask)
+    try:
+        yield
+    finally:
+        _Measure.bwd_phases = old
+
 
 def maybe_contiguous(x):
     return x.contiguous() if x is not None and not x.is_contiguous() else x
@@ -165,6 +187,7 @@ def _base_params(q, dtype, scale, causal, window_size, softcap):
     p.is_causal = int(bool(causal))
     p.window_left, p.window_right = int(window_size[0]), int(window_size[1])
     p.k_descale = p.v_descale = 1.0
+    p.bwd_phases = getattr(_TLS, "bwd_phases", 0)
     return p
 
 

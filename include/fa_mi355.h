@@ -141,7 +141,9 @@ typedef struct fa_params {
 
     /* ---- split-KV (decode) ---- */
     int32_t num_splits;             /* 0 = heuristic, 1 = no split */
-    int32_t _pad1;
+    int32_t bwd_phases;             /* fa_bwd / fa_varlen_bwd: 0 = all; else bit 0 preprocess, bit 1 dK/dV, bit 2 dQ
+                                       (per call, for per-kernel timing by bench.py; partial masks leave the
+                                       skipped outputs untouched) */
     void*   workspace;              /* >= fa_*_workspace_bytes(params) bytes, or NULL if 0 */
     size_t  workspace_bytes;
 } fa_params;
@@ -152,11 +154,6 @@ size_t      fa_params_size(void);
 const char* fa_last_error(void);
 const char* fa_build_info(void);           /* arch, compiler, kernel variants */
 
-#ifdef FA_MEASURE
-/* Measurement builds only (-DFA_MEASURE, tools/): select which backward phases fa_bwd / fa_varlen_bwd launch -
- * bit 0 preprocess, bit 1 dK/dV, bit 2 dQ.  Process-wide; NOT part of the product ABI. */
-void fa_debug_set_bwd_phases(int mask);
-#endif
 
 /* Workspace queries (bytes; 0 = none needed). */
 size_t fa_fwd_workspace_bytes(const fa_params* p);

@@ -1,5 +1,4 @@
 """softcap (Gemma-2 style) vs plain causal: forward and backward kernels (bf16 B8 H16 S4096 D128)."""
-# needs a measurement build of the library: python flash-attention-v100_amd/build.py --variant m.so FA_MEASURE ; FA_MI355_LIB=m.so
 import os, sys
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, os.path.join(ROOT, "flash-attention-v100_amd")); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
@@ -15,7 +14,7 @@ for cap in (0.0, 0.0, 50.0):
     o = flash_attn.flash_attn_func(q, k, v, causal=True, softcap=cap)
     res = {}
     for nm, mask in (("dkdv", 2), ("dq", 4), ("all", 7)):
-        _lib.lib.fa_debug_set_bwd_phases(mask)
+        _fi._TLS.__setattr__("bwd_phases", mask)
         res[nm] = timeit(lambda: torch.autograd.grad(o, (q, k, v), do, retain_graph=True), iters=5)
-    _lib.lib.fa_debug_set_bwd_phases(7)
+    _fi._TLS.__setattr__("bwd_phases", 7)
     print(f"softcap={cap}: fwd {tf:.3f} | dkdv {res['dkdv']:.3f} dq {res['dq']:.3f} bwd {res['all']:.3f} ms", flush=True)

@@ -1,5 +1,4 @@
 """Per-kernel backward times for a dense shape: python tools/bwd_breakdown.py B S H D [causal]"""
-# needs a measurement build of the library: python flash-attention-v100_amd/build.py --variant m.so FA_MEASURE ; FA_MI355_LIB=m.so
 import os, sys
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, os.path.join(ROOT, "flash-attention-v100_amd")); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
@@ -15,6 +14,6 @@ with torch.no_grad():
 o = flash_attn.flash_attn_func(q, k, v, causal=True)
 res = {}
 for nm, mask in (("pre", 1), ("dkdv", 2), ("dq", 4), ("all", 7)):
-    _lib.lib.fa_debug_set_bwd_phases(mask)
+    _fi._TLS.__setattr__("bwd_phases", mask)
     res[nm] = timeit(lambda: torch.autograd.grad(o, (q, k, v), do, retain_graph=True), iters=5)
 print(f"B{B} S{S} H{H} D{D}: fwd {tf:.3f} ms ({fl/tf/1e9:.0f} TF) | pre {res['pre']:.3f} dkdv {res['dkdv']:.3f} ({2*fl/res['dkdv']/1e9:.0f} TF) dq {res['dq']:.3f} ({0.5*fl/res['dq']/1e9:.0f} TF alg) all {res['all']:.3f}")
