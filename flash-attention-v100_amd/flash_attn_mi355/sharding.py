@@ -57,3 +57,41 @@ def merge_attention_shards(outs, lses):
     w = w / torch.where(den > 0, den, torch.ones_like(den))
     out = sum(o.float() * w[i].transpose(1, 2).unsqueeze(-1) for i, o in enumerate(outs))
     return out.to(outs[0].dtype), tot
+
+
+def context_parallel_attention(q, k_shard, v_shard, group=None, causal=False, softmax_scale=None, attn_fn=None):
+    """Attention over keys / values that are SHARDED along the sequence across the ranks of `group`
+    (context parallelism; the consumers SURVEY.md section 8(f) row 4 cites: flash_attn_interface.py:129-131,
+    utils/benchmarks/benchmark_unsloth.py:19-39).
+
+    Every rank holds all queries `q` (B, Sq, H, D) and one contiguous, equally sized shard of the keys / values
+    `k_shard`, `v_shard` (B, Sk / N, Hk, D), rank r owning keys [r Sk/N, (r+1) Sk/N).  Each rank runs ONE local
+    attention call, the partial (out, lse) pairs are all-gathered (the only collective; RCCL over xGMI under the
+    "nccl" backend) and merged with merge_attention_shards.  causal=True is the bottom-right aligned causal mask of
+    the GLOBAL problem: in rank r's local coordinates that is a right window of (N - 1 - r) Sk/N keys, which the
+    kernels take as window_size=(-1, wr) - no mask tensor is ever built.
+
+    attn_fn(q, k, v, window_size, softmax_scale) -> (out, lse) replaces the local attention call (tests on CPU);
+    the default is flash_attn_func(..., return_attn_probs=True).  Returns (out, lse) of the full problem on every rank.
+    Forward only (inference / evaluation use; a training-time ring would interleave the exchange with the backward)."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    skl = k_shard.shape[1]
+    window = (-1, (world - 1 - rank) * skl) if causal else (-1, -1)
+    if attn_fn is None:
+        from .flash_attn_interface import flash_attn_func
+
+        def attn_fn(q_, k_, v_, window_size, scale):
+            o, lse, _ = flash_attn_func(q_, k_, v_, softmax_scale=scale, causal=False, window_size=window_size,
+                                        return_attn_probs=True)
+            return o, lse
+    out, lse = attn_fn(q, k_shard, v_shard, window, softmax_scale)
+    if world == 1:
+        return out, lse
+    outs = [torch.empty_like(out) for _ in range(world)]
+    lses = [torch.empty_like(lse) for _ in range(world)]
+    dist.all_gather(outs, out.contiguous(), group=group)
+    dist.all_gather(lses, lse.contiguous(), group=group)
+    return merge_attention_shards(outs, lses)

@@ -368,3 +368,27 @@ def test_rope_append_and_paged_gather_independent_pins(interleaved):
                 pr = torch.softmax(s, 0)
                 ref = pr @ vg[:n_vis, h // 2]
                 assert (out[b, t_, h].cpu().double() - ref).abs().max() <= 4e-3, (b, t_, h)
+
+
+# ------------------------------------------------------------------------------------------------ context parallel
+@pytest.mark.parametrize("causal", [False, True])
+def test_context_parallel_two_shards_on_one_gpu(causal):
+    """the per-rank calls of context_parallel_attention (local attention over a key shard with the shifted causal
+    window) + merge_attention_shards, both shards on one GPU: equals attention over all keys"""
+    from flash_attn_mi355.sharding import merge_attention_shards
+    fa = _fa()
+    dt = "bf16"
+    B, Sq, Sk, H, Hk, D, N = 2, 512, 1024, 4, 2, 128, 2
+    q = rand16((B, Sq, H, D), dt, 1); k = rand16((B, Sk, Hk, D), dt, 2); v = rand16((B, Sk, Hk, D), dt, 3)
+    skl = Sk // N
+    outs, lses = [], []
+    for r in range(N):
+        window = (-1, (N - 1 - r) * skl) if causal else (-1, -1)
+        o, lse, _ = fa.flash_attn_func(q, k[:, r * skl:(r + 1) * skl], v[:, r * skl:(r + 1) * skl], causal=False,
+                                       window_size=window, return_attn_probs=True)
+        outs.append(o); lses.append(lse)
+    out, lse = merge_attention_shards(outs, lses)
+    t = lambda x: f64(x).transpose(0, 2, 1, 3)
+    o_ref, lse_ref, _ = oracle.attn_fwd(t(q), t(k), t(v), D ** -0.5, causal=causal)
+    assert_close(t(out), o_ref, dt, "out", mult=1.5)
+    assert_lse_close(f64(lse), lse_ref, "lse", atol=1e-4)

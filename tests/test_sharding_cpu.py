@@ -91,3 +91,54 @@ def test_merge_attention_shards_matches_full_attention():
     out, lse = merge_attention_shards(outs, lses)
     assert np.allclose(out.permute(0, 2, 1, 3).numpy(), o_ref, atol=1e-5)
     assert np.allclose(lse.numpy(), lse_ref, atol=1e-5)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# context parallelism: keys / values sharded along the sequence, (out, lse) all-gathered and merged
+# ---------------------------------------------------------------------------------------------------------
+def _torch_attn(q, k, v, window, scale):
+    """test-local stand-in for the GPU kernel (the product has no CPU path): fp64 attention with a right window,
+    bottom-right aligned like the kernels; returns (out, lse)."""
+    B, Sq, H, D = q.shape
+    Sk, Hk = k.shape[1], k.shape[2]
+    scale = D ** -0.5 if scale is None else scale
+    qf = q.double().permute(0, 2, 1, 3)
+    kf = k.double().permute(0, 2, 1, 3).repeat_interleave(H // Hk, 1)
+    vf = v.double().permute(0, 2, 1, 3).repeat_interleave(H // Hk, 1)
+    s = qf @ kf.transpose(-1, -2) * scale
+    if window[1] >= 0:
+        i = torch.arange(Sq)[:, None]; j = torch.arange(Sk)[None, :]
+        s = s.masked_fill(j > i + (Sk - Sq) + window[1], float("-inf"))
+    lse = torch.logsumexp(s, -1)
+    p = torch.nan_to_num(torch.exp(s - lse[..., None]), nan=0.0)
+    return (p @ vf).permute(0, 2, 1, 3).contiguous(), lse.float()
+
+
+def _cp_worker(rank, world, port, q, k, v, causal, out_file):
+    from flash_attn_mi355.sharding import context_parallel_attention
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    skl = k.shape[1] // world
+    ks, vs = k[:, rank * skl:(rank + 1) * skl], v[:, rank * skl:(rank + 1) * skl]
+    out, lse = context_parallel_attention(q, ks, vs, causal=causal, attn_fn=_torch_attn)
+    if rank == 1:                                   # any rank holds the full result
+        torch.save({"out": out, "lse": lse}, out_file)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("causal", [False, True])
+def test_context_parallel_attention_two_ranks(tmp_path, causal):
+    torch.manual_seed(1)
+    B, Sq, Sk, H, Hk, D, world = 2, 40, 96, 4, 2, 16, 2
+    q = torch.randn(B, Sq, H, D); k = torch.randn(B, Sk, Hk, D); v = torch.randn(B, Sk, Hk, D)
+    out_file = str(tmp_path / "cp.pt")
+    mp.spawn(_cp_worker, args=(world, _free_port(), q, k, v, causal, out_file), nprocs=world, join=True)
+    res = torch.load(out_file)
+    o_ref, lse_ref = _torch_attn(q, k, v, (-1, 0) if causal else (-1, -1), None)
+    assert (res["out"].double() - o_ref).abs().max() < 2e-6          # the merge runs in fp32
+    assert (res["lse"].double() - lse_ref.double()).abs().max() < 1e-5
+    # and against the oracle (independent of the stand-in)
+    t = lambda x: x.double().numpy().transpose(0, 2, 1, 3)
+    o2, lse2, _ = oracle.attn_fwd(t(q), t(k), t(v), D ** -0.5, causal=causal)
+    assert np.abs(res["out"].double().numpy().transpose(0, 2, 1, 3) - o2).max() < 2e-6
