@@ -460,6 +460,209 @@ __global__ void __launch_bounds__(256) decode_combine_kernel(const DecArgs da) {
     if (cc == 0) p.lse[b * p.lse_batch_stride + (int64_t)hq * p.lse_head_stride + t] = den > 0.f ? m + __logf(den) : -INFINITY;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// fp8 KV, ONE query row per kv-head (T_q = 1, H_q == H_k: BASELINE config 4): streaming matrix-vector kernel.
+//
+// With a single query row the 32-row MFMA tile of fa_decode_kernel carries one useful column, and its fp8 path
+// pays a dequantise + DOUBLED LDS round trip per byte (3.8 TB/s).  Here nothing touches
+// LDS or the matrix pipe: 8 lanes own one key (16 fp8 bytes = 16 head-dim columns each), a wave instruction
+// streams 8 keys (8 x 128 contiguous bytes), q . k is 16 FMAs per lane + a 3-step DPP sum over the 8 lanes,
+// P V is 16 more FMAs into per-lane partial outputs; the 8 key groups of a wave keep their own (m, l, o)
+// and merge once at the end (LDS), like split-KV.  VALU work: ~1.8 lane-instructions per byte, < 25 % of
+// the vector rate at 5 TB/s - the kernel is bound by how 128-byte rows stream from HBM (tools/decode_rowsize_probe.py).
+// k_descale folds into the softmax scale, v_descale into the final normalisation; RoPE on q as in fa_decode_kernel.
+// ---------------------------------------------------------------------------------------------
+constexpr int GEMV_THREADS = 256;
+constexpr int GEMV_KEYS = 32;                  // keys per wave step: 4 loads x 8 keys (x K and V)
+
+__device__ __forceinline__ float grp8_sum(float x) {
+    // sum over the 8 consecutive lanes of a key group: xor 1, xor 2 (quad permutes), then the other quad (half-row mirror)
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xf, 0xf, false));
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xf, 0xf, false));
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xf, 0xf, false));
+    return x;
+}
+
+template <typename T, bool PAGED>
+__global__ void __launch_bounds__(GEMV_THREADS) fa_decode_gemv_fp8_kernel(const DecArgs da) {
+    using E = Elem<T>;
+    constexpr int D = 128;
+    __shared__ float red[32 * (D + 2)];                     // 4 waves x 8 key groups: o[128], m, l
+
+    const KArgs& a = da.a;
+    const fa_params& p = a.p;
+    const int unit = blockIdx.x, split = blockIdx.y;
+    const int b = unit / p.nheads_k, hk = unit - b * p.nheads_k;
+    const int tid = threadIdx.x, lane = tid & 63, grp = lane >> 3, sub = lane & 7;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    const int L = p.cache_seqlens ? p.cache_seqlens[b] : 0;
+    const int lp = p.cache_leftpad ? p.cache_leftpad[b] : 0;
+    const int cb = p.cache_batch_idx ? p.cache_batch_idx[b] : b;
+    const int seqlen_k = L + p.seqlen_new;
+    const int off = seqlen_k - 1;                           // T_q == 1: the row sits at the bottom-right corner
+    const int wl = p.window_left;
+    const int wr = p.is_causal ? 0 : p.window_right;
+    int lo = 0, hi = seqlen_k - 1;
+    if (wr >= 0) { const int h2 = off + wr; hi = h2 < hi ? h2 : hi; }
+    if (wl >= 0) { const int l2 = off - wl; lo = l2 > lo ? l2 : lo; }
+
+    // ---- q: this lane's 16 columns, RoPE as in fa_decode_kernel, rounded to the io type, then x scale ----
+    float qs[16];
+    {
+        const int h = hk;                                   // G == 1
+        const uint16_t* qrow = reinterpret_cast<const uint16_t*>(p.q) + (int64_t)b * p.q_batch_stride + (int64_t)h * p.q_head_stride;
+        const int half = p.rotary_dim >> 1;
+        const int pos = L + lp;
+        const uint16_t* cosp = reinterpret_cast<const uint16_t*>(p.rotary_cos) + (int64_t)pos * half;
+        const uint16_t* sinp = reinterpret_cast<const uint16_t*>(p.rotary_sin) + (int64_t)pos * half;
+        const float c = a.scale_log2e * p.k_descale;
+#pragma unroll
+        for (int cpart = 0; cpart < 2; ++cpart) {
+            const int d_base = 16 * sub + 8 * cpart;
+            u32x4 x = *reinterpret_cast<const u32x4*>(qrow + d_base);
+            if (p.rotary_dim > 0 && d_base < p.rotary_dim && pos >= 0 && pos < p.seqlen_ro) {
+                u32x4 xp = x;
+                if (!p.rotary_interleaved) {
+                    const int pd = d_base < half ? d_base + half : d_base - half;
+                    xp = *reinterpret_cast<const u32x4*>(qrow + pd);
+                }
+                rope_chunk<T>(x, xp, cosp, sinp, d_base, p.rotary_dim, p.rotary_interleaved != 0);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { qs[8 * cpart + 2 * i] = E::lo(x[i]) * c; qs[8 * cpart + 2 * i + 1] = E::hi(x[i]) * c; }
+        }
+    }
+
+    // ---- key range of this split; the 4 waves take alternate 32-key steps ----
+    const int step_lo = lo / GEMV_KEYS, step_hi = hi >= lo ? hi / GEMV_KEYS + 1 : step_lo;
+    const int n_all = step_hi - step_lo;
+    const int per_split = ((n_all + da.n_splits - 1) / da.n_splits + 3) & ~3;
+    const int s_lo = step_lo + split * per_split;
+    int s_hi = s_lo + per_split; s_hi = s_hi < step_hi ? s_hi : step_hi;
+
+    const uint8_t* kbase = reinterpret_cast<const uint8_t*>(p.k) + (int64_t)hk * p.k_head_stride + 16 * sub;
+    const uint8_t* vbase = reinterpret_cast<const uint8_t*>(p.v) + (int64_t)hk * p.v_head_stride + 16 * sub;
+    const int32_t* btab = PAGED ? p.block_table + (int64_t)b * p.block_table_batch_stride : nullptr;
+
+    float o[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o[i] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    auto addr = [&](int j, int64_t& ko, int64_t& vo) {
+        const int pos = lp + j;
+        if (PAGED) {
+            const int pg = da.page_shift >= 0 ? (pos >> da.page_shift) : pos / p.page_block_size;
+            const int pr = pos - pg * p.page_block_size;
+            const int64_t phys = btab[pg];
+            ko = phys * p.k_batch_stride + (int64_t)pr * p.k_row_stride;
+            vo = phys * p.v_batch_stride + (int64_t)pr * p.v_row_stride;
+        } else {
+            ko = (int64_t)cb * p.k_batch_stride + (int64_t)pos * p.k_row_stride;
+            vo = (int64_t)cb * p.v_batch_stride + (int64_t)pos * p.v_row_stride;
+        }
+    };
+    auto load_step = [&](int step, u32x4 (&kx)[4], u32x4 (&vx)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int j = step * GEMV_KEYS + 8 * i + grp;
+            const int jc = j < seqlen_k ? j : (seqlen_k > 0 ? seqlen_k - 1 : 0);      // clamp: masked below, never faults
+            int64_t ko, vo;
+            addr(jc, ko, vo);
+            kx[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(kbase + ko));
+            vx[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(vbase + vo));
+        }
+    };
+    auto dot16 = [&](const u32x4& w) {
+        float acc = 0.f;
+#pragma unroll
+        for (int d4 = 0; d4 < 4; ++d4) {
+            const f32x2 a0 = __builtin_amdgcn_cvt_pk_f32_fp8(w[d4], false);
+            const f32x2 a1 = __builtin_amdgcn_cvt_pk_f32_fp8(w[d4], true);
+            acc = fmaf(a0[0], qs[4 * d4 + 0], acc); acc = fmaf(a0[1], qs[4 * d4 + 1], acc);
+            acc = fmaf(a1[0], qs[4 * d4 + 2], acc); acc = fmaf(a1[1], qs[4 * d4 + 3], acc);
+        }
+        return acc;
+    };
+    auto compute_step = [&](int step, const u32x4 (&kx)[4], const u32x4 (&vx)[4]) {
+        float sv[4];
+        float mx = m_run;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int j = step * GEMV_KEYS + 8 * i + grp;
+            const float sd = grp8_sum(dot16(kx[i]));
+            sv[i] = (j >= lo && j <= hi) ? sd : -INFINITY;
+            mx = fmaxf(mx, sv[i]);
+        }
+        const float m_use = (mx == -INFINITY) ? 0.f : mx;
+        const float alpha = fast_exp2(m_run - m_use);        // m_run = -inf -> 0
+        m_run = mx;
+        float pw[4], ps = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { pw[i] = fast_exp2(sv[i] - m_use); ps += pw[i]; }
+        l_run = fmaf(l_run, alpha, ps);
+#pragma unroll
+        for (int x = 0; x < 16; ++x) o[x] *= alpha;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int d4 = 0; d4 < 4; ++d4) {
+                const f32x2 a0 = __builtin_amdgcn_cvt_pk_f32_fp8(vx[i][d4], false);
+                const f32x2 a1 = __builtin_amdgcn_cvt_pk_f32_fp8(vx[i][d4], true);
+                o[4 * d4 + 0] = fmaf(pw[i], a0[0], o[4 * d4 + 0]); o[4 * d4 + 1] = fmaf(pw[i], a0[1], o[4 * d4 + 1]);
+                o[4 * d4 + 2] = fmaf(pw[i], a1[0], o[4 * d4 + 2]); o[4 * d4 + 3] = fmaf(pw[i], a1[1], o[4 * d4 + 3]);
+            }
+        }
+    };
+
+    // two register sets: the loads of step s + 4 are in flight while step s is consumed
+    u32x4 kA[4], vA[4], kB[4], vB[4];
+    int st = s_lo + wave;
+    if (st < s_hi) load_step(st, kA, vA);
+    for (; st < s_hi; st += 8) {
+        if (st + 4 < s_hi) load_step(st + 4, kB, vB);
+        compute_step(st, kA, vA);
+        if (st + 4 < s_hi) {
+            if (st + 8 < s_hi) load_step(st + 8, kA, vA);
+            compute_step(st + 4, kB, vB);
+        }
+    }
+
+    // ---- merge the 32 key groups of the workgroup ----
+    float* mine = red + (wave * 8 + grp) * (D + 2);
+#pragma unroll
+    for (int x = 0; x < 16; ++x) mine[16 * sub + x] = o[x];
+    if (sub == 0) { mine[D] = m_run; mine[D + 1] = l_run; }
+    __syncthreads();
+    if (tid < D) {
+        float m_all = -INFINITY;
+        for (int g2 = 0; g2 < 32; ++g2) m_all = fmaxf(m_all, red[g2 * (D + 2) + D]);
+        const float m_s = (m_all == -INFINITY) ? 0.f : m_all;
+        float l_all = 0.f, acc = 0.f;
+        for (int g2 = 0; g2 < 32; ++g2) {
+            const float sc = fast_exp2(red[g2 * (D + 2) + D] - m_s);
+            l_all = fmaf(red[g2 * (D + 2) + D + 1], sc, l_all);
+            acc = fmaf(red[g2 * (D + 2) + tid], sc, acc);
+        }
+        const float inv = l_all > 0.f ? p.v_descale / l_all : 0.f;
+        const float lse = l_all > 0.f ? (m_all + fast_log2(l_all)) * kLn2 : -INFINITY;
+        const int hq = hk;
+        if (da.n_splits == 1) {
+            uint16_t* op = reinterpret_cast<uint16_t*>(p.o) + (int64_t)b * p.o_batch_stride + (int64_t)hq * p.o_head_stride;
+            const float val = acc * inv;
+            const float other = __shfl_xor(val, 1);
+            if ((tid & 1) == 0) *reinterpret_cast<uint32_t*>(op + tid) = E::pack2(val, other);
+            if (tid == 0) p.lse[(int64_t)b * p.lse_batch_stride + (int64_t)hq * p.lse_head_stride] = lse;
+        } else {
+            const int64_t prow = ((int64_t)split * p.batch + b) * p.nheads_q + hq;
+            da.o_partial[prow * D + tid] = acc * inv;
+            if (tid == 0) da.lse_partial[prow] = lse;
+        }
+    }
+}
+
 // ---- host ---------------------------------------------------------------------------------------
 bool decode_applicable(const fa_params& p) {
     if (p.alibi_slopes || p.softcap > 0.f) return false;
@@ -490,6 +693,18 @@ static int launch_decode_td(DecArgs& da, hipStream_t stream) {
     const bool paged = p.block_table != nullptr;
     dim3 grid(p.batch * p.nheads_k, da.n_splits);
     const size_t smem = DecSmem<D>::TOTAL;
+    if constexpr (D == 128) {
+        // one query row per kv-head and an fp8 cache: the streaming matrix-vector kernel
+        if (kv8 && da.rows == 1 && da.group == 1) {
+            if (paged) hipLaunchKernelGGL((fa_decode_gemv_fp8_kernel<T, true>), grid, dim3(GEMV_THREADS), 0, stream, da);
+            else       hipLaunchKernelGGL((fa_decode_gemv_fp8_kernel<T, false>), grid, dim3(GEMV_THREADS), 0, stream, da);
+            if (da.n_splits > 1) {
+                const int64_t total = (int64_t)p.batch * p.nheads_q * p.seqlen_q * (D / 8);
+                hipLaunchKernelGGL(decode_combine_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, da);
+            }
+            return 0;
+        }
+    }
 #define FA_LAUNCH_DEC(KV8, PAGED)                                                                                   \
     do {                                                                                                            \
         auto kern = fa_decode_kernel<T, D, KV8, PAGED>;                                                             \

@@ -392,3 +392,52 @@ def test_context_parallel_two_shards_on_one_gpu(causal):
     o_ref, lse_ref, _ = oracle.attn_fwd(t(q), t(k), t(v), D ** -0.5, causal=causal)
     assert_close(t(out), o_ref, dt, "out", mult=1.5)
     assert_lse_close(f64(lse), lse_ref, "lse", atol=1e-4)
+
+
+# ------------------------------------------------------------------------------------------------ fp8 matrix-vector decode
+@pytest.mark.parametrize("paged,window,interleaved,use_lp,splits", [
+    (True, (-1, -1), False, False, 0), (False, (-1, -1), True, True, 0), (True, (300, -1), False, False, 4),
+    (False, (-1, -1), False, False, 3), (True, (-1, -1), True, True, 1)])
+def test_decode_fp8_gemv_kernel(paged, window, interleaved, use_lp, splits):
+    """fa_decode_gemv_fp8_kernel (one query row per kv-head, fp8 cache: BASELINE config 4's kernel) vs the oracle:
+    paged / dense caches, cache_batch_idx, left pad, windows, both RoPE styles, split-KV, ragged cache lengths."""
+    fa = _fa()
+    dt = "bf16"
+    B, H, D, page = 5, 4, 128, 256
+    kd, vd = 0.05, 0.04
+    Smax = 1100
+    g = torch.Generator().manual_seed(3)
+    seqlens = torch.tensor([Smax - 30, 1, 255, 256, 700], dtype=torch.int32)
+    lp = torch.tensor([0, 5, 17, 3, 0], dtype=torch.int32) if use_lp else None
+    q = rand16((B, 1, H, D), dt, 1)
+    knew = rand16((B, 1, H, D), dt, 4); vnew = rand16((B, 1, H, D), dt, 5)
+    if paged:
+        pps = (Smax + page - 1) // page
+        nblk = B * pps
+        kc16 = rand16((nblk, page, H, D), dt, 2, scale=1.5); vc16 = rand16((nblk, page, H, D), dt, 3, scale=1.5)
+        bt = torch.randperm(nblk, generator=g).reshape(B, pps).to(torch.int32)
+        bidx = None
+        cap = pps * page
+    else:
+        kc16 = rand16((B + 2, Smax, H, D), dt, 2, scale=1.5); vc16 = rand16((B + 2, Smax, H, D), dt, 3, scale=1.5)
+        bt = None
+        bidx = torch.tensor([6, 0, 3, 1, 5], dtype=torch.int32)
+        cap = Smax
+    kc = (kc16.float() / kd).to(torch.float8_e4m3fn); vc = (vc16.float() / vd).to(torch.float8_e4m3fn)
+    pos = torch.arange(cap + 8, dtype=torch.float32)[:, None]
+    ang = pos / (10000 ** (torch.arange(0, D, 2, dtype=torch.float32) / D))[None, :]
+    cos, sin = torch.cos(ang).to(DT[dt]).cuda(), torch.sin(ang).to(DT[dt]).cuda()
+    kc_ref = kc.float().double().cpu().numpy().copy(); vc_ref = vc.float().double().cpu().numpy().copy()
+    out, lse = fa.flash_attn_with_kvcache(q, kc, vc, k=knew, v=vnew, rotary_cos=cos, rotary_sin=sin,
+                                          cache_seqlens=seqlens.cuda(), cache_batch_idx=None if bidx is None else bidx.cuda(),
+                                          cache_leftpad=None if lp is None else lp.cuda(),
+                                          block_table=None if bt is None else bt.cuda(), causal=True, window_size=window,
+                                          rotary_interleaved=interleaved, num_splits=splits, return_softmax_lse=True,
+                                          k_descale=kd, v_descale=vd)
+    o_ref, lse_ref = oracle.kvcache_fwd(f64(q), kc_ref, vc_ref, k=f64(knew), v=f64(vnew), rotary_cos=f64(cos), rotary_sin=f64(sin),
+                                        cache_seqlens=seqlens.numpy(), cache_batch_idx=None if bidx is None else bidx.numpy(),
+                                        cache_leftpad=None if lp is None else lp.numpy(),
+                                        block_table=None if bt is None else bt.numpy(), causal=True, window=window,
+                                        rotary_interleaved=interleaved, io_dtype=dt, k_descale=kd, v_descale=vd)
+    assert_close(f64(out), o_ref, dt, "out", mult=1.5)
+    assert_lse_close(f64(lse), lse_ref, "lse", atol=3e-2)
