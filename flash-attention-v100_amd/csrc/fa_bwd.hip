@@ -18,6 +18,7 @@
 // their GEMMs (as the reference does) and the MFMA C-layout is reused as the next B operand.
 #include <cstdlib>
 #include <type_traits>
+#include <cstring>
 #include "fa_common.h"
 
 namespace fa {
@@ -54,8 +55,16 @@ __global__ void __launch_bounds__(256) bwd_preprocess_kernel(const KArgs a) {
         }
     }
     for (int m = cpr >> 1; m > 0; m >>= 1) acc += __shfl_xor(acc, m, 64);
-    if (row < total_rows && cc == 0)
+    if (row < total_rows && cc == 0) {
         p.softmax_d[b * p.lse_batch_stride + (int64_t)h * p.lse_head_stride + i] = acc;
+        if (a.stats_ws) {           // dense only: the asm dK/dV kernel streams both statistics from one workspace
+            const float lse = p.lse[b * p.lse_batch_stride + (int64_t)h * p.lse_head_stride + i];
+            const int64_t plane = (int64_t)p.batch * p.nheads_q * p.seqlen_q;
+            const int64_t at = (b * p.nheads_q + h) * p.seqlen_q + i;
+            a.stats_ws[at] = lse == -INFINITY ? INFINITY : lse * kLog2e;      // P = exp2(S c - lse2) = 0 for rows without keys
+            a.stats_ws[plane + at] = acc;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1658,7 +1667,11 @@ __global__ void __launch_bounds__(BWD_THREADS, 2) fa_bwd_dq_from_ds_kernel(const
 // kernel then recomputes S and dP).  OPT-IN through FA_BWD_DS_MAX_GB=<limit>: measured at config 2
 // the dQ kernel drops from 0.81 to 0.53 ms, but writing the tiles costs the one-wave-per-SIMD dK/dV
 // kernel +0.29 ms (1.55 -> 1.84 ms; store issue is fully exposed there) - a wash that costs 4.3 GB.
-size_t bwd_workspace_bytes(const fa_params& p) {
+bool bwd_asm_applicable(const KArgs& a);
+size_t bwd_asm_workspace_bytes(const fa_params& p);
+int launch_bwd_dkdv_asm(const KArgs& a, hipStream_t stream);
+
+static size_t bwd_ds_workspace_bytes(const fa_params& p) {
 #ifdef FA_MEASURE
     static const double max_gb = getenv("FA_BWD_DS_MAX_GB") ? atof(getenv("FA_BWD_DS_MAX_GB")) : 0.0;
 #else
@@ -1671,6 +1684,19 @@ size_t bwd_workspace_bytes(const fa_params& p) {
     const double total = (double)per_head * p.batch * p.nheads_q;
     if (total > max_gb * 1073741824.0) return 0;
     return (size_t)total;
+}
+// workspace of the backward ops: the dS hand-off (measurement builds) or the statistics planes of the asm dK/dV kernel
+static KArgs bwd_probe_args(const fa_params& p) {
+    KArgs a;
+    memset(&a, 0, sizeof(a));
+    a.p = p;
+    a.has_bias = (p.alibi_slopes != nullptr) || (p.softcap > 0.f);
+    return a;
+}
+size_t bwd_workspace_bytes(const fa_params& p) {
+    const size_t ds = bwd_ds_workspace_bytes(p);
+    if (ds > 0) return ds;
+    return bwd_asm_applicable(bwd_probe_args(p)) ? bwd_asm_workspace_bytes(p) : 0;
 }
 #ifdef FA_TIMERS
 extern "C" int fa_debug_read_timers(unsigned long long* out, int n) {
@@ -1715,7 +1741,11 @@ static int launch_bwd_td(const KArgs& a, hipStream_t stream) {
         constexpr bool dkv2_env = true;
 #endif
         bool done = false;
+        if constexpr (D == 128) {
+            if (a.stats_ws && grid > 0) { launch_bwd_dkdv_asm(a, stream); done = true; }
+        }
         if constexpr (D <= 128) {
+            if (done) {} else {
             const bool cap_only = p.softcap > 0.f && !p.alibi_slopes;
             if (dkv2_env && (!a.has_bias || ((lin_alibi || cap_only) && !drop)) && grid > 0) {
                 const size_t smem2 = Dkv2Smem<D>::TOTAL;
@@ -1737,6 +1767,7 @@ static int launch_bwd_td(const KArgs& a, hipStream_t stream) {
                 else FA_LAUNCH_DKV2(0, false);
 #undef FA_LAUNCH_DKV2
                 done = true;
+            }
             }
         }
         if (grid > 0 && !done) {
@@ -1784,11 +1815,14 @@ static int launch_bwd_td(const KArgs& a, hipStream_t stream) {
 int launch_bwd(const KArgs& a_in, hipStream_t stream) {
     KArgs a = a_in;
     a.ds_ws = nullptr;
-    const size_t need = bwd_workspace_bytes(a.p);
+    a.stats_ws = nullptr;
+    const size_t need = bwd_ds_workspace_bytes(a.p);
     if (need > 0 && a.p.workspace && a.p.workspace_bytes >= need) {
         a.ds_ws = a.p.workspace;
         a.ds_nqb = (a.p.seqlen_q + 31) / 32;
         a.ds_nkb = (a.p.seqlen_k + 31) / 32;
+    } else if (bwd_asm_applicable(a) && a.p.workspace && a.p.workspace_bytes >= bwd_asm_workspace_bytes(a.p)) {
+        a.stats_ws = reinterpret_cast<float*>(a.p.workspace);     // (without a workspace the hipcc kernels run)
     }
     const bool bf = a.p.dtype == FA_BF16;
     switch (a.p.head_dim) {

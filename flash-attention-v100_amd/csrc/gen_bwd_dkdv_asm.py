@@ -1,0 +1,458 @@
+#!/usr/bin/env python3
+"""Generator for the hand-scheduled gfx950 dK/dV kernel (fa_bwd_asm.hip): D = 128, no bias / dropout, dense.
+
+Replaces the hot loop of the reference's kernel/fused_mha_backward.cu:367-474 (dK / dV accumulation) for
+BASELINE config 2's shape family.  hipcc's version of this loop (fa_bwd_dkdv2_kernel) carries ~10 VALU
+instructions per (q, key) element - twice what the arithmetic needs - and 1.75 LDS reads per MFMA; the kernel is
+instruction-issue bound, so the stream is written out by hand:
+
+  * workgroup = 4 waves (one per SIMD, the whole 512-register file each) on 128 keys, 32 keys per wave;
+    dK^T / dV^T accumulators a[0:127], the wave's K / V fragments a[128:191] (B operands of S = Q K^T, dP = dO V^T);
+  * a "stage" is 32 query rows of one q-head: Q and dO tiles arrive by LDS-DMA in a ring of four 16 KiB stages
+    (both are read twice: by rows for S / dP, transposed for dK / dV), the row statistics (LSE log2e, D) of the
+    stage as a 256-byte piece;
+  * software pipeline over stages, unrolled by four (ring slot, buffer parity and every LDS address are immediates):
+        iteration it:  MFMA  S, dP of stage it+1   and   dV, dK of stage it-1       (32 MFMAs)
+                       VALU  P = exp2(S c - lse2), dS = P (dP - D), packing, of stage it   (5 per element)
+    so the VALU work of a stage never depends on the MFMAs issued beside it;
+  * the pipeline is filled and drained by VIRTUAL stages (fully masked, zero-filled LDS): one loop body, no variants;
+  * masks (causal / window / key tail / rows past the sequence) set S = -inf in a called routine on edge stages only;
+    the statistics are sanitised by the preprocess kernel (LSE = -inf -> +inf) so that -inf scores never meet NaN.
+
+Run:  python gen_bwd_dkdv_asm.py > fa_bwd_asm_gen.h
+"""
+import sys
+from gen_fwd_asm import Ins, Gen, rl, vr, ar, sr
+
+# ------------------------------------------------------------------ LDS map
+STG = 16384                    # one stage: Q tile 8 KiB + dO tile 8 KiB
+NRING = 4
+STATS = NRING * STG            # 4 x 256 B: [lse2 x 32 | D x 32] per ring slot
+LDS_TOTAL = STATS + NRING * 256
+
+# ------------------------------------------------------------------ SGPRs
+S_QRS, S_DORS, S_KRS, S_VRS, S_DKRS, S_DVRS, S_STRS = 16, 20, 24, 28, 32, 36, 40     # buffer descriptors (s40: stats workspace)
+S_C = 44                        # softmax_scale * log2e
+S_SCALE = 45                    # softmax_scale (dK epilogue)
+S_NITER = 46                    # real stages (group x tiles)
+S_MT0, S_MT1 = 47, 48           # 32-row tile range of the key block
+S_QROW32, S_DOROW32 = 49, 50    # bytes of 32 rows of q / dO
+S_QHEAD, S_DOHEAD = 51, 52      # bytes between q heads in q / dO
+S_STHEAD = 53                   # bytes between heads in the statistics planes (seqlen_q * 4)
+S_W1024 = 54                    # wave * 1024
+S_QLOMAX, S_QHIMIN = 55, 56     # mask predicate: edge iff q0 < qlo_max or q0 + 31 > qhi_min (key tail: qhi_min = -1)
+# (the q / dO / statistics descriptors start at the FIRST q-head of the kv-head's group)
+# owned
+S_IT = 60
+S_T = 61                        # s61..s66 temps
+S_DMT, S_DQS, S_DDOS, S_DSTS = 67, 68, 69, 70       # DMA stream: tile index, q / dO / stats soffsets
+S_VMT = 71                      # VALU stream: tile index of stage `it`
+S_OOB = 72
+S_N0 = 73                       # q0 of the stage being masked
+S_SUB, S_RET = 74, 76
+S_MASKFN = (78, 80)
+S_DIT = 82                      # DMA stream: stage index it + 2
+S_LAST = 83
+
+# ------------------------------------------------------------------ VGPRs
+V_KOFF, V_VOFF = 16, 17         # in: per-lane global offsets of the K / V fragment loads
+V_DKOFF, V_DVOFF = 18, 19       # in: dK / dV store offsets
+V_ROW = 20                      # in: 8 row-read addresses (swzt image, tile-relative)
+V_TR = 28                       # in: 8 transposed-read addresses [h][d]
+V_STB = 36                      # in: statistics read base (16 g)
+V_DMAQ, V_DMADO, V_DMAST = 37, 38, 39
+V_LOG, V_WID = 40, 41           # in: qlo - 4g (0x3fffffff: no row) and qhi - qlo of the lane's key
+V_S = (64, 96)                  # S accumulators of the two buffer parities (16 each) ...
+V_DP = (80, 112)                # ... and dP
+V_P = (128, 144)                # packed P (8 regs) per parity
+V_DS = (136, 152)               # packed dS
+V_ST = (160, 192)               # statistics per parity: lse2 x16, D x16
+V_RR = 224                      # row-fragment ring (4 x 4)
+V_TRR = 240                     # transposed-fragment ring (4 x 4)
+V_T = 44                        # temps v44..v63
+A_DK, A_DV, A_K, A_V = 0, 64, 128, 160
+
+
+class DKV(Gen):
+    def reset_dkv(self):
+        self.now = 0
+        self.last = {}
+        self.lds_q = []
+        self.srcc_rd = {}
+        for par in (0, 1):
+            for r in rl("v", V_S[par], 16) + rl("v", V_DP[par], 16):
+                self.last[r] = (-8, "mfma", None)
+        for r in rl("a", 0, 128):
+            self.last[r] = (-8, "mfma", None)
+
+    # ---- streams of one iteration (copy c of 4: ring slot and parity are compile-time) ----
+    def sdp_stream(self, stage_slot, par):
+        """S, dP of stage it+1: (reads, mfmas) - row fragments through a 4-entry ring"""
+        items = []
+        for ks in range(8):
+            for (tens, acc, bfrag) in ((0, V_S[par], A_K), (1, V_DP[par], A_V)):
+                n = ks * 2 + tens
+                ring = V_RR + 4 * (n % 4)
+                off = stage_slot * STG + tens * 8192
+                rd = Ins(f"ds_read_b128 {vr(ring, 4)}, v{V_ROW + ks} offset:{off}", "lds", [f"v{V_ROW + ks}"], rl("v", ring, 4))
+                mf = self.mfma("v", acc, "v", ring, "a", bfrag + 4 * ks, ks == 0)
+                items.append((rd, mf))
+        return items
+
+    def dvdk_stream(self, stage_slot, par):
+        """dV, dK of stage it-1: transposed fragments through a 4-entry ring; B operands = packed P / dS"""
+        items = []
+        n = 0
+        for t in range(2):
+            for d in range(4):
+                for (tens, acc, b) in ((1, A_DV + 16 * d, V_P[par] + 4 * t), (0, A_DK + 16 * d, V_DS[par] + 4 * t)):
+                    ring = V_TRR + 4 * (n % 4)
+                    off = stage_slot * STG + tens * 8192 + t * 4096
+                    rds = [Ins(f"ds_read_b64_tr_b16 {vr(ring + 2 * h, 2)}, v{V_TR + 4 * h + d} offset:{off}", "lds",
+                               [f"v{V_TR + 4 * h + d}"], rl("v", ring + 2 * h, 2)) for h in range(2)]
+                    mf = self.mfma("a", acc, "v", ring, "v", b, False)
+                    items.append((rds, mf))
+                    n += 1
+        return items
+
+    def stats_reads(self, slot, par):
+        """statistics of stage it+1 -> registers of the other parity (read by the VALU stream of the next iteration)"""
+        out = []
+        for i in range(4):
+            for (which, base) in ((0, V_ST[par]), (1, V_ST[par] + 16)):
+                off = slot * 256 + which * 128 + i * 32          # the lane base (v36) carries STATS: past the 16-bit offset field
+                out.append(Ins(f"ds_read_b128 {vr(base + 4 * i, 4)}, v{V_STB} offset:{off}", "lds", [f"v{V_STB}"], rl("v", base + 4 * i, 4)))
+        return out
+
+    def valu_stream(self, par):
+        S, DP, ST = V_S[par], V_DP[par], V_ST[par]
+        out = []
+        for r in range(16 + 3):
+            if r < 16:
+                out.append(Ins(f"v_fma_f32 v{S + r}, v{S + r}, s{S_C}, -v{ST + r}", "valu", [f"v{S + r}", f"v{ST + r}"], [f"v{S + r}"]))
+                out.append(Ins(f"v_sub_f32 v{DP + r}, v{DP + r}, v{ST + 16 + r}", "valu", [f"v{DP + r}", f"v{ST + 16 + r}"], [f"v{DP + r}"]))
+            if 0 <= r - 1 < 16:
+                q = r - 1
+                out.append(Ins(f"v_exp_f32 v{S + q}, v{S + q}", "trans", [f"v{S + q}"], [f"v{S + q}"]))
+            if 0 <= r - 3 < 16:
+                q = r - 3
+                out.append(Ins(f"v_mul_f32 v{DP + q}, v{S + q}, v{DP + q}", "valu", [f"v{S + q}", f"v{DP + q}"], [f"v{DP + q}"]))
+                if q % 2 == 1:
+                    e = q // 2
+                    out.append(Ins(f"{self.cvt} v{V_P[par] + e}, v{S + q - 1}, v{S + q}", "valu", [f"v{S + q - 1}", f"v{S + q}"], [f"v{V_P[par] + e}"]))
+                    out.append(Ins(f"{self.cvt} v{V_DS[par] + e}, v{DP + q - 1}, v{DP + q}", "valu", [f"v{DP + q - 1}", f"v{DP + q}"], [f"v{V_DS[par] + e}"]))
+        return out
+
+    def dma_stream(self, slot):
+        """stage it+2 -> ring slot: 2 Q pieces + 2 dO pieces per wave (source offsets in s[S_T+3], s[S_T+4], half a
+        stage = 16 rows in s[S_T+1], s[S_T+2]), the 256-byte statistics piece by wave 0 (offset s[S_T+5])"""
+        g = []
+        base = slot * STG
+        t = S_T
+        for (rs, so, half, vo, toff) in ((S_QRS, t + 3, t + 1, V_DMAQ, 0), (S_DORS, t + 4, t + 2, V_DMADO, 8192)):
+            for jj in range(2):
+                p = [Ins(f"s_add_u32 m0, s{S_W1024}, {base + toff + 4096 * jj}", "salu", [], ["m0", "scc"]),
+                     Ins(f"buffer_load_dwordx4 v{vo}, {sr(rs, 4)}, s{so} offen lds", "dma", ["m0", f"v{vo}", f"s{so}"], [])]
+                if jj == 0:
+                    p.append(Ins(f"s_add_u32 s{so}, s{so}, s{half}", "salu", [f"s{so}", f"s{half}"], [f"s{so}", "scc"]))
+                g.append(p)
+        u = self.uid()
+        st = [Ins(f"s_cmp_eq_u32 s{S_W1024}, 0", "raw"), Ins(f"s_cbranch_scc0 L_ns{u}_%=", "raw"),
+              Ins(f"s_mov_b32 m0, {STATS + slot * 256}", "raw"), Ins("s_nop 0", "raw"),
+              Ins(f"buffer_load_dword v{V_DMAST}, {sr(S_STRS, 4)}, s{t + 5} offen lds", "raw"), Ins(f"L_ns{u}_%=:", "raw")]
+        g.append(st)
+        return g
+
+    def gen_iteration(self, c, cfg):
+        """copy c (0..3): it = c - 1 (mod 4) at loop entry; stage it+1 lives in ring slot (c + 1) % 4 ... see slot()"""
+        self.reset_dkv()
+        # it = c - 1 (mod 4); stage s lives in ring slot (s + 1) % 4 and in the register buffers of parity s & 1
+        sl_prev, sl_next, sl_dma = (c + 3) % NRING, (c + 1) % NRING, (c + 2) % NRING
+        par_cur, par_oth = (c + 1) % 2, c % 2              # parity of stage it | of stages it - 1 and it + 1
+        A = self.raw
+        t = S_T
+        # ---- SALU head: mask predicate of stage `it` (virtual stages are masked completely) ...
+        u = self.uid()
+        A(f"s_lshl_b32 s{S_N0}, s{S_VMT}, 5")                                # q0 of stage it
+        A(f"s_cmp_lt_i32 s{S_IT}, 0")
+        A(f"s_cbranch_scc1 L_dm{u}_%=")
+        A(f"s_cmp_ge_i32 s{S_IT}, s{S_NITER}")
+        A(f"s_cbranch_scc1 L_dm{u}_%=")
+        A(f"s_cmp_lt_i32 s{S_N0}, s{S_QLOMAX}")
+        A(f"s_cbranch_scc1 L_dm{u}_%=")
+        A(f"s_add_u32 s{t}, s{S_N0}, 31")
+        A(f"s_cmp_gt_i32 s{t}, s{S_QHIMIN}")
+        A(f"s_cbranch_scc0 L_nm{u}_%=")
+        self.out.append(f"L_dm{u}_%=:")
+        A(f"s_swappc_b64 {sr(S_RET, 2)}, {sr(S_MASKFN[par_cur], 2)}")
+        self.out.append(f"L_nm{u}_%=:")
+        # ... and the source offsets of the stage the DMA stream points at (it + 2): zeros past the last real stage
+        A(f"s_lshr_b32 s{t + 1}, s{S_QROW32}, 1")
+        A(f"s_lshr_b32 s{t + 2}, s{S_DOROW32}, 1")
+        A(f"s_cmp_lt_i32 s{S_DIT}, s{S_NITER}")
+        A(f"s_cselect_b32 s{t + 3}, s{S_DQS}, s{S_OOB}")
+        A(f"s_cselect_b32 s{t + 4}, s{S_DDOS}, s{S_OOB}")
+        A(f"s_cselect_b32 s{t + 5}, s{S_DSTS}, s{S_OOB}")
+        # ---- streams
+        sdp = self.sdp_stream(sl_next, par_oth)
+        dvdk = self.dvdk_stream(sl_prev, par_oth)
+        stats = self.stats_reads(sl_next, par_oth)
+        valu = self.valu_stream(par_cur)
+        dma = self.dma_stream(sl_dma)
+        # ---- interleave: 32 MFMAs = dV/dK of stage it-1 first (their operands are oldest), then S/dP of stage it+1
+        mf_items = [("t", x) for x in dvdk] + [("r", x) for x in sdp]
+        nv, vi = len(valu), 0
+        pre = cfg.get("pre", 3)
+        # pre-issue the reads of the first `pre` items
+        reads = []
+        for kind, (rd, mf) in mf_items:
+            reads.append(rd if isinstance(rd, list) else [rd])
+        issued = 0
+        for k in range(min(pre, len(mf_items))):
+            for r in reads[k]:
+                self.emit(r)
+            issued = k + 1
+        dma_at = cfg.get("dma_at", [2, 8, 14, 20, 26])
+        stats_at = cfg.get("stats_at", [17, 19, 21, 23, 25, 27, 29, 31])
+        M = len(mf_items)
+        for k, (kind, (rd, mf)) in enumerate(mf_items):
+            if issued < M:
+                for r in reads[issued]:
+                    self.emit(r)
+                issued += 1
+            self.emit(mf)
+            if k in dma_at and dma:
+                for ins in dma.pop(0):
+                    self._emit_any(ins)
+            if k in stats_at and stats:
+                self.emit(stats.pop(0))
+            take = -(-(nv - vi) // (M - k))
+            for _ in range(take):
+                if vi < nv:
+                    self.emit(valu[vi])
+                    vi += 1
+        for grp in dma:
+            for ins in grp:
+                self._emit_any(ins)
+        for ins in stats:
+            self.emit(ins)
+        while vi < nv:
+            self.emit(valu[vi])
+            vi += 1
+        self.drain_lds()
+
+    def _emit_any(self, ins):
+        if ins.kind == "raw":
+            if ins.txt.endswith(":"):
+                self.out.append(ins.txt)
+            else:
+                self.raw(ins.txt)
+        else:
+            self.emit(ins)
+
+    def salu_advance(self):
+        """advance the VALU stream (stage it -> it+1) and the DMA stream (stage it+2 -> it+3): tile index wraps to
+        mt0 with the next q-head of the group; the statistics piece of the NEXT DMA stage is issued by wave 0."""
+        o = []
+        t = S_T
+        # VALU stream tile index
+        o += [f"s_add_u32 s{S_VMT}, s{S_VMT}, 1",
+              f"s_cmp_ge_i32 s{S_VMT}, s{S_MT1}",
+              f"s_cselect_b32 s{S_VMT}, s{S_MT0}, s{S_VMT}"]
+        # DMA stream: next stage
+        o += [f"s_add_u32 s{S_DIT}, s{S_DIT}, 1",
+              f"s_add_u32 s{S_DMT}, s{S_DMT}, 1",
+              f"s_add_u32 s{S_DQS}, s{S_DQS}, s{S_QROW32}",
+              f"s_add_u32 s{S_DDOS}, s{S_DDOS}, s{S_DOROW32}",
+              f"s_add_u32 s{S_DSTS}, s{S_DSTS}, 128",
+              f"s_cmp_ge_i32 s{S_DMT}, s{S_MT1}",
+              f"s_cbranch_scc0 L_nw{{u}}_%=",
+              # wrap: next q-head, first tile
+              f"s_sub_u32 s{t}, s{S_MT1}, s{S_MT0}",
+              f"s_mov_b32 s{S_DMT}, s{S_MT0}",
+              f"s_mul_i32 s{t + 1}, s{t}, s{S_QROW32}",
+              f"s_sub_u32 s{S_DQS}, s{S_DQS}, s{t + 1}",
+              f"s_add_u32 s{S_DQS}, s{S_DQS}, s{S_QHEAD}",
+              f"s_mul_i32 s{t + 1}, s{t}, s{S_DOROW32}",
+              f"s_sub_u32 s{S_DDOS}, s{S_DDOS}, s{t + 1}",
+              f"s_add_u32 s{S_DDOS}, s{S_DDOS}, s{S_DOHEAD}",
+              f"s_lshl_b32 s{t + 1}, s{t}, 7",
+              f"s_sub_u32 s{S_DSTS}, s{S_DSTS}, s{t + 1}",
+              f"s_add_u32 s{S_DSTS}, s{S_DSTS}, s{S_STHEAD}",
+              f"L_nw{{u}}_%=:"]
+        return o
+
+    def gen_mask_routine(self, par):
+        o = []
+        S, T = V_S[par], V_T
+        tlo, tinf = f"v{T}", f"v{T + 1}"
+        o.append("s_nop 7")
+        o.append("s_nop 3")
+        o.append(f"v_subrev_u32 {tlo}, s{S_N0}, v{V_LOG}")           # lo_t = (qlo - 4g) - q0
+        o.append(f"v_mov_b32 {tinf}, 0xff800000")
+        # virtual stages: everything is masked
+        o.append(f"s_cmp_lt_i32 s{S_IT}, 0")
+        o.append(f"s_cbranch_scc1 L_mall{par}_%=")
+        o.append(f"s_cmp_ge_i32 s{S_IT}, s{S_NITER}")
+        o.append(f"s_cbranch_scc0 L_mreg{par}_%=")
+        o.append(f"L_mall{par}_%=:")
+        o.append(f"v_mov_b32 {tlo}, 0x3fffffff")
+        o.append(f"L_mreg{par}_%=:")
+        o.append("s_nop 0")
+        for r in range(16):
+            c = (r & 3) + 8 * (r >> 2)
+            t = f"v{T + 2 + (r & 3)}"
+            o.append(f"v_sub_u32 {t}, {c}, {tlo}")
+            o.append(f"v_cmp_gt_u32 vcc, {t}, v{V_WID}")
+            o.append(f"v_cndmask_b32 v{S + r}, v{S + r}, {tinf}, vcc")
+        o.append(f"s_setpc_b64 {sr(S_RET, 2)}")
+        return o
+
+    def gen_body(self, cfg):
+        L = []
+        A = L.append
+        t = S_T
+        A("s_nop 7")
+        A(f"s_getpc_b64 {sr(S_SUB, 2)}")
+        A("L_pc_%=:")
+        for (reg, lab) in ((S_MASKFN[0], "L_mask0"), (S_MASKFN[1], "L_mask1")):
+            A(f"s_add_u32 s{reg}, s{S_SUB}, {lab}_%=-L_pc_%=")
+            A(f"s_addc_u32 s{reg + 1}, s{S_SUB + 1}, 0")
+        A(f"s_mov_b32 s{S_OOB}, 0x80000000")
+        A("s_barrier")                                            # previous pass is done with LDS
+        # ---- K / V fragments of this wave's 32 keys
+        for ks in range(8):
+            A(f"buffer_load_dwordx4 {ar(A_K + 4 * ks, 4)}, v{V_KOFF}, {sr(S_KRS, 4)}, 0 offen offset:{32 * ks}")
+            A(f"buffer_load_dwordx4 {ar(A_V + 4 * ks, 4)}, v{V_VOFF}, {sr(S_VRS, 4)}, 0 offen offset:{32 * ks}")
+        # ---- ring slots 3 and 0 (virtual stages -2, -1): zeros through an out-of-range source; stage 0 -> slot 1
+        for slot in (3, 0):
+            for toff in (0, 8192):
+                for jj in range(2):
+                    A(f"s_add_u32 m0, s{S_W1024}, {slot * STG + toff + 4096 * jj}")
+                    A("s_nop 0")
+                    A(f"buffer_load_dwordx4 v{V_DMAQ}, {sr(S_QRS, 4)}, s{S_OOB} offen lds")
+        A(f"s_mov_b32 s{S_DIT}, 0")
+        A(f"s_mov_b32 s{S_DMT}, s{S_MT0}")
+        A(f"s_mul_i32 s{S_DQS}, s{S_MT0}, s{S_QROW32}")
+        A(f"s_mul_i32 s{S_DDOS}, s{S_MT0}, s{S_DOROW32}")
+        A(f"s_lshl_b32 s{S_DSTS}, s{S_MT0}, 7")
+        A(f"s_lshr_b32 s{t + 1}, s{S_QROW32}, 1")
+        A(f"s_lshr_b32 s{t + 2}, s{S_DOROW32}, 1")
+        A(f"s_cmp_lt_i32 s{S_DIT}, s{S_NITER}")
+        A(f"s_cselect_b32 s{t + 3}, s{S_DQS}, s{S_OOB}")
+        A(f"s_cselect_b32 s{t + 4}, s{S_DDOS}, s{S_OOB}")
+        A(f"s_cselect_b32 s{t + 5}, s{S_DSTS}, s{S_OOB}")
+        self.out = []
+        self.reset_dkv()
+        for grp in self.dma_stream(1):
+            for ins in grp:
+                self._emit_any(ins)
+        L += self.out
+
+        def dma_advance():
+            u = self.uid()
+            return [x.replace("{u}", str(u)) for x in self.salu_advance()[3:]]
+
+        L += dma_advance()
+        # ---- state
+        for i in range(128):
+            A(f"v_accvgpr_write_b32 a{i}, 0")
+        for par in (0, 1):
+            for r in range(16):
+                A(f"v_mov_b32 v{V_S[par] + r}, 0")
+                A(f"v_mov_b32 v{V_DP[par] + r}, 0")
+            for r in range(8):
+                A(f"v_mov_b32 v{V_P[par] + r}, 0")
+                A(f"v_mov_b32 v{V_DS[par] + r}, 0")
+            for r in range(32):
+                A(f"v_mov_b32 v{V_ST[par] + r}, 0")
+        A(f"s_mov_b32 s{S_IT}, -1")
+        A(f"s_mov_b32 s{S_VMT}, s{S_MT0}")
+        A(f"s_sub_u32 s{S_VMT}, s{S_VMT}, 1")                      # stage -1 (virtual): advanced to mt0 before stage 0
+        A("s_waitcnt vmcnt(0)")
+        report = {}
+        for c in range(NRING):
+            A(f"L_it{c}_%=:")
+            A("s_barrier")
+            self.out, self.stats = [], {"nop_states": 0, "lgkm_waits": 0}
+            self.gen_iteration(c, cfg)
+            report[c] = (dict(self.stats), len(self.out))
+            L += self.out
+            # ---- tail: advance both streams; the DMA of this iteration must have landed before the next barrier
+            u = self.uid()
+            for x in self.salu_advance():
+                A(x.replace("{u}", str(u)))
+            A(f"s_cmp_lt_i32 s{S_IT}, 0")                          # virtual stage -1 -> stage 0 starts at tile mt0
+            A(f"s_cselect_b32 s{S_VMT}, s{S_MT0}, s{S_VMT}")
+            A("s_waitcnt vmcnt(0)")
+            A(f"s_add_u32 s{S_IT}, s{S_IT}, 1")
+            A(f"s_cmp_le_i32 s{S_IT}, s{S_NITER}")
+            if c < NRING - 1:
+                A("s_cbranch_scc0 L_done_%=")
+            else:
+                A("s_cbranch_scc1 L_it0_%=")
+        A("L_done_%=:")
+        A("s_waitcnt vmcnt(0)")
+        A("s_nop 7")
+        A("s_nop 7")
+        # ---- epilogue: dK * softmax_scale, dV -> 16 bit, row stores
+        T = V_T
+        for (acc, voff, rs, scale) in ((A_DK, V_DKOFF, S_DKRS, True), (A_DV, V_DVOFF, S_DVRS, False)):
+            for d in range(4):
+                for r4 in range(4):
+                    base = acc + 16 * d + 4 * r4
+                    tt = T + 4 * (r4 & 1)
+                    for e in range(4):
+                        A(f"v_accvgpr_read_b32 v{tt + e}, a{base + e}")
+                    if scale:
+                        for e in range(4):
+                            A(f"v_mul_f32 v{tt + e}, s{S_SCALE}, v{tt + e}")
+                    pk = T + 8 + 2 * (r4 & 1)
+                    A(f"{self.cvt} v{pk}, v{tt}, v{tt + 1}")
+                    A(f"{self.cvt} v{pk + 1}, v{tt + 2}, v{tt + 3}")
+                    A(f"buffer_store_dwordx2 {vr(pk, 2)}, v{voff}, {sr(rs, 4)}, 0 offen offset:{64 * d + 16 * r4}")
+        A("s_waitcnt vmcnt(0)")
+        A("s_branch L_end_%=")
+        for par in (0, 1):
+            A(f"L_mask{par}_%=:")
+            L += self.gen_mask_routine(par)
+        A("L_end_%=:")
+        return L, report
+
+
+def clobbers():
+    c = ["memory", "vcc", "scc", "m0"]
+    c += [f"v{i}" for i in range(42, 256)]
+    c += [f"a{i}" for i in range(192)]
+    c += [f"s{i}" for i in range(S_IT, S_LAST + 1)]
+    return c
+
+
+def main():
+    cfg = {}
+    ko = frozenset()
+    for a in sys.argv[1:]:
+        if a.startswith("--ko="):
+            ko = frozenset(x for x in a[5:].split(",") if x)
+        elif a.startswith("--cfg="):
+            import json
+            cfg.update(json.loads(a[6:]))
+    print("// GENERATED by gen_bwd_dkdv_asm.py - do not edit.  See that script for the schedule and the register map.")
+    print("#pragma once")
+    print(f"#define FA_BWD_ASM_LDS_BYTES {LDS_TOTAL}")
+    for dt in ("bf16", "f16"):
+        g = DKV(dt)
+        g.ko = ko
+        body, report = g.gen_body(cfg)
+        print(f"#define FA_BWD_DKDV_ASM_BODY_{dt.upper()} \\")
+        for ln in body:
+            print(f'    "{ln}\\n" \\')
+        print('    ""')
+        for k, (st, n) in report.items():
+            print(f"// {dt} copy {k}: {n} lines, nop states {st['nop_states']}, lgkmcnt waits {st['lgkm_waits']}")
+    cl = ", ".join(f'"{c}"' for c in clobbers())
+    print(f"#define FA_BWD_DKDV_ASM_CLOBBERS {cl}")
+
+
+if __name__ == "__main__":
+    main()
