@@ -354,7 +354,8 @@ def main():
                               "achieved": round(2.5 * ff / (kern["bwd_all"] * 1e-3) / 1e12, 1)}
         dom = max(("fwd", "bwd_dkdv", "bwd_dq"), key=lambda n: dur[n])
         fwd_kernel = "fa_fwd_ws_kernel" if os.environ.get("FA_FWD_WS") == "1" else "fa_fwd_asm_kernel"
-        roofline = {"bound": "mfma", "kernel": {"fwd": fwd_kernel, "bwd_dkdv": "fa_bwd_dkdv2_kernel",
+        dkdv_kernel = "fa_bwd_dkdv2_kernel" if os.environ.get("FA_BWD_ASM") == "0" else "fa_bwd_dkdv_asm_kernel"
+        roofline = {"bound": "mfma", "kernel": {"fwd": fwd_kernel, "bwd_dkdv": dkdv_kernel,
                                                   "bwd_dq": "fa_bwd_dq_kernel"}[dom],
                     "achieved": kernels[dom]["achieved"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                     "frac": kernels[dom]["frac"], "traffic": None}

@@ -373,7 +373,8 @@ class DKV(Gen):
         report = {}
         for c in range(NRING):
             A(f"L_it{c}_%=:")
-            A("s_barrier")
+            if "bar" not in self.ko:
+                A("s_barrier")
             self.out, self.stats = [], {"nop_states": 0, "lgkm_waits": 0}
             self.gen_iteration(c, cfg)
             report[c] = (dict(self.stats), len(self.out))
@@ -384,7 +385,8 @@ class DKV(Gen):
                 A(x.replace("{u}", str(u)))
             A(f"s_cmp_lt_i32 s{S_IT}, 0")                          # virtual stage -1 -> stage 0 starts at tile mt0
             A(f"s_cselect_b32 s{S_VMT}, s{S_MT0}, s{S_VMT}")
-            A("s_waitcnt vmcnt(0)")
+            if "vmwait" not in self.ko:
+                A("s_waitcnt vmcnt(0)")
             A(f"s_add_u32 s{S_IT}, s{S_IT}, 1")
             A(f"s_cmp_le_i32 s{S_IT}, s{S_NITER}")
             if c < NRING - 1:

@@ -18,8 +18,9 @@ def build(specs):
     os.makedirs(OUT, exist_ok=True)
     bdir = os.path.join(CSRC, "build")
     which = os.environ.get("VARIANT_KERNEL", "ws")           # ws: fa_fwd_ws.hip / gen_fwd_ws.py ; asm: fa_fwd_asm.hip / gen_fwd_asm.py
-    src, gen, macro = (("fa_fwd_ws.hip", "gen_fwd_ws.py", "FA_FWD_WS_GEN_H") if which == "ws" else
-                       ("fa_fwd_asm.hip", "gen_fwd_asm.py", "FA_FWD_ASM_GEN_H"))
+    src, gen, macro = {"ws": ("fa_fwd_ws.hip", "gen_fwd_ws.py", "FA_FWD_WS_GEN_H"),
+                       "asm": ("fa_fwd_asm.hip", "gen_fwd_asm.py", "FA_FWD_ASM_GEN_H"),
+                       "bwd": ("fa_bwd_asm.hip", "gen_bwd_dkdv_asm.py", "FA_BWD_ASM_GEN_H")}[which]
     others = [os.path.join(bdir, s.replace(".hip", ".o")) for s in b.SOURCES if s != src]
     procs = []
     for spec in specs:
@@ -60,6 +61,34 @@ def one():
     print(json.dumps(res))
 
 
+def one_bwd():
+    """dK/dV kernel alone (fa_params::bwd_phases = 2; the statistics workspace keeps the previous full pass's values)"""
+    import torch
+    import flash_attn
+    from flash_attn_mi355 import flash_attn_interface as fi
+    torch.manual_seed(421)
+    res = {}
+    for (tag, B, S, H, Hk, causal) in (("causal4k", 8, 4096, 16, 16, True), ("full4k", 8, 4096, 16, 16, False), ("gqa4k", 4, 4096, 32, 8, True)):
+        q = torch.randn(B, S, H, 128, device="cuda", dtype=torch.bfloat16, requires_grad=True)
+        k, v = (torch.randn(B, S, Hk, 128, device="cuda", dtype=torch.bfloat16, requires_grad=True) for _ in range(2))
+        do = torch.randn(B, S, H, 128, device="cuda", dtype=torch.bfloat16)
+        o = flash_attn.flash_attn_func(q, k, v, causal=causal)
+        torch.autograd.grad(o, (q, k, v), do, retain_graph=True)
+        with fi.bwd_phases(2):
+            for _ in range(3):
+                torch.autograd.grad(o, (q, k, v), do, retain_graph=True)
+            torch.cuda.synchronize()
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            for _ in range(10):
+                torch.autograd.grad(o, (q, k, v), do, retain_graph=True)
+            e.record(); torch.cuda.synchronize()
+        ms = s.elapsed_time(e) / 10
+        fl = 8.0 * B * H * S * S * 128 * (0.5 if causal else 1.0)
+        res[tag] = (ms, fl / ms / 1e9)
+    print(json.dumps(res))
+
+
 def time_all(names):
     if not names:
         names = sorted(f[6:-3] for f in os.listdir(OUT) if f.startswith("libfa_") and f.endswith(".so"))
@@ -69,7 +98,8 @@ def time_all(names):
             env = dict(os.environ)
             if n != "default":
                 env["FA_MI355_LIB"] = os.path.join(OUT, f"libfa_{n}.so")
-            r = subprocess.run([sys.executable, os.path.abspath(__file__), "one"], env=env, capture_output=True, text=True)
+            mode = "one_bwd" if os.environ.get("VARIANT_KERNEL") == "bwd" else "one"
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), mode], env=env, capture_output=True, text=True)
             line = [l for l in r.stdout.splitlines() if l.startswith("{")]
             if not line:
                 print(n, "FAILED", r.stderr[-500:])
@@ -83,6 +113,8 @@ if __name__ == "__main__":
         build(sys.argv[2:])
     elif sys.argv[1] == "one":
         one()
+    elif sys.argv[1] == "one_bwd":
+        one_bwd()
     elif sys.argv[1] == "timers":
         pass
     else:

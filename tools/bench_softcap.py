@@ -14,7 +14,7 @@ for cap in (0.0, 0.0, 50.0):
     o = flash_attn.flash_attn_func(q, k, v, causal=True, softcap=cap)
     res = {}
     for nm, mask in (("dkdv", 2), ("dq", 4), ("all", 7)):
-        _fi._TLS.__setattr__("bwd_phases", mask)
+        setattr(_fi._TLS, "bwd_phases", mask)
         res[nm] = timeit(lambda: torch.autograd.grad(o, (q, k, v), do, retain_graph=True), iters=5)
-    _fi._TLS.__setattr__("bwd_phases", 7)
+    setattr(_fi._TLS, "bwd_phases", 7)
     print(f"softcap={cap}: fwd {tf:.3f} | dkdv {res['dkdv']:.3f} dq {res['dq']:.3f} bwd {res['all']:.3f} ms", flush=True)

@@ -14,6 +14,6 @@ with torch.no_grad():
 o = flash_attn.flash_attn_func(q, k, v, causal=True)
 res = {}
 for nm, mask in (("pre", 1), ("dkdv", 2), ("dq", 4), ("all", 7)):
-    _fi._TLS.__setattr__("bwd_phases", mask)
+    setattr(_fi._TLS, "bwd_phases", mask)
     res[nm] = timeit(lambda: torch.autograd.grad(o, (q, k, v), do, retain_graph=True), iters=5)
 print(f"B{B} S{S} H{H} D{D}: fwd {tf:.3f} ms ({fl/tf/1e9:.0f} TF) | pre {res['pre']:.3f} dkdv {res['dkdv']:.3f} ({2*fl/res['dkdv']/1e9:.0f} TF) dq {res['dq']:.3f} ({0.5*fl/res['dq']/1e9:.0f} TF alg) all {res['all']:.3f}")

@@ -19,9 +19,9 @@ def run(name, fwd, flops):
     ins = [t for t in o.grad_fn.next_functions] if False else None
     res = {}
     for nm, mask in (("pre", 1), ("dkdv", 2), ("dq", 4), ("all", 7)):
-        _fi._TLS.__setattr__("bwd_phases", mask)
+        setattr(_fi._TLS, "bwd_phases", mask)
         res[nm] = timeit(lambda: torch.autograd.grad(o, INS, do, retain_graph=True))
-    _fi._TLS.__setattr__("bwd_phases", 7)
+    setattr(_fi._TLS, "bwd_phases", 7)
     print(f"{name:34s} fwd {tf:.3f} ms ({flops/tf/1e9:6.0f} TF) | pre {res['pre']:.3f} dkdv {res['dkdv']:.3f} ({2*flops/res['dkdv']/1e9:5.0f} TF) dq {res['dq']:.3f} all {res['all']:.3f} ({2.5*flops/res['all']/1e9:5.0f} TF)", flush=True)
 q, k, v = mk(T, H, D), mk(T, H, D), mk(T, H, D); INS = (q, k, v)
 fl = 4.0 * D * H * sum(pairs(int(L), W) for L in lens)
