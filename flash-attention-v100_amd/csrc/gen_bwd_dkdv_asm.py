@@ -8,13 +8,17 @@ instruction-issue bound, so the stream is written out by hand:
 
   * workgroup = 4 waves (one per SIMD, the whole 512-register file each) on 128 keys, 32 keys per wave;
     dK^T / dV^T accumulators a[0:127], the wave's K / V fragments a[128:191] (B operands of S = Q K^T, dP = dO V^T);
-  * a "stage" is 32 query rows of one q-head: Q and dO tiles arrive by LDS-DMA in a ring of four 16 KiB stages
+  * a "stage" is 32 query rows of one q-head: Q and dO tiles arrive by LDS-DMA in a ring of six 16 KiB stages
     (both are read twice: by rows for S / dP, transposed for dK / dV), the row statistics (LSE log2e, D) of the
     stage as a 256-byte piece;
-  * software pipeline over stages, unrolled by four (ring slot, buffer parity and every LDS address are immediates):
+  * software pipeline over stages, unrolled by six (ring slot, buffer parity and every LDS address are immediates):
         iteration it:  MFMA  S, dP of stage it+1   and   dV, dK of stage it-1       (32 MFMAs)
                        VALU  P = exp2(S c - lse2), dS = P (dP - D), packing, of stage it   (5 per element)
-    so the VALU work of a stage never depends on the MFMAs issued beside it;
+                       DMA   stage it+3 (needed by iteration it+2: the end-of-iteration wait is a COUNTED vmcnt that
+                             leaves this iteration's pieces in flight - memory latency is covered by a whole iteration)
+    so the VALU work of a stage never depends on the MFMAs issued beside it; MFMA A operands come from two
+    eight-entry fragment rings in a[192:255], read seven MFMAs ahead (the first seven transposed reads of an
+    iteration are issued at the end of the previous one, across the barrier: their stage landed long ago);
   * the pipeline is filled and drained by VIRTUAL stages (fully masked, zero-filled LDS): one loop body, no variants;
   * masks (causal / window / key tail / rows past the sequence) set S = -inf in a called routine on edge stages only;
     the statistics are sanitised by the preprocess kernel (LSE = -inf -> +inf) so that -inf scores never meet NaN.
@@ -26,8 +30,8 @@ from gen_fwd_asm import Ins, Gen, rl, vr, ar, sr
 
 # ------------------------------------------------------------------ LDS map
 STG = 16384                    # one stage: Q tile 8 KiB + dO tile 8 KiB
-NRING = 4
-STATS = NRING * STG            # 4 x 256 B: [lse2 x 32 | D x 32] per ring slot
+NRING = 6
+STATS = NRING * STG            # 6 x 256 B: [lse2 x 32 | D x 32] per ring slot
 LDS_TOTAL = STATS + NRING * 256
 
 # ------------------------------------------------------------------ SGPRs
@@ -44,14 +48,14 @@ S_QLOMAX, S_QHIMIN = 55, 56     # mask predicate: edge iff q0 < qlo_max or q0 + 
 # (the q / dO / statistics descriptors start at the FIRST q-head of the kv-head's group)
 # owned
 S_IT = 60
-S_T = 61                        # s61..s66 temps
+S_T = 61                        # s61..s66 temps (s61: scratch; s64..s66: DMA source offsets of the iteration)
 S_DMT, S_DQS, S_DDOS, S_DSTS = 67, 68, 69, 70       # DMA stream: tile index, q / dO / stats soffsets
 S_VMT = 71                      # VALU stream: tile index of stage `it`
 S_OOB = 72
 S_N0 = 73                       # q0 of the stage being masked
 S_SUB, S_RET = 74, 76
 S_MASKFN = (78, 80)
-S_DIT = 82                      # DMA stream: stage index it + 2
+S_DIT = 82                      # DMA stream: stage index it + 3
 S_LAST = 83
 
 # ------------------------------------------------------------------ VGPRs
@@ -67,10 +71,13 @@ V_DP = (80, 112)                # ... and dP
 V_P = (128, 144)                # packed P (8 regs) per parity
 V_DS = (136, 152)               # packed dS
 V_ST = (160, 192)               # statistics per parity: lse2 x16, D x16
-V_RR = 224                      # row-fragment ring (4 x 4)
-V_TRR = 240                     # transposed-fragment ring (4 x 4)
+V_DMAQ2, V_DMADO2 = 224, 225    # owned: the lane's second piece (16 rows further)
+V_HI = 226                      # owned: v20..v35 + 65536 (ring slots 4, 5 lie past the 16-bit offset field)
 V_T = 44                        # temps v44..v63
 A_DK, A_DV, A_K, A_V = 0, 64, 128, 160
+A_RR = 192                      # row-fragment ring (8 x 4)
+A_TRR = 224                     # transposed-fragment ring (8 x 4)
+NFR = 8
 
 
 class DKV(Gen):
@@ -92,10 +99,13 @@ class DKV(Gen):
         for ks in range(8):
             for (tens, acc, bfrag) in ((0, V_S[par], A_K), (1, V_DP[par], A_V)):
                 n = ks * 2 + tens
-                ring = V_RR + 4 * (n % 4)
+                ring = A_RR + 4 * (n % NFR)
                 off = stage_slot * STG + tens * 8192
-                rd = Ins(f"ds_read_b128 {vr(ring, 4)}, v{V_ROW + ks} offset:{off}", "lds", [f"v{V_ROW + ks}"], rl("v", ring, 4))
-                mf = self.mfma("v", acc, "v", ring, "a", bfrag + 4 * ks, ks == 0)
+                adr = V_ROW + ks
+                if off >= 65536:
+                    off, adr = off - 65536, V_HI + ks
+                rd = Ins(f"ds_read_b128 {ar(ring, 4)}, v{adr} offset:{off}", "lds", [f"v{adr}"], rl("a", ring, 4))
+                mf = self.mfma("v", acc, "a", ring, "a", bfrag + 4 * ks, ks == 0)
                 items.append((rd, mf))
         return items
 
@@ -106,11 +116,14 @@ class DKV(Gen):
         for t in range(2):
             for d in range(4):
                 for (tens, acc, b) in ((1, A_DV + 16 * d, V_P[par] + 4 * t), (0, A_DK + 16 * d, V_DS[par] + 4 * t)):
-                    ring = V_TRR + 4 * (n % 4)
+                    ring = A_TRR + 4 * (n % NFR)
                     off = stage_slot * STG + tens * 8192 + t * 4096
-                    rds = [Ins(f"ds_read_b64_tr_b16 {vr(ring + 2 * h, 2)}, v{V_TR + 4 * h + d} offset:{off}", "lds",
-                               [f"v{V_TR + 4 * h + d}"], rl("v", ring + 2 * h, 2)) for h in range(2)]
-                    mf = self.mfma("a", acc, "v", ring, "v", b, False)
+                    hi = off >= 65536
+                    off -= 65536 if hi else 0
+                    adr = [(V_HI + 8 if hi else V_TR) + 4 * h + d for h in range(2)]
+                    rds = [Ins(f"ds_read_b64_tr_b16 {ar(ring + 2 * h, 2)}, v{adr[h]} offset:{off}", "lds",
+                               [f"v{adr[h]}"], rl("a", ring + 2 * h, 2)) for h in range(2)]
+                    mf = self.mfma("a", acc, "a", ring, "v", b, False)
                     items.append((rds, mf))
                     n += 1
         return items
@@ -144,18 +157,17 @@ class DKV(Gen):
         return out
 
     def dma_stream(self, slot):
-        """stage it+2 -> ring slot: 2 Q pieces + 2 dO pieces per wave (source offsets in s[S_T+3], s[S_T+4], half a
-        stage = 16 rows in s[S_T+1], s[S_T+2]), the 256-byte statistics piece by wave 0 (offset s[S_T+5])"""
+        """stage it+3 -> ring slot: 2 Q pieces + 2 dO pieces per wave (source offsets in s[S_T+3], s[S_T+4]; the second
+        piece of a tile lies 16 rows further: its own lane offsets), the 256-byte statistics piece by wave 0
+        (offset s[S_T+5])"""
         g = []
         base = slot * STG
         t = S_T
-        for (rs, so, half, vo, toff) in ((S_QRS, t + 3, t + 1, V_DMAQ, 0), (S_DORS, t + 4, t + 2, V_DMADO, 8192)):
+        for (rs, so, vos, toff) in ((S_QRS, t + 3, (V_DMAQ, V_DMAQ2), 0), (S_DORS, t + 4, (V_DMADO, V_DMADO2), 8192)):
             for jj in range(2):
-                p = [Ins(f"s_add_u32 m0, s{S_W1024}, {base + toff + 4096 * jj}", "salu", [], ["m0", "scc"]),
-                     Ins(f"buffer_load_dwordx4 v{vo}, {sr(rs, 4)}, s{so} offen lds", "dma", ["m0", f"v{vo}", f"s{so}"], [])]
-                if jj == 0:
-                    p.append(Ins(f"s_add_u32 s{so}, s{so}, s{half}", "salu", [f"s{so}", f"s{half}"], [f"s{so}", "scc"]))
-                g.append(p)
+                vo = vos[jj]
+                g.append([Ins(f"s_add_u32 m0, s{S_W1024}, {base + toff + 4096 * jj}", "salu", [], ["m0", "scc"]),
+                          Ins(f"buffer_load_dwordx4 v{vo}, {sr(rs, 4)}, s{so} offen lds", "dma", ["m0", f"v{vo}", f"s{so}"], [])])
         u = self.uid()
         st = [Ins(f"s_cmp_eq_u32 s{S_W1024}, 0", "raw"), Ins(f"s_cbranch_scc0 L_ns{u}_%=", "raw"),
               Ins(f"s_mov_b32 m0, {STATS + slot * 256}", "raw"), Ins("s_nop 0", "raw"),
@@ -163,12 +175,24 @@ class DKV(Gen):
         g.append(st)
         return g
 
-    def gen_iteration(self, c, cfg):
-        """copy c (0..3): it = c - 1 (mod 4) at loop entry; stage it+1 lives in ring slot (c + 1) % 4 ... see slot()"""
+    def slots(self, c):
+        """copy c (0..5): it = c - 1 (mod 6) at loop entry; stage s lives in ring slot (s + 1) % 6 and in the register
+        buffers of parity s & 1 -> (slot of stage it-1, of stage it+1, of the DMA target it+3, parity of it, of it+-1)"""
+        return (c + 5) % NRING, (c + 1) % NRING, (c + 3) % NRING, (c + 1) % 2, c % 2
+
+    def pre_reads(self, c, pre):
+        """the transposed reads of the first `pre` dV / dK MFMAs of copy c (issued at the end of the previous copy)"""
+        sl_prev, _, _, _, par_oth = self.slots(c)
+        out = []
+        for (rds, mf) in self.dvdk_stream(sl_prev, par_oth)[:pre]:
+            out += rds
+        return out
+
+    def gen_iteration(self, c, cfg, carry):
+        """`carry`: the LDS queue the previous copy leaves behind (its statistics reads and our first `pre` reads)"""
         self.reset_dkv()
-        # it = c - 1 (mod 4); stage s lives in ring slot (s + 1) % 4 and in the register buffers of parity s & 1
-        sl_prev, sl_next, sl_dma = (c + 3) % NRING, (c + 1) % NRING, (c + 2) % NRING
-        par_cur, par_oth = (c + 1) % 2, c % 2              # parity of stage it | of stages it - 1 and it + 1
+        self.lds_q = [set(x) for x in carry]
+        sl_prev, sl_next, sl_dma, par_cur, par_oth = self.slots(c)
         A = self.raw
         t = S_T
         # ---- SALU head: mask predicate of stage `it` (virtual stages are masked completely) ...
@@ -186,9 +210,7 @@ class DKV(Gen):
         self.out.append(f"L_dm{u}_%=:")
         A(f"s_swappc_b64 {sr(S_RET, 2)}, {sr(S_MASKFN[par_cur], 2)}")
         self.out.append(f"L_nm{u}_%=:")
-        # ... and the source offsets of the stage the DMA stream points at (it + 2): zeros past the last real stage
-        A(f"s_lshr_b32 s{t + 1}, s{S_QROW32}, 1")
-        A(f"s_lshr_b32 s{t + 2}, s{S_DOROW32}, 1")
+        # ... and the source offsets of the stage the DMA stream points at (it + 3): zeros past the last real stage
         A(f"s_cmp_lt_i32 s{S_DIT}, s{S_NITER}")
         A(f"s_cselect_b32 s{t + 3}, s{S_DQS}, s{S_OOB}")
         A(f"s_cselect_b32 s{t + 4}, s{S_DDOS}, s{S_OOB}")
@@ -202,18 +224,14 @@ class DKV(Gen):
         # ---- interleave: 32 MFMAs = dV/dK of stage it-1 first (their operands are oldest), then S/dP of stage it+1
         mf_items = [("t", x) for x in dvdk] + [("r", x) for x in sdp]
         nv, vi = len(valu), 0
-        pre = cfg.get("pre", 3)
-        # pre-issue the reads of the first `pre` items
+        pre = cfg.get("pre", 7)
+        assert pre < NFR
         reads = []
         for kind, (rd, mf) in mf_items:
             reads.append(rd if isinstance(rd, list) else [rd])
-        issued = 0
-        for k in range(min(pre, len(mf_items))):
-            for r in reads[k]:
-                self.emit(r)
-            issued = k + 1
-        dma_at = cfg.get("dma_at", [2, 8, 14, 20, 26])
-        stats_at = cfg.get("stats_at", [17, 19, 21, 23, 25, 27, 29, 31])
+        issued = pre                                              # (the previous copy issued them)
+        dma_at = cfg.get("dma_at", [1, 7, 13, 19, 25])
+        stats_at = cfg.get("stats_at", [16, 18, 20, 22, 24, 26, 28, 30])
         M = len(mf_items)
         for k, (kind, (rd, mf)) in enumerate(mf_items):
             if issued < M:
@@ -239,7 +257,9 @@ class DKV(Gen):
         while vi < nv:
             self.emit(valu[vi])
             vi += 1
-        self.drain_lds()
+        for r in self.pre_reads((c + 1) % NRING, pre):
+            self.emit(r)
+        return [set(x) for x in self.lds_q]
 
     def _emit_any(self, ins):
         if ins.kind == "raw":
@@ -312,6 +332,7 @@ class DKV(Gen):
         L = []
         A = L.append
         t = S_T
+        pre = cfg.get("pre", 7)
         A("s_nop 7")
         A(f"s_getpc_b64 {sr(S_SUB, 2)}")
         A("L_pc_%=:")
@@ -324,8 +345,15 @@ class DKV(Gen):
         for ks in range(8):
             A(f"buffer_load_dwordx4 {ar(A_K + 4 * ks, 4)}, v{V_KOFF}, {sr(S_KRS, 4)}, 0 offen offset:{32 * ks}")
             A(f"buffer_load_dwordx4 {ar(A_V + 4 * ks, 4)}, v{V_VOFF}, {sr(S_VRS, 4)}, 0 offen offset:{32 * ks}")
-        # ---- ring slots 3 and 0 (virtual stages -2, -1): zeros through an out-of-range source; stage 0 -> slot 1
-        for slot in (3, 0):
+        # ---- lane offsets of the second piece of a tile (16 rows further)
+        A(f"s_lshr_b32 s{t}, s{S_QROW32}, 1")
+        A(f"v_add_u32 v{V_DMAQ2}, s{t}, v{V_DMAQ}")
+        A(f"s_lshr_b32 s{t}, s{S_DOROW32}, 1")
+        A(f"v_add_u32 v{V_DMADO2}, s{t}, v{V_DMADO}")
+        for i in range(16):
+            A(f"v_add_u32 v{V_HI + i}, 0x10000, v{V_ROW + i}")
+        # ---- ring slots 5 and 0 (virtual stages -2, -1): zeros through an out-of-range source
+        for slot in (NRING - 1, 0):
             for toff in (0, 8192):
                 for jj in range(2):
                     A(f"s_add_u32 m0, s{S_W1024}, {slot * STG + toff + 4096 * jj}")
@@ -336,24 +364,25 @@ class DKV(Gen):
         A(f"s_mul_i32 s{S_DQS}, s{S_MT0}, s{S_QROW32}")
         A(f"s_mul_i32 s{S_DDOS}, s{S_MT0}, s{S_DOROW32}")
         A(f"s_lshl_b32 s{S_DSTS}, s{S_MT0}, 7")
-        A(f"s_lshr_b32 s{t + 1}, s{S_QROW32}, 1")
-        A(f"s_lshr_b32 s{t + 2}, s{S_DOROW32}, 1")
-        A(f"s_cmp_lt_i32 s{S_DIT}, s{S_NITER}")
-        A(f"s_cselect_b32 s{t + 3}, s{S_DQS}, s{S_OOB}")
-        A(f"s_cselect_b32 s{t + 4}, s{S_DDOS}, s{S_OOB}")
-        A(f"s_cselect_b32 s{t + 5}, s{S_DSTS}, s{S_OOB}")
-        self.out = []
-        self.reset_dkv()
-        for grp in self.dma_stream(1):
-            for ins in grp:
-                self._emit_any(ins)
-        L += self.out
 
         def dma_advance():
             u = self.uid()
             return [x.replace("{u}", str(u)) for x in self.salu_advance()[3:]]
 
-        L += dma_advance()
+        # ---- stages 0, 1 -> slots 1, 2 (stage 2 is the first iteration's DMA)
+        for slot in (1, 2):
+            A(f"s_cmp_lt_i32 s{S_DIT}, s{S_NITER}")
+            A(f"s_cselect_b32 s{t + 3}, s{S_DQS}, s{S_OOB}")
+            A(f"s_cselect_b32 s{t + 4}, s{S_DDOS}, s{S_OOB}")
+            A(f"s_cselect_b32 s{t + 5}, s{S_DSTS}, s{S_OOB}")
+            A("s_nop 3")
+            self.out = []
+            self.reset_dkv()
+            for grp in self.dma_stream(slot):
+                for ins in grp:
+                    self._emit_any(ins)
+            L += self.out
+            L += dma_advance()
         # ---- state
         for i in range(128):
             A(f"v_accvgpr_write_b32 a{i}, 0")
@@ -370,23 +399,41 @@ class DKV(Gen):
         A(f"s_mov_b32 s{S_VMT}, s{S_MT0}")
         A(f"s_sub_u32 s{S_VMT}, s{S_VMT}, 1")                      # stage -1 (virtual): advanced to mt0 before stage 0
         A("s_waitcnt vmcnt(0)")
+        A("s_barrier")                                            # every wave's zero fill has landed
+        ko_lds = "lds" in self.ko or "ldsv" in self.ko
+        if not ko_lds:
+            for r in self.pre_reads(0, pre):
+                A(r.txt)
+        # ---- the loop: six copies; the LDS queue a copy leaves behind seeds the next one (two generation passes)
+        carries = {}
+        for c in range(NRING):
+            self.out, self.stats = [], {"nop_states": 0, "lgkm_waits": 0}
+            carries[c] = self.gen_iteration(c, cfg, [])
         report = {}
         for c in range(NRING):
             A(f"L_it{c}_%=:")
             if "bar" not in self.ko:
                 A("s_barrier")
             self.out, self.stats = [], {"nop_states": 0, "lgkm_waits": 0}
-            self.gen_iteration(c, cfg)
+            left = self.gen_iteration(c, cfg, carries[(c - 1) % NRING])
+            assert left == carries[c], "the carried LDS queue must not depend on its seed"
             report[c] = (dict(self.stats), len(self.out))
             L += self.out
-            # ---- tail: advance both streams; the DMA of this iteration must have landed before the next barrier
+            # ---- tail: advance both streams; the pieces of the PREVIOUS iteration must have landed before the next
+            # barrier (this iteration's stay in flight: 4 per wave, 5 on wave 0 which also fetches the statistics)
             u = self.uid()
             for x in self.salu_advance():
                 A(x.replace("{u}", str(u)))
             A(f"s_cmp_lt_i32 s{S_IT}, 0")                          # virtual stage -1 -> stage 0 starts at tile mt0
             A(f"s_cselect_b32 s{S_VMT}, s{S_MT0}, s{S_VMT}")
             if "vmwait" not in self.ko:
-                A("s_waitcnt vmcnt(0)")
+                A(f"s_cmp_eq_u32 s{S_W1024}, 0")
+                A(f"s_cbranch_scc1 L_w0{u}_%=")
+                A("s_waitcnt vmcnt(4)")
+                A(f"s_branch L_wj{u}_%=")
+                A(f"L_w0{u}_%=:")
+                A("s_waitcnt vmcnt(5)")
+                A(f"L_wj{u}_%=:")
             A(f"s_add_u32 s{S_IT}, s{S_IT}, 1")
             A(f"s_cmp_le_i32 s{S_IT}, s{S_NITER}")
             if c < NRING - 1:
@@ -394,7 +441,7 @@ class DKV(Gen):
             else:
                 A("s_cbranch_scc1 L_it0_%=")
         A("L_done_%=:")
-        A("s_waitcnt vmcnt(0)")
+        A("s_waitcnt vmcnt(0) lgkmcnt(0)")
         A("s_nop 7")
         A("s_nop 7")
         # ---- epilogue: dK * softmax_scale, dV -> 16 bit, row stores
@@ -425,7 +472,7 @@ class DKV(Gen):
 def clobbers():
     c = ["memory", "vcc", "scc", "m0"]
     c += [f"v{i}" for i in range(42, 256)]
-    c += [f"a{i}" for i in range(192)]
+    c += [f"a{i}" for i in range(256)]
     c += [f"s{i}" for i in range(S_IT, S_LAST + 1)]
     return c
 
@@ -442,6 +489,7 @@ def main():
     print("// GENERATED by gen_bwd_dkdv_asm.py - do not edit.  See that script for the schedule and the register map.")
     print("#pragma once")
     print(f"#define FA_BWD_ASM_LDS_BYTES {LDS_TOTAL}")
+    print(f"#define FA_BWD_ASM_STATS_OFF {STATS}")
     for dt in ("bf16", "f16"):
         g = DKV(dt)
         g.ko = ko
