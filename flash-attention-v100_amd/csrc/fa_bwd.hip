@@ -62,7 +62,7 @@ __global__ void __launch_bounds__(256) bwd_preprocess_kernel(const KArgs a) {
             const int64_t plane = (int64_t)p.batch * p.nheads_q * p.seqlen_q;
             const int64_t at = (b * p.nheads_q + h) * p.seqlen_q + i;
             a.stats_ws[at] = lse == -INFINITY ? INFINITY : lse * kLog2e;      // P = exp2(S c - lse2) = 0 for rows without keys
-            a.stats_ws[plane + at] = acc;
+            a.stats_ws[plane + at] = -acc;                                    // the dP accumulators start from -D
         }
     }
 }

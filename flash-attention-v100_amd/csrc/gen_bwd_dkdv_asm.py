@@ -44,12 +44,12 @@ S_QROW32, S_DOROW32 = 49, 50    # bytes of 32 rows of q / dO
 S_QHEAD, S_DOHEAD = 51, 52      # bytes between q heads in q / dO
 S_STHEAD = 53                   # bytes between heads in the statistics planes (seqlen_q * 4)
 S_W1024 = 54                    # wave * 1024
-S_QLOMAX, S_QHIMIN = 55, 56     # mask predicate: edge iff q0 < qlo_max or q0 + 31 > qhi_min (key tail: qhi_min = -1)
+S_TL, S_NFULL = 55, 56          # mask predicate in 32-row tiles: a stage is unmasked iff (tile - TL) <u NFULL
 # (the q / dO / statistics descriptors start at the FIRST q-head of the kv-head's group)
 # owned
 S_IT = 60
 S_T = 61                        # s61..s66 temps (s61: scratch; s64..s66: DMA source offsets of the iteration)
-S_DMT, S_DQS, S_DDOS, S_DSTS = 67, 68, 69, 70       # DMA stream: tile index, q / dO / stats soffsets
+S_DQEND, S_DQS, S_DDOS, S_DSTS = 67, 68, 69, 70     # DMA stream: q soffset of the head's tile mt1; q / dO / stats soffsets
 S_VMT = 71                      # VALU stream: tile index of stage `it`
 S_OOB = 72
 S_N0 = 73                       # q0 of the stage being masked
@@ -70,7 +70,8 @@ V_S = (64, 96)                  # S accumulators of the two buffer parities (16 
 V_DP = (80, 112)                # ... and dP
 V_P = (128, 144)                # packed P (8 regs) per parity
 V_DS = (136, 152)               # packed dS
-V_ST = (160, 192)               # statistics per parity: lse2 x16, D x16
+V_LSE = (160, 176)              # lse2 of the lane's 16 rows, per parity
+V_D = 192                       # -D of the lane's 16 rows (stage it+1): srcC of the first dP MFMA
 V_DMAQ2, V_DMADO2 = 224, 225    # owned: the lane's second piece (16 rows further)
 V_HI = 226                      # owned: v20..v35 + 65536 (ring slots 4, 5 lie past the 16-bit offset field)
 V_T = 44                        # temps v44..v63
@@ -106,6 +107,9 @@ class DKV(Gen):
                     off, adr = off - 65536, V_HI + ks
                 rd = Ins(f"ds_read_b128 {ar(ring, 4)}, v{adr} offset:{off}", "lds", [f"v{adr}"], rl("a", ring, 4))
                 mf = self.mfma("v", acc, "a", ring, "a", bfrag + 4 * ks, ks == 0)
+                if ks == 0 and tens == 1:          # dP = dO V^T - D: the accumulator starts from the -D rows
+                    mf = Ins(f"{self.mf} {vr(acc, 16)}, {ar(ring, 4)}, {ar(bfrag, 4)}, {vr(V_D, 16)}", "mfma",
+                             rl("a", ring, 4) + rl("a", bfrag, 4) + rl("v", V_D, 16), rl("v", acc, 16))
                 items.append((rd, mf))
         return items
 
@@ -129,21 +133,21 @@ class DKV(Gen):
         return items
 
     def stats_reads(self, slot, par):
-        """statistics of stage it+1 -> registers of the other parity (read by the VALU stream of the next iteration)"""
-        out = []
+        """statistics of stage it+1: (-D reads -> V_D, consumed by this iteration's first dP MFMA;
+        lse2 reads -> registers of the other parity, consumed by the VALU stream of the next iteration)"""
+        dd, ll = [], []
         for i in range(4):
-            for (which, base) in ((0, V_ST[par]), (1, V_ST[par] + 16)):
+            for (which, base, out) in ((1, V_D, dd), (0, V_LSE[par], ll)):
                 off = slot * 256 + which * 128 + i * 32          # the lane base (v36) carries STATS: past the 16-bit offset field
                 out.append(Ins(f"ds_read_b128 {vr(base + 4 * i, 4)}, v{V_STB} offset:{off}", "lds", [f"v{V_STB}"], rl("v", base + 4 * i, 4)))
-        return out
+        return dd, ll
 
     def valu_stream(self, par):
-        S, DP, ST = V_S[par], V_DP[par], V_ST[par]
+        S, DP, L = V_S[par], V_DP[par], V_LSE[par]
         out = []
         for r in range(16 + 3):
             if r < 16:
-                out.append(Ins(f"v_fma_f32 v{S + r}, v{S + r}, s{S_C}, -v{ST + r}", "valu", [f"v{S + r}", f"v{ST + r}"], [f"v{S + r}"]))
-                out.append(Ins(f"v_sub_f32 v{DP + r}, v{DP + r}, v{ST + 16 + r}", "valu", [f"v{DP + r}", f"v{ST + 16 + r}"], [f"v{DP + r}"]))
+                out.append(Ins(f"v_fma_f32 v{S + r}, v{S + r}, s{S_C}, -v{L + r}", "valu", [f"v{S + r}", f"v{L + r}"], [f"v{S + r}"]))
             if 0 <= r - 1 < 16:
                 q = r - 1
                 out.append(Ins(f"v_exp_f32 v{S + q}, v{S + q}", "trans", [f"v{S + q}"], [f"v{S + q}"]))
@@ -156,24 +160,23 @@ class DKV(Gen):
                     out.append(Ins(f"{self.cvt} v{V_DS[par] + e}, v{DP + q - 1}, v{DP + q}", "valu", [f"v{DP + q - 1}", f"v{DP + q}"], [f"v{V_DS[par] + e}"]))
         return out
 
-    def dma_stream(self, slot):
+    def dma_stream(self, slot, c):
         """stage it+3 -> ring slot: 2 Q pieces + 2 dO pieces per wave (source offsets in s[S_T+3], s[S_T+4]; the second
-        piece of a tile lies 16 rows further: its own lane offsets), the 256-byte statistics piece by wave 0
-        (offset s[S_T+5])"""
+        piece of a tile lies 16 rows further: its own lane offsets), then the 256-byte statistics piece by ONE wave
+        (copy c: wave c % 4; offset s[S_T+5]).  -> list of (m0 write, DMA) pairs + the statistics block"""
         g = []
         base = slot * STG
         t = S_T
         for (rs, so, vos, toff) in ((S_QRS, t + 3, (V_DMAQ, V_DMAQ2), 0), (S_DORS, t + 4, (V_DMADO, V_DMADO2), 8192)):
             for jj in range(2):
                 vo = vos[jj]
-                g.append([Ins(f"s_add_u32 m0, s{S_W1024}, {base + toff + 4096 * jj}", "salu", [], ["m0", "scc"]),
-                          Ins(f"buffer_load_dwordx4 v{vo}, {sr(rs, 4)}, s{so} offen lds", "dma", ["m0", f"v{vo}", f"s{so}"], [])])
+                g.append((Ins(f"s_add_u32 m0, s{S_W1024}, {base + toff + 4096 * jj}", "salu", [], ["m0", "scc"]),
+                          Ins(f"buffer_load_dwordx4 v{vo}, {sr(rs, 4)}, s{so} offen lds", "dma", ["m0", f"v{vo}", f"s{so}"], [])))
         u = self.uid()
-        st = [Ins(f"s_cmp_eq_u32 s{S_W1024}, 0", "raw"), Ins(f"s_cbranch_scc0 L_ns{u}_%=", "raw"),
-              Ins(f"s_mov_b32 m0, {STATS + slot * 256}", "raw"), Ins("s_nop 0", "raw"),
+        st = [Ins(f"s_mov_b32 m0, {STATS + slot * 256}", "raw"), Ins(f"s_cmp_eq_u32 s{S_W1024}, {1024 * (c % 4)}", "raw"),
+              Ins(f"s_cbranch_scc0 L_ns{u}_%=", "raw"),
               Ins(f"buffer_load_dword v{V_DMAST}, {sr(S_STRS, 4)}, s{t + 5} offen lds", "raw"), Ins(f"L_ns{u}_%=:", "raw")]
-        g.append(st)
-        return g
+        return g, st
 
     def slots(self, c):
         """copy c (0..5): it = c - 1 (mod 6) at loop entry; stage s lives in ring slot (s + 1) % 6 and in the register
@@ -188,25 +191,38 @@ class DKV(Gen):
             out += rds
         return out
 
+    def wait_regs(self, regs):
+        """one s_waitcnt covering every outstanding LDS read that writes one of `regs`"""
+        if "lds" in self.ko:
+            return
+        touched = set(regs)
+        idx = -1
+        for i, q in enumerate(self.lds_q):
+            if q & touched:
+                idx = i
+        if idx >= 0:
+            n_after = len(self.lds_q) - 1 - idx
+            if n_after < 15:
+                self.out.append(f"s_waitcnt lgkmcnt({n_after})")
+                self.now += 1
+                self.stats["lgkm_waits"] += 1
+            self.lds_q = self.lds_q[idx + 1:]
+
     def gen_iteration(self, c, cfg, carry):
-        """`carry`: the LDS queue the previous copy leaves behind (its statistics reads and our first `pre` reads)"""
+        """`carry`: the LDS queue the previous copy leaves behind (its lse2 reads and our first `pre` reads)"""
         self.reset_dkv()
         self.lds_q = [set(x) for x in carry]
         sl_prev, sl_next, sl_dma, par_cur, par_oth = self.slots(c)
         A = self.raw
         t = S_T
-        # ---- SALU head: mask predicate of stage `it` (virtual stages are masked completely) ...
+        # ---- SALU head: is stage `it` masked at all?  virtual stages (it = -1, it >= n_iter: one unsigned compare)
+        # and tiles outside [TL, TL + NFULL) call the mask routine ...
         u = self.uid()
-        A(f"s_lshl_b32 s{S_N0}, s{S_VMT}, 5")                                # q0 of stage it
-        A(f"s_cmp_lt_i32 s{S_IT}, 0")
+        A(f"s_cmp_ge_u32 s{S_IT}, s{S_NITER}")
         A(f"s_cbranch_scc1 L_dm{u}_%=")
-        A(f"s_cmp_ge_i32 s{S_IT}, s{S_NITER}")
-        A(f"s_cbranch_scc1 L_dm{u}_%=")
-        A(f"s_cmp_lt_i32 s{S_N0}, s{S_QLOMAX}")
-        A(f"s_cbranch_scc1 L_dm{u}_%=")
-        A(f"s_add_u32 s{t}, s{S_N0}, 31")
-        A(f"s_cmp_gt_i32 s{t}, s{S_QHIMIN}")
-        A(f"s_cbranch_scc0 L_nm{u}_%=")
+        A(f"s_sub_u32 s{t}, s{S_VMT}, s{S_TL}")
+        A(f"s_cmp_lt_u32 s{t}, s{S_NFULL}")
+        A(f"s_cbranch_scc1 L_nm{u}_%=")
         self.out.append(f"L_dm{u}_%=:")
         A(f"s_swappc_b64 {sr(S_RET, 2)}, {sr(S_MASKFN[par_cur], 2)}")
         self.out.append(f"L_nm{u}_%=:")
@@ -218,42 +234,51 @@ class DKV(Gen):
         # ---- streams
         sdp = self.sdp_stream(sl_next, par_oth)
         dvdk = self.dvdk_stream(sl_prev, par_oth)
-        stats = self.stats_reads(sl_next, par_oth)
+        d_reads, l_reads = self.stats_reads(sl_next, par_oth)
         valu = self.valu_stream(par_cur)
-        dma = self.dma_stream(sl_dma)
+        dma, dma_st = self.dma_stream(sl_dma, c)
         # ---- interleave: 32 MFMAs = dV/dK of stage it-1 first (their operands are oldest), then S/dP of stage it+1
         mf_items = [("t", x) for x in dvdk] + [("r", x) for x in sdp]
         nv, vi = len(valu), 0
         pre = cfg.get("pre", 7)
-        assert pre < NFR
+        wb = cfg.get("wait_batch", 2)                                # one lgkmcnt wait per `wb` MFMAs
+        assert pre < NFR and pre - (wb - 1) >= 3
         reads = []
         for kind, (rd, mf) in mf_items:
             reads.append(rd if isinstance(rd, list) else [rd])
         issued = pre                                              # (the previous copy issued them)
-        dma_at = cfg.get("dma_at", [1, 7, 13, 19, 25])
-        stats_at = cfg.get("stats_at", [16, 18, 20, 22, 24, 26, 28, 30])
+        dma_at = cfg.get("dma_at", [2, 8, 14, 20])
+        st_at = cfg.get("st_at", 26)
+        d_at = cfg.get("d_at", [1, 3, 5, 7])
+        l_at = cfg.get("l_at", [19, 23, 27, 30])
         M = len(mf_items)
         for k, (kind, (rd, mf)) in enumerate(mf_items):
             if issued < M:
                 for r in reads[issued]:
                     self.emit(r)
                 issued += 1
+            if k % wb == 0:                                           # operands of this MFMA and the next wb-1
+                regs = []
+                for kk in range(k, min(k + wb, M)):
+                    regs += mf_items[kk][1][1].rd
+                self.wait_regs([r for r in regs if not (r.startswith("v") and V_S[0] <= int(r[1:]) < V_P[0])])
             self.emit(mf)
-            if k in dma_at and dma:
-                for ins in dma.pop(0):
+            if (k + 1) in dma_at:
+                self.emit(dma[dma_at.index(k + 1)][0])                # M0 one slot ahead of its DMA
+            if k in dma_at:
+                self.emit(dma[dma_at.index(k)][1])
+            if k == st_at:
+                for ins in dma_st:
                     self._emit_any(ins)
-            if k in stats_at and stats:
-                self.emit(stats.pop(0))
+            if k in d_at:
+                self.emit(d_reads[d_at.index(k)])
+            if k in l_at:
+                self.emit(l_reads[l_at.index(k)])
             take = -(-(nv - vi) // (M - k))
             for _ in range(take):
                 if vi < nv:
                     self.emit(valu[vi])
                     vi += 1
-        for grp in dma:
-            for ins in grp:
-                self._emit_any(ins)
-        for ins in stats:
-            self.emit(ins)
         while vi < nv:
             self.emit(valu[vi])
             vi += 1
@@ -271,28 +296,25 @@ class DKV(Gen):
             self.emit(ins)
 
     def salu_advance(self):
-        """advance the VALU stream (stage it -> it+1) and the DMA stream (stage it+2 -> it+3): tile index wraps to
-        mt0 with the next q-head of the group; the statistics piece of the NEXT DMA stage is issued by wave 0."""
+        """advance the VALU stream (stage it -> it+1) and the DMA stream (stage it+3 -> it+4): past the head's last
+        tile both wrap to tile mt0 of the next q-head of the group"""
         o = []
         t = S_T
-        # VALU stream tile index
         o += [f"s_add_u32 s{S_VMT}, s{S_VMT}, 1",
               f"s_cmp_ge_i32 s{S_VMT}, s{S_MT1}",
               f"s_cselect_b32 s{S_VMT}, s{S_MT0}, s{S_VMT}"]
-        # DMA stream: next stage
         o += [f"s_add_u32 s{S_DIT}, s{S_DIT}, 1",
-              f"s_add_u32 s{S_DMT}, s{S_DMT}, 1",
               f"s_add_u32 s{S_DQS}, s{S_DQS}, s{S_QROW32}",
               f"s_add_u32 s{S_DDOS}, s{S_DDOS}, s{S_DOROW32}",
               f"s_add_u32 s{S_DSTS}, s{S_DSTS}, 128",
-              f"s_cmp_ge_i32 s{S_DMT}, s{S_MT1}",
+              f"s_cmp_ge_u32 s{S_DQS}, s{S_DQEND}",
               f"s_cbranch_scc0 L_nw{{u}}_%=",
               # wrap: next q-head, first tile
               f"s_sub_u32 s{t}, s{S_MT1}, s{S_MT0}",
-              f"s_mov_b32 s{S_DMT}, s{S_MT0}",
               f"s_mul_i32 s{t + 1}, s{t}, s{S_QROW32}",
               f"s_sub_u32 s{S_DQS}, s{S_DQS}, s{t + 1}",
               f"s_add_u32 s{S_DQS}, s{S_DQS}, s{S_QHEAD}",
+              f"s_add_u32 s{S_DQEND}, s{S_DQEND}, s{S_QHEAD}",
               f"s_mul_i32 s{t + 1}, s{t}, s{S_DOROW32}",
               f"s_sub_u32 s{S_DDOS}, s{S_DDOS}, s{t + 1}",
               f"s_add_u32 s{S_DDOS}, s{S_DDOS}, s{S_DOHEAD}",
@@ -306,16 +328,14 @@ class DKV(Gen):
         o = []
         S, T = V_S[par], V_T
         tlo, tinf = f"v{T}", f"v{T + 1}"
+        o.append(f"s_lshl_b32 s{S_N0}, s{S_VMT}, 5")                  # q0 of the stage
         o.append("s_nop 7")
         o.append("s_nop 3")
         o.append(f"v_subrev_u32 {tlo}, s{S_N0}, v{V_LOG}")           # lo_t = (qlo - 4g) - q0
         o.append(f"v_mov_b32 {tinf}, 0xff800000")
         # virtual stages: everything is masked
-        o.append(f"s_cmp_lt_i32 s{S_IT}, 0")
-        o.append(f"s_cbranch_scc1 L_mall{par}_%=")
-        o.append(f"s_cmp_ge_i32 s{S_IT}, s{S_NITER}")
+        o.append(f"s_cmp_ge_u32 s{S_IT}, s{S_NITER}")
         o.append(f"s_cbranch_scc0 L_mreg{par}_%=")
-        o.append(f"L_mall{par}_%=:")
         o.append(f"v_mov_b32 {tlo}, 0x3fffffff")
         o.append(f"L_mreg{par}_%=:")
         o.append("s_nop 0")
@@ -360,14 +380,14 @@ class DKV(Gen):
                     A("s_nop 0")
                     A(f"buffer_load_dwordx4 v{V_DMAQ}, {sr(S_QRS, 4)}, s{S_OOB} offen lds")
         A(f"s_mov_b32 s{S_DIT}, 0")
-        A(f"s_mov_b32 s{S_DMT}, s{S_MT0}")
+        A(f"s_mul_i32 s{S_DQEND}, s{S_MT1}, s{S_QROW32}")
         A(f"s_mul_i32 s{S_DQS}, s{S_MT0}, s{S_QROW32}")
         A(f"s_mul_i32 s{S_DDOS}, s{S_MT0}, s{S_DOROW32}")
         A(f"s_lshl_b32 s{S_DSTS}, s{S_MT0}, 7")
 
         def dma_advance():
             u = self.uid()
-            return [x.replace("{u}", str(u)) for x in self.salu_advance()[3:]]
+            return [x.replace("{u}", str(u)) for x in self.salu_advance()[3:]]      # (the DMA stream only)
 
         # ---- stages 0, 1 -> slots 1, 2 (stage 2 is the first iteration's DMA)
         for slot in (1, 2):
@@ -378,9 +398,12 @@ class DKV(Gen):
             A("s_nop 3")
             self.out = []
             self.reset_dkv()
-            for grp in self.dma_stream(slot):
-                for ins in grp:
-                    self._emit_any(ins)
+            pairs, st = self.dma_stream(slot, 0)                   # (statistics piece: wave 0)
+            for (m0w, ld) in pairs:
+                self.emit(m0w)
+                self.emit(ld)
+            for ins in st:
+                self._emit_any(ins)
             L += self.out
             L += dma_advance()
         # ---- state
@@ -393,8 +416,8 @@ class DKV(Gen):
             for r in range(8):
                 A(f"v_mov_b32 v{V_P[par] + r}, 0")
                 A(f"v_mov_b32 v{V_DS[par] + r}, 0")
-            for r in range(32):
-                A(f"v_mov_b32 v{V_ST[par] + r}, 0")
+            for r in range(16):
+                A(f"v_mov_b32 v{V_LSE[par] + r}, 0")
         A(f"s_mov_b32 s{S_IT}, -1")
         A(f"s_mov_b32 s{S_VMT}, s{S_MT0}")
         A(f"s_sub_u32 s{S_VMT}, s{S_VMT}, 1")                      # stage -1 (virtual): advanced to mt0 before stage 0
@@ -424,16 +447,8 @@ class DKV(Gen):
             u = self.uid()
             for x in self.salu_advance():
                 A(x.replace("{u}", str(u)))
-            A(f"s_cmp_lt_i32 s{S_IT}, 0")                          # virtual stage -1 -> stage 0 starts at tile mt0
-            A(f"s_cselect_b32 s{S_VMT}, s{S_MT0}, s{S_VMT}")
             if "vmwait" not in self.ko:
-                A(f"s_cmp_eq_u32 s{S_W1024}, 0")
-                A(f"s_cbranch_scc1 L_w0{u}_%=")
-                A("s_waitcnt vmcnt(4)")
-                A(f"s_branch L_wj{u}_%=")
-                A(f"L_w0{u}_%=:")
-                A("s_waitcnt vmcnt(5)")
-                A(f"L_wj{u}_%=:")
+                A("s_waitcnt vmcnt(4)")      # (the wave that fetched the statistics, last, also waits for its first tile piece)
             A(f"s_add_u32 s{S_IT}, s{S_IT}, 1")
             A(f"s_cmp_le_i32 s{S_IT}, s{S_NITER}")
             if c < NRING - 1:
