@@ -32,7 +32,12 @@ from gen_fwd_asm import Ins, Gen, rl, vr, ar, sr
 STG = 16384                    # one stage: Q tile 8 KiB + dO tile 8 KiB
 NRING = 6
 STATS = NRING * STG            # 6 x 256 B: [lse2 x 32 | D x 32] per ring slot
-LDS_TOTAL = STATS + NRING * 256
+KST = 3 * STG                   # prologue: K tiles of the four waves (8 KiB each) staged in ring slots 3, 4 ...
+VST = STATS + NRING * 256       # ... and the V tiles behind the statistics
+LDS_TOTAL = VST + 4 * 8192
+EP_PITCH = 272                  # epilogue: per-wave [32 keys][256 B + 16] images of dK and dV (bank-conflict-free 8-byte writes)
+EP_T = 32 * EP_PITCH            # one tensor
+EP_WAVE = 2 * EP_T              # one wave
 
 # ------------------------------------------------------------------ SGPRs
 S_QRS, S_DORS, S_KRS, S_VRS, S_DKRS, S_DVRS, S_STRS = 16, 20, 24, 28, 32, 36, 40     # buffer descriptors (s40: stats workspace)
@@ -59,8 +64,9 @@ S_DIT = 82                      # DMA stream: stage index it + 3
 S_LAST = 83
 
 # ------------------------------------------------------------------ VGPRs
-V_KOFF, V_VOFF = 16, 17         # in: per-lane global offsets of the K / V fragment loads
-V_DKOFF, V_DVOFF = 18, 19       # in: dK / dV store offsets
+V_CBS = 16                      # in: v16..v19 = swizzled column byte of the lane's 16-byte DMA chunk for rows 4p + (lane >> 4), p = 0..3
+V_KRB, V_VRB = 42, 43           # in (uniform): bytes per K / V row
+V_DKRB, V_DVRB, V_KW0 = 208, 209, 210   # in (uniform): bytes per dK / dV row, first key of the wave
 V_ROW = 20                      # in: 8 row-read addresses (swzt image, tile-relative)
 V_TR = 28                       # in: 8 transposed-read addresses [h][d]
 V_STB = 36                      # in: statistics read base (16 g)
@@ -74,6 +80,8 @@ V_LSE = (160, 176)              # lse2 of the lane's 16 rows, per parity
 V_D = 192                       # -D of the lane's 16 rows (stage it+1): srcC of the first dP MFMA
 V_DMAQ2, V_DMADO2 = 224, 225    # owned: the lane's second piece (16 rows further)
 V_HI = 226                      # owned: v20..v35 + 65536 (ring slots 4, 5 lie past the 16-bit offset field)
+V_EP = 212                      # epilogue: eight 4-register entries v212..v243 (the loop's owned registers are dead by then)
+V_TM = 244                      # measurement build: four time stamps
 V_T = 44                        # temps v44..v63
 A_DK, A_DV, A_K, A_V = 0, 64, 128, 160
 A_RR = 192                      # row-fragment ring (8 x 4)
@@ -353,7 +361,15 @@ class DKV(Gen):
         A = L.append
         t = S_T
         pre = cfg.get("pre", 7)
+        timers = cfg.get("timers", 0)          # measurement build: four s_memtime stamps land in the lane's dK row
+
+        def stamp(i):
+            if timers:
+                A(f"s_memtime {sr(t + 1, 2)}")
+                A("s_waitcnt lgkmcnt(0)")
+                A(f"v_mov_b32 v{V_TM + i}, s{t + 1}")
         A("s_nop 7")
+        stamp(0)
         A(f"s_getpc_b64 {sr(S_SUB, 2)}")
         A("L_pc_%=:")
         for (reg, lab) in ((S_MASKFN[0], "L_mask0"), (S_MASKFN[1], "L_mask1")):
@@ -361,10 +377,32 @@ class DKV(Gen):
             A(f"s_addc_u32 s{reg + 1}, s{S_SUB + 1}, 0")
         A(f"s_mov_b32 s{S_OOB}, 0x80000000")
         A("s_barrier")                                            # previous pass is done with LDS
-        # ---- K / V fragments of this wave's 32 keys
-        for ks in range(8):
-            A(f"buffer_load_dwordx4 {ar(A_K + 4 * ks, 4)}, v{V_KOFF}, {sr(S_KRS, 4)}, 0 offen offset:{32 * ks}")
-            A(f"buffer_load_dwordx4 {ar(A_V + 4 * ks, 4)}, v{V_VOFF}, {sr(S_VRS, 4)}, 0 offen offset:{32 * ks}")
+        # ---- K / V tiles of this wave's 32 keys: eight 4-row LDS-DMA pieces each (whole 256-byte rows from memory)
+        # into a wave-private staging area, read back as MFMA B fragments once everything has landed
+        T = V_T
+        A(f"v_mbcnt_lo_u32_b32 v{T}, -1, 0")
+        A(f"v_mbcnt_hi_u32_b32 v{T}, -1, v{T}")                   # lane
+        A(f"v_lshrrev_b32 v{T + 1}, 4, v{T}")                     # lane >> 4
+        A(f"v_readfirstlane_b32 s{t}, v{V_KRB}")
+        A(f"v_readfirstlane_b32 s{t + 1}, v{V_VRB}")
+        A(f"v_readfirstlane_b32 s{t + 2}, v{V_KW0}")
+        A("s_nop 4")
+        for pp in range(4):
+            A(f"v_add_u32 v{T + 10}, {4 * pp}, v{T + 1}")
+            A(f"v_mad_u32_u24 v{T + 2 + pp}, v{T + 10}, s{t}, v{V_CBS + pp}")
+            A(f"v_mad_u32_u24 v{T + 6 + pp}, v{T + 10}, s{t + 1}, v{V_CBS + pp}")
+        A(f"s_mul_i32 s{t + 3}, s{t + 2}, s{t}")                  # byte offset of the wave's first key row
+        A(f"s_mul_i32 s{t + 4}, s{t + 2}, s{t + 1}")
+        A(f"s_lshl_b32 s{t}, s{t}, 4")
+        A(f"s_lshl_b32 s{t + 1}, s{t + 1}, 4")
+        A(f"s_add_u32 s{t}, s{t}, s{t + 3}")                      # ... and of its 16th
+        A(f"s_add_u32 s{t + 1}, s{t + 1}, s{t + 4}")
+        A(f"s_lshl_b32 s{t + 5}, s{S_W1024}, 3")                  # wave * 8192
+        for (st0, vb, rs, so) in ((KST, T + 2, S_KRS, (t + 3, t)), (VST, T + 6, S_VRS, (t + 4, t + 1))):
+            for pc in range(8):
+                A(f"s_add_u32 m0, s{t + 5}, {st0 + 1024 * pc}")
+                A("s_nop 0")
+                A(f"buffer_load_dwordx4 v{vb + pc % 4}, {sr(rs, 4)}, s{so[pc // 4]} offen lds")
         # ---- lane offsets of the second piece of a tile (16 rows further)
         A(f"s_lshr_b32 s{t}, s{S_QROW32}, 1")
         A(f"v_add_u32 v{V_DMAQ2}, s{t}, v{V_DMAQ}")
@@ -422,7 +460,17 @@ class DKV(Gen):
         A(f"s_mov_b32 s{S_VMT}, s{S_MT0}")
         A(f"s_sub_u32 s{S_VMT}, s{S_VMT}, 1")                      # stage -1 (virtual): advanced to mt0 before stage 0
         A("s_waitcnt vmcnt(0)")
-        A("s_barrier")                                            # every wave's zero fill has landed
+        A(f"s_lshl_b32 s{t + 5}, s{S_W1024}, 3")
+        A(f"s_add_u32 s{t + 4}, s{t + 5}, {VST}")
+        for ks in range(8):
+            A(f"v_add_u32 v{T + ks}, s{t + 5}, v{V_ROW + ks}")
+            A(f"v_add_u32 v{T + 8 + ks}, s{t + 4}, v{V_ROW + ks}")
+        for ks in range(8):
+            A(f"ds_read_b128 {ar(A_K + 4 * ks, 4)}, v{T + ks} offset:{KST}")
+            A(f"ds_read_b128 {ar(A_V + 4 * ks, 4)}, v{T + 8 + ks}")
+        A("s_waitcnt lgkmcnt(0)")
+        stamp(1)
+        A("s_barrier")                                            # every wave's zero fill has landed, K / V staging is free
         ko_lds = "lds" in self.ko or "ldsv" in self.ko
         if not ko_lds:
             for r in self.pre_reads(0, pre):
@@ -457,25 +505,66 @@ class DKV(Gen):
                 A("s_cbranch_scc1 L_it0_%=")
         A("L_done_%=:")
         A("s_waitcnt vmcnt(0) lgkmcnt(0)")
-        A("s_nop 7")
-        A("s_nop 7")
-        # ---- epilogue: dK * softmax_scale, dV -> 16 bit, row stores
+        stamp(2)
+        A("s_barrier")                                            # every wave is done with the stage ring
+        # ---- epilogue: dK * softmax_scale, dV -> 16 bit; through a wave-private LDS image so that the stores cover
+        # whole 256-byte rows (4 rows per instruction) instead of 8-byte shreds of 32 rows
         T = V_T
-        for (acc, voff, rs, scale) in ((A_DK, V_DKOFF, S_DKRS, True), (A_DV, V_DVOFF, S_DVRS, False)):
+        A(f"v_mbcnt_lo_u32_b32 v{T}, -1, 0")
+        A(f"v_mbcnt_hi_u32_b32 v{T}, -1, v{T}")                   # lane
+        A(f"v_and_b32 v{T + 1}, 31, v{T}")                        # key of the accumulator columns
+        A(f"v_lshrrev_b32 v{T + 2}, 5, v{T}")                     # g
+        A(f"v_lshrrev_b32 v{T + 3}, 4, v{T}")                     # lane >> 4: row of the lane's 16-byte chunk
+        A(f"v_and_b32 v{T + 4}, 15, v{T}")
+        A(f"v_lshlrev_b32 v{T + 4}, 4, v{T + 4}")                 # its column byte
+        A(f"s_mul_i32 s{t}, s{S_W1024}, {EP_WAVE // 1024}")       # wave * EP_WAVE
+        A(f"v_mul_u32_u24 v{T + 5}, {EP_PITCH}, v{T + 1}")
+        A(f"v_lshl_add_u32 v{T + 5}, v{T + 2}, 3, v{T + 5}")
+        A(f"v_add_u32 v{T + 5}, s{t}, v{T + 5}")                  # write base: key * pitch + 8 g
+        A(f"v_mul_u32_u24 v{T + 6}, {EP_PITCH}, v{T + 3}")
+        A(f"v_add3_u32 v{T + 6}, v{T + 6}, v{T + 4}, s{t}")       # read base: row * pitch + column byte
+        A(f"v_readfirstlane_b32 s{t + 1}, v{V_DKRB}")
+        A(f"v_readfirstlane_b32 s{t + 2}, v{V_DVRB}")
+        A(f"v_readfirstlane_b32 s{t + 3}, v{V_KW0}")
+        A("s_nop 4")
+        A(f"v_add_u32 v{T + 3}, s{t + 3}, v{T + 3}")              # global row
+        A(f"v_mad_u32_u24 v{T + 7}, v{T + 3}, s{t + 1}, v{T + 4}")   # dK byte offset of the lane's chunk
+        A(f"v_mad_u32_u24 v{T + 8}, v{T + 3}, s{t + 2}, v{T + 4}")   # dV
+        A(f"s_lshl_b32 s{t + 1}, s{t + 1}, 2")                    # 4 rows further
+        A(f"s_lshl_b32 s{t + 2}, s{t + 2}, 2")
+        A("s_nop 7")
+        for ti, (acc, scale) in enumerate(((A_DK, True), (A_DV, False))):
             for d in range(4):
                 for r4 in range(4):
                     base = acc + 16 * d + 4 * r4
-                    tt = T + 4 * (r4 & 1)
+                    tt = T + 10 + 4 * (r4 & 1)
                     for e in range(4):
                         A(f"v_accvgpr_read_b32 v{tt + e}, a{base + e}")
                     if scale:
                         for e in range(4):
                             A(f"v_mul_f32 v{tt + e}, s{S_SCALE}, v{tt + e}")
-                    pk = T + 8 + 2 * (r4 & 1)
+                    pk = V_EP + 2 * ((4 * d + r4) % 8)
                     A(f"{self.cvt} v{pk}, v{tt}, v{tt + 1}")
                     A(f"{self.cvt} v{pk + 1}, v{tt + 2}, v{tt + 3}")
-                    A(f"buffer_store_dwordx2 {vr(pk, 2)}, v{voff}, {sr(rs, 4)}, 0 offen offset:{64 * d + 16 * r4}")
-        A("s_waitcnt vmcnt(0)")
+                    A(f"ds_write_b64 v{T + 5}, {vr(pk, 2)} offset:{ti * EP_T + 64 * d + 16 * r4}")
+        A("s_waitcnt lgkmcnt(0)")
+        for ti, (voff, rs, step) in enumerate(((T + 7, S_DKRS, t + 1), (T + 8, S_DVRS, t + 2))):
+            A(f"s_mov_b32 s{t + 4}, 0")
+            for j in range(8):
+                A(f"ds_read_b128 {vr(V_EP + 4 * j, 4)}, v{T + 6} offset:{ti * EP_T + 4 * EP_PITCH * j}")
+            for j in range(8):
+                A(f"s_waitcnt lgkmcnt({7 - j})")
+                A(f"buffer_store_dwordx4 {vr(V_EP + 4 * j, 4)}, v{voff}, {sr(rs, 4)}, s{t + 4} offen")
+                A(f"s_add_u32 s{t + 4}, s{t + 4}, s{step}")
+            A("s_nop 1")
+        if timers:
+            A("s_waitcnt vmcnt(0)")
+            stamp(3)
+            A("s_mov_b64 exec, 1")
+            for i in range(4):
+                A(f"buffer_store_dword v{V_TM + i}, v{T + 7}, {sr(S_DKRS, 4)}, 0 offen offset:{16 * i}")
+            A("s_mov_b64 exec, -1")
+            A("s_waitcnt vmcnt(0)")
         A("s_branch L_end_%=")
         for par in (0, 1):
             A(f"L_mask{par}_%=:")
@@ -486,7 +575,7 @@ class DKV(Gen):
 
 def clobbers():
     c = ["memory", "vcc", "scc", "m0"]
-    c += [f"v{i}" for i in range(42, 256)]
+    c += [f"v{i}" for i in range(44, 256) if i not in (V_DKRB, V_DVRB, V_KW0)]
     c += [f"a{i}" for i in range(256)]
     c += [f"s{i}" for i in range(S_IT, S_LAST + 1)]
     return c

@@ -23,6 +23,13 @@ __global__ void __launch_bounds__(512) k(unsigned long long* out, float* sink, i
   __shared__ float lds[4096];
   f16v c0 = {}, c1 = {}, c2 = {}, c3 = {}, c4 = {}, c5 = {}, c6 = {}, c7 = {};
   s8v a = {1, 2, 3, 4, 5, 6, 7, 8}, b = {1, 1, 1, 1, 1, 1, 1, 1};
+  if (iters > 10000) {   // chip-wide runs: pseudo-random bf16 operands in (-2, 2) (data toggling sets the MFMA power draw)
+    unsigned h = (threadIdx.x + 977u * blockIdx.x) * 2654435761u;
+    for (int i = 0; i < 8; ++i) {
+      h = h * 1664525u + 1013904223u; a[i] = (short)(((h >> 16) & 0x807f) | 0x3f80);
+      h = h * 1664525u + 1013904223u; b[i] = (short)(((h >> 16) & 0x807f) | 0x3f00);
+    }
+  }
   float x0 = threadIdx.x, x1 = 1.f, x2 = 2.f;
   double p0 = threadIdx.x, p1 = 3.0;
   typedef float f4 __attribute__((ext_vector_type(4)));
@@ -76,7 +83,31 @@ template <int P> void run(const char* name, int per_iter) {
            (double)h / (iters * 20 * 8.0 * per_iter), per_iter, (double)h / (ms * 1e3), ms * 1e6 / (iters * 20 * 8.0 * per_iter));
   }
 }
+template <int P> void run_full(const char* name, int per_iter) {
+  // every CU busy: does the shader clock hold under chip-wide MFMA load?  (ticks/us = effective clock in MHz)
+  unsigned long long* d; float* s;
+  (void)hipMalloc(&d, 8 * 8192); (void)hipMalloc(&s, 4096);
+  const int iters = 20000;
+  hipLaunchKernelGGL(k<P>, dim3(1024), dim3(256), 0, 0, d, s, iters);
+  hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  (void)hipEventRecord(e0, 0);
+  hipLaunchKernelGGL(k<P>, dim3(1024), dim3(256), 0, 0, d, s, iters);
+  (void)hipEventRecord(e1, 0);
+  (void)hipEventSynchronize(e1);
+  float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
+  unsigned long long h[1024];
+  (void)hipMemcpy(h, d, 8 * 1024, hipMemcpyDeviceToHost);
+  double avg = 0; for (int i = 0; i < 1024; ++i) avg += (double)h[i]; avg /= 1024;
+  // 1024 blocks over 256 CUs, one block per CU at a time (launch bounds 512 threads... the register use lets several
+  // blocks share a CU: the per-block tick count and the wall time give the clock only together with the residency)
+  printf("%-30s chip-wide: %.2f ticks per unit per block, kernel %.3f ms, sum of block ticks / wall = %.0f MHz x blocks-in-flight/CU\n",
+         name, avg / (iters * 8.0 * per_iter), ms, avg * 1024 / 256 / (ms * 1e3));
+  double flops = 1024.0 * 4 * iters * 8.0 * per_iter * 32768.0;
+  if (P == 0) printf("   MFMA rate: %.0f TFLOP/s dense bf16\n", flops / (ms * 1e-3) / 1e12);
+}
 int main() {
+  run_full<0>("mfma only", 8);
+  run_full<6>("mfma + 3 fma", 4);
   run<0>("mfma only (unit = mfma)", 8);
   run<1>("v_fma_f32 (unit = instr)", 24);
   run<2>("v_pk_fma_f32 (unit = instr)", 24);
