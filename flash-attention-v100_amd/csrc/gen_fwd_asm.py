@@ -27,7 +27,7 @@ import sys
 # ----------------------------------------------------------------------------- register map
 # VGPR (v0-v15 are left to the compiler)
 V_QOFF = (16, 17)        # in: Q voffset of qb0 / qb1 (prologue only)
-V_OOFF = (18, 19)        # in: O voffset
+V_ORB, V_R0 = 18, 19     # in (uniform): bytes per O row, first row of the wave's 64
 V_LSEOFF = (20, 21)      # in: LSE voffset
 V_DMAK, V_DMAV = 22, 23  # in: LDS-DMA source voffsets
 V_KBASE = 24             # in: 8 regs, K fragment read address (stage 0)
@@ -773,12 +773,35 @@ class Gen:
             L += self.gen_mask_routine(qb)
             A(f"L_resc{qb}_%=:")
             L += self.gen_rescale_routine(qb)
-        # ---- epilogue
+        # ---- epilogue: O / l -> 16 bit, LSE.  O goes through a wave-private LDS image ([64 rows][256 B + 16]) so that the
+        # stores cover whole 256-byte rows (4 rows per instruction) instead of 8-byte shreds of 32 rows
+        EP_PITCH, EP_QB = 272, 32 * 272
         A("L_done_%=:")
-        A("s_waitcnt vmcnt(0)")
-        A("s_nop 7")
-        A("s_nop 7")
+        A("s_waitcnt vmcnt(0) lgkmcnt(0)")
+        A("s_barrier")                                   # every wave is done with the K / V ring
         T = V_T
+        t = S_TMP
+        lane, wbase, rbase, goff = T + 20, T + 21, T + 22, T + 23
+        A(f"v_mbcnt_lo_u32_b32 v{lane}, -1, 0")
+        A(f"v_mbcnt_hi_u32_b32 v{lane}, -1, v{lane}")
+        A(f"v_and_b32 v{T + 24}, 31, v{lane}")                     # q row of the accumulator columns
+        A(f"v_lshrrev_b32 v{T + 25}, 5, v{lane}")                  # g
+        A(f"v_lshrrev_b32 v{T + 26}, 4, v{lane}")                  # lane >> 4: row of the lane's 16-byte chunk
+        A(f"v_and_b32 v{T + 27}, 15, v{lane}")
+        A(f"v_lshlrev_b32 v{T + 27}, 4, v{T + 27}")                # its column byte
+        A(f"s_mul_i32 s{t}, s{S_W1024}, {2 * EP_QB // 1024}")      # wave * 17408
+        A(f"v_mul_u32_u24 v{wbase}, {EP_PITCH}, v{T + 24}")
+        A(f"v_lshl_add_u32 v{wbase}, v{T + 25}, 3, v{wbase}")
+        A(f"v_add_u32 v{wbase}, s{t}, v{wbase}")                   # write base: row * pitch + 8 g
+        A(f"v_mul_u32_u24 v{rbase}, {EP_PITCH}, v{T + 26}")
+        A(f"v_add3_u32 v{rbase}, v{rbase}, v{T + 27}, s{t}")       # read base: row * pitch + column byte
+        A(f"v_readfirstlane_b32 s{t + 1}, v{V_ORB}")
+        A(f"v_readfirstlane_b32 s{t + 2}, v{V_R0}")
+        A("s_nop 4")
+        A(f"v_add_u32 v{T + 26}, s{t + 2}, v{T + 26}")             # global row
+        A(f"v_mad_u32_u24 v{goff}, v{T + 26}, s{t + 1}, v{T + 27}")   # byte offset of the lane's chunk
+        A(f"s_lshl_b32 s{t + 1}, s{t + 1}, 2")                     # 4 rows further
+        A("s_nop 7")
         for qb in range(2):
             l, mrun = f"v{V_L[qb]}", f"v{V_MRUN[qb]}"
             ta, lt, inv, lse, zero = f"v{T}", f"v{T + 1}", f"v{T + 2}", f"v{T + 3}", f"v{T + 4}"
@@ -803,10 +826,20 @@ class Gen:
                         A(f"v_accvgpr_read_b32 v{tt + e}, a{base + e}")
                     for e in range(4):
                         A(f"v_mul_f32 v{tt + e}, v{tt + e}, {inv}")
-                    pk = T + 16 + 2 * (r4 & 1)
+                    pk = V_S[1] + 2 * ((4 * d + r4) % 8)
                     A(f"{self.cvt} v{pk}, v{tt}, v{tt + 1}")
                     A(f"{self.cvt} v{pk + 1}, v{tt + 2}, v{tt + 3}")
-                    A(f"buffer_store_dwordx2 {vr(pk, 2)}, v{V_OOFF[qb]}, {sr(S_ORS, 4)}, 0 offen offset:{64 * d + 16 * r4}")
+                    A(f"ds_write_b64 v{wbase}, {vr(pk, 2)} offset:{qb * EP_QB + 64 * d + 16 * r4}")
+        A("s_waitcnt lgkmcnt(0)")
+        A(f"s_mov_b32 s{t + 3}, 0")
+        for qb in range(2):
+            for j in range(8):
+                A(f"ds_read_b128 {vr(V_S[0] + 4 * j, 4)}, v{rbase} offset:{qb * EP_QB + 4 * EP_PITCH * j}")
+            for j in range(8):
+                A(f"s_waitcnt lgkmcnt({7 - j})")
+                A(f"buffer_store_dwordx4 {vr(V_S[0] + 4 * j, 4)}, v{goff}, {sr(S_ORS, 4)}, s{t + 3} offen")
+                A(f"s_add_u32 s{t + 3}, s{t + 3}, s{t + 1}")
+            A("s_nop 1")
         A("s_waitcnt vmcnt(0)")
         return L, report
 
@@ -820,7 +853,7 @@ DEFAULT_CFG = {
 
 def clobbers():
     c = ["memory", "vcc", "scc", "m0"]
-    c += [f"v{i}" for i in range(37, 256)]
+    c += [f"v{i}" for i in range(37, 256)]      # (v16..v36 are inputs)
     c += [f"a{i}" for i in range(256)]
     c += [f"s{i}" for i in range(S_R0, S_LAST + 1)]
     return c
