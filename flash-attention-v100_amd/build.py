@@ -16,6 +16,8 @@ LIB = os.path.join(OUT_DIR, "libfa_mi355.so")
 SOURCES = ["fa_api.hip", "fa_fwd.hip", "fa_fwd_asm.hip", "fa_fwd_ws.hip", "fa_bwd.hip", "fa_bwd_asm.hip", "fa_kvcache.hip", "fa_decode.hip", "fa_rows.hip"]
 GENERATED = [("gen_fwd_asm.py", "fa_fwd_asm_gen.h"), ("gen_fwd_ws.py", "fa_fwd_ws_gen.h"),
              ("gen_bwd_dkdv_asm.py", "fa_bwd_asm_gen.h")]      # (generator, header): hand-scheduled asm bodies
+ASM_SOURCES = ("fa_fwd_asm.hip", "fa_fwd_ws.hip", "fa_bwd_asm.hip")   # kernels whose body is one hand-scheduled asm statement
+RESOURCES = os.path.join(OUT_DIR, "kernel_resources.json")              # their register / scratch use, checked at build time
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"),
          "-I" + CSRC, "-Wno-unused-value"]
 
@@ -46,6 +48,39 @@ def _generate():
                 f.write(txt)
 
 
+def _asm_kernel_resources(log):
+    """Parse hipcc's -Rpass-analysis=kernel-resource-usage remarks: {kernel: {"vgpr", "agpr", "sgpr", "spill", "scratch", "lds"}}."""
+    import re
+    res, cur = {}, None
+    for line in log.splitlines():
+        m = re.search(r"remark: +(?:[^ ]+: )?(Function Name|VGPRs|AGPRs|SGPRs|VGPRs Spill|SGPRs Spill|ScratchSize \[bytes/lane\]|LDS Size \[bytes/block\]): (\S+)", line)
+        if not m:
+            continue
+        k, v = m.group(1), m.group(2)
+        if k == "Function Name":
+            cur = res.setdefault(v, {})
+        elif cur is not None:
+            key = {"VGPRs": "vgpr", "AGPRs": "agpr", "SGPRs": "sgpr", "VGPRs Spill": "spill", "SGPRs Spill": "sgpr_spill",
+                   "ScratchSize [bytes/lane]": "scratch", "LDS Size [bytes/block]": "lds"}[k]
+            cur[key] = int(v)
+    return res
+
+
+def _check_asm_kernels(all_res):
+    """A hand-scheduled body owns its registers: a spill, scratch use or more than 256 + 256 registers means the
+    compiler had to work around the asm statement's constraints (and a 257-register kernel does not even load)."""
+    bad = []
+    for name, r in all_res.items():
+        if "asm_kernel" not in name and "ws_kernel" not in name:
+            continue
+        total_cap = 256 if "ws_kernel" in name else 512            # two waves per SIMD | one
+        if (r.get("spill", 0) or r.get("sgpr_spill", 0) or r.get("scratch", 0) or r.get("vgpr", 0) > 256 or r.get("agpr", 0) > 256
+                or r.get("vgpr", 0) + r.get("agpr", 0) > total_cap):
+            bad.append(f"{name}: {r}")
+    if bad:
+        raise RuntimeError("asm kernel resource check failed:\n" + "\n".join(bad))
+
+
 def build(force=False, verbose=False, defines=(), out=None):
     """Compile every HIP source for gfx950 and link libfa_mi355.so. Returns the path.
     `defines` / `out` build an experiment variant next to the product library (A/B runs
@@ -68,14 +103,22 @@ def build(force=False, verbose=False, defines=(), out=None):
     for src in SOURCES:
         obj = os.path.join(bdir, src.replace(".hip", ".o"))
         objs.append(obj)
-        cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        extra = ["-Rpass-analysis=kernel-resource-usage"] if src in ASM_SOURCES else []
+        cmd = [hipcc] + FLAGS + extra + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    resources = {}
     for src, pr in procs:
         out, _ = pr.communicate()
         if pr.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{out.decode(errors='replace')}")
+        if src in ASM_SOURCES:
+            resources.update(_asm_kernel_resources(out.decode(errors="replace")))
+    _check_asm_kernels(resources)
+    import json
+    with open(RESOURCES, "w") as f:
+        json.dump(resources, f, indent=1, sort_keys=True)
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     if out.returncode != 0:

@@ -328,7 +328,7 @@ struct KArgs {
     void* ds_ws;                   // [B, Hq, ds_nqb, ds_nkb][2 KiB]: one 32-query x 32-key dS tile each
     int ds_nqb, ds_nkb;            // ceil(seqlen_q / 32), ceil(seqlen_k / 32)
     // backward, asm dK/dV kernel (fa_bwd_asm.hip): row statistics written by the preprocess kernel, or NULL
-    float* stats_ws;               // [2][B][Hq][Sq]: plane 0 = LSE log2(e) (+inf where LSE = -inf), plane 1 = D
+    float* stats_ws;               // [2][B][Hq][Sq]: plane 0 = LSE log2(e) (+inf where LSE = -inf), plane 1 = -D
 };
 
 // ---- ALiBi through the matrix pipe (causal-like masks: every visible key is at or left of the diagonal) ----

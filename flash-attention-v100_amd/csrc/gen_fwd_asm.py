@@ -634,7 +634,18 @@ class Gen:
     def gen_body(self, cfg):
         L = []
         A = L.append
+        timers = cfg.get("timers", 0)      # measurement build: s_memtime stamps land in the LSE rows r0 .. r0+4 of the wave
+
+        def stamp(i):
+            if timers:
+                A(f"s_memtime {sr(S_TMP + 2, 2)}")
+                A("s_waitcnt lgkmcnt(0)")
+                A(f"v_mov_b32 v{246 + i}, s{S_TMP + 2}")
         A("s_nop 7")
+        stamp(0)
+        if timers:
+            A(f"v_mov_b32 v250, 0")        # generic iterations
+            A(f"v_mov_b32 v251, 0")        # fast-loop iterations
         # ---- routine addresses
         A(f"s_getpc_b64 {sr(S_SUB, 2)}")
         A("L_pc_%=:")
@@ -674,9 +685,12 @@ class Gen:
             A(f"v_add_u32 v{V_KADDR + i}, s{S_R1}, v{V_KBASE + i}")
         A(f"v_add_u32 v{V_VADDR}, s{S_R0}, v{V_VBASE}")
         A("s_waitcnt vmcnt(8)")                          # Q and K(n_min) have landed
+        stamp(1)
 
         # ---- iteration loop + dispatch
         A("L_top_%=:")
+        if timers:
+            A("v_add_u32 v250, 1, v250")
         if "bar" not in self.ko:
             A("s_barrier")
         L += self.skew(cfg)
@@ -744,6 +758,8 @@ class Gen:
                     A("s_barrier")
                 L += self.skew(cfg)
                 A(f"L_fast{c}_body_%=:")
+                if timers:
+                    A("v_add_u32 v251, 1, v251")
                 self.out = []
                 self.stats = {"nop_states": 0, "lgkm_waits": 0}
                 self.gen_iteration(1, 1, 1, cfg, fast=sl)
@@ -778,6 +794,7 @@ class Gen:
         EP_PITCH, EP_QB = 272, 32 * 272
         A("L_done_%=:")
         A("s_waitcnt vmcnt(0) lgkmcnt(0)")
+        stamp(2)
         A("s_barrier")                                   # every wave is done with the K / V ring
         T = V_T
         t = S_TMP
@@ -841,6 +858,13 @@ class Gen:
                 A(f"s_add_u32 s{t + 3}, s{t + 3}, s{t + 1}")
             A("s_nop 1")
         A("s_waitcnt vmcnt(0)")
+        if timers:
+            stamp(3)
+            A("s_mov_b64 exec, 1")
+            for i in range(6):
+                A(f"buffer_store_dword v{246 + i}, v{V_LSEOFF[0]}, {sr(S_LRS, 4)}, 0 offen offset:{4 * i}")
+            A("s_mov_b64 exec, -1")
+            A("s_waitcnt vmcnt(0)")
         return L, report
 
 
