@@ -19,11 +19,11 @@ typedef short s8v __attribute__((ext_vector_type(8)));
         : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(c4), "+v"(c5), "+v"(c6), "+v"(c7)                             \
         : "v"(a), "v"(b), "v"(x0), "v"(x1), "v"(x2), "v"(p0), "v"(p1), "v"(ld), "v"(addr) : "s20", "s21", "s22", "s23", "memory");
 template <int PAT>
-__global__ void __launch_bounds__(512) k(unsigned long long* out, float* sink, int iters) {
+__global__ void __launch_bounds__(512) k(unsigned long long* out, float* sink, int iters, int rnd = 0) {
   __shared__ float lds[4096];
   f16v c0 = {}, c1 = {}, c2 = {}, c3 = {}, c4 = {}, c5 = {}, c6 = {}, c7 = {};
   s8v a = {1, 2, 3, 4, 5, 6, 7, 8}, b = {1, 1, 1, 1, 1, 1, 1, 1};
-  if (iters > 10000) {   // chip-wide runs: pseudo-random bf16 operands in (-2, 2) (data toggling sets the MFMA power draw)
+  if (rnd) {   // pseudo-random bf16 operands in (-2, 2) (data toggling sets the MFMA power draw)
     unsigned h = (threadIdx.x + 977u * blockIdx.x) * 2654435761u;
     for (int i = 0; i < 8; ++i) {
       h = h * 1664525u + 1013904223u; a[i] = (short)(((h >> 16) & 0x807f) | 0x3f80);
@@ -83,15 +83,15 @@ template <int P> void run(const char* name, int per_iter) {
            (double)h / (iters * 20 * 8.0 * per_iter), per_iter, (double)h / (ms * 1e3), ms * 1e6 / (iters * 20 * 8.0 * per_iter));
   }
 }
-template <int P> void run_full(const char* name, int per_iter) {
+template <int P> void run_full(const char* name, int per_iter, int rnd) {
   // every CU busy: does the shader clock hold under chip-wide MFMA load?  (ticks/us = effective clock in MHz)
   unsigned long long* d; float* s;
   (void)hipMalloc(&d, 8 * 8192); (void)hipMalloc(&s, 4096);
   const int iters = 20000;
-  hipLaunchKernelGGL(k<P>, dim3(1024), dim3(256), 0, 0, d, s, iters);
+  hipLaunchKernelGGL(k<P>, dim3(1024), dim3(256), 0, 0, d, s, iters, rnd);
   hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
   (void)hipEventRecord(e0, 0);
-  hipLaunchKernelGGL(k<P>, dim3(1024), dim3(256), 0, 0, d, s, iters);
+  hipLaunchKernelGGL(k<P>, dim3(1024), dim3(256), 0, 0, d, s, iters, rnd);
   (void)hipEventRecord(e1, 0);
   (void)hipEventSynchronize(e1);
   float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
@@ -100,14 +100,16 @@ template <int P> void run_full(const char* name, int per_iter) {
   double avg = 0; for (int i = 0; i < 1024; ++i) avg += (double)h[i]; avg /= 1024;
   // 1024 blocks over 256 CUs, one block per CU at a time (launch bounds 512 threads... the register use lets several
   // blocks share a CU: the per-block tick count and the wall time give the clock only together with the residency)
-  printf("%-30s chip-wide: %.2f ticks per unit per block, kernel %.3f ms, sum of block ticks / wall = %.0f MHz x blocks-in-flight/CU\n",
-         name, avg / (iters * 8.0 * per_iter), ms, avg * 1024 / 256 / (ms * 1e3));
+  printf("%-30s %s operands, chip-wide: %.2f ticks per unit per block, kernel %.3f ms, sum of block ticks / wall = %.0f MHz x blocks-in-flight/CU\n",
+         name, rnd ? "random bf16" : "constant", avg / (iters * 8.0 * per_iter), ms, avg * 1024 / 256 / (ms * 1e3));
   double flops = 1024.0 * 4 * iters * 8.0 * per_iter * 32768.0;
-  if (P == 0) printf("   MFMA rate: %.0f TFLOP/s dense bf16\n", flops / (ms * 1e-3) / 1e12);
+  printf("   MFMA rate: %.0f TFLOP/s dense bf16\n", flops / (ms * 1e-3) / 1e12);
 }
 int main() {
-  run_full<0>("mfma only", 8);
-  run_full<6>("mfma + 3 fma", 4);
+  run_full<0>("mfma only", 8, 0);
+  run_full<0>("mfma only", 8, 1);
+  run_full<6>("mfma + 3 fma", 4, 0);
+  run_full<6>("mfma + 3 fma", 4, 1);
   run<0>("mfma only (unit = mfma)", 8);
   run<1>("v_fma_f32 (unit = instr)", 24);
   run<2>("v_pk_fma_f32 (unit = instr)", 24);
