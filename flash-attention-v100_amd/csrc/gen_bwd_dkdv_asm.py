@@ -50,6 +50,8 @@ S_QHEAD, S_DOHEAD = 51, 52      # bytes between q heads in q / dO
 S_STHEAD = 53                   # bytes between heads in the statistics planes (seqlen_q * 4)
 S_W1024 = 54                    # wave * 1024
 S_TL, S_NFULL = 55, 56          # mask predicate in 32-row tiles: a stage is unmasked iff (tile - TL) <u NFULL
+S_FLO, S_FEND = 57, 58          # iterations [FLO, FEND) may run the fast copies: stage real and unmasked, DMA stage real,
+                                # no head wrap (FLO >= FEND: never; the host sets that for GQA groups)
 # (the q / dO / statistics descriptors start at the FIRST q-head of the kv-head's group)
 # owned
 S_IT = 60
@@ -168,14 +170,15 @@ class DKV(Gen):
                     out.append(Ins(f"{self.cvt} v{V_DS[par] + e}, v{DP + q - 1}, v{DP + q}", "valu", [f"v{DP + q - 1}", f"v{DP + q}"], [f"v{V_DS[par] + e}"]))
         return out
 
-    def dma_stream(self, slot, c):
+    def dma_stream(self, slot, c, fast=False):
         """stage it+3 -> ring slot: 2 Q pieces + 2 dO pieces per wave (source offsets in s[S_T+3], s[S_T+4]; the second
         piece of a tile lies 16 rows further: its own lane offsets), then the 256-byte statistics piece by ONE wave
         (copy c: wave c % 4; offset s[S_T+5]).  -> list of (m0 write, DMA) pairs + the statistics block"""
         g = []
         base = slot * STG
         t = S_T
-        for (rs, so, vos, toff) in ((S_QRS, t + 3, (V_DMAQ, V_DMAQ2), 0), (S_DORS, t + 4, (V_DMADO, V_DMADO2), 8192)):
+        sq, sdo, sst = (S_DQS, S_DDOS, S_DSTS) if fast else (t + 3, t + 4, t + 5)
+        for (rs, so, vos, toff) in ((S_QRS, sq, (V_DMAQ, V_DMAQ2), 0), (S_DORS, sdo, (V_DMADO, V_DMADO2), 8192)):
             for jj in range(2):
                 vo = vos[jj]
                 g.append((Ins(f"s_add_u32 m0, s{S_W1024}, {base + toff + 4096 * jj}", "salu", [], ["m0", "scc"]),
@@ -183,7 +186,7 @@ class DKV(Gen):
         u = self.uid()
         st = [Ins(f"s_mov_b32 m0, {STATS + slot * 256}", "raw"), Ins(f"s_cmp_eq_u32 s{S_W1024}, {1024 * (c % 4)}", "raw"),
               Ins(f"s_cbranch_scc0 L_ns{u}_%=", "raw"),
-              Ins(f"buffer_load_dword v{V_DMAST}, {sr(S_STRS, 4)}, s{t + 5} offen lds", "raw"), Ins(f"L_ns{u}_%=:", "raw")]
+              Ins(f"buffer_load_dword v{V_DMAST}, {sr(S_STRS, 4)}, s{sst} offen lds", "raw"), Ins(f"L_ns{u}_%=:", "raw")]
         return g, st
 
     def slots(self, c):
@@ -216,11 +219,20 @@ class DKV(Gen):
                 self.stats["lgkm_waits"] += 1
             self.lds_q = self.lds_q[idx + 1:]
 
-    def gen_iteration(self, c, cfg, carry):
-        """`carry`: the LDS queue the previous copy leaves behind (its lse2 reads and our first `pre` reads)"""
+    def gen_iteration(self, c, cfg, carry, fast=False):
+        """`carry`: the LDS queue the previous copy leaves behind (its lse2 reads and our first `pre` reads).
+        fast: the host guarantees a real, mask-free stage, a real DMA stage and no head wrap - no predicate, no selects"""
         self.reset_dkv()
         self.lds_q = [set(x) for x in carry]
         sl_prev, sl_next, sl_dma, par_cur, par_oth = self.slots(c)
+        A = self.raw
+        t = S_T
+        if not fast:
+            self.gen_head(par_cur)
+        self.gen_streams(c, cfg, fast)
+        return [set(x) for x in self.lds_q]
+
+    def gen_head(self, par_cur):
         A = self.raw
         t = S_T
         # ---- SALU head: is stage `it` masked at all?  virtual stages (it = -1, it >= n_iter: one unsigned compare)
@@ -239,12 +251,15 @@ class DKV(Gen):
         A(f"s_cselect_b32 s{t + 3}, s{S_DQS}, s{S_OOB}")
         A(f"s_cselect_b32 s{t + 4}, s{S_DDOS}, s{S_OOB}")
         A(f"s_cselect_b32 s{t + 5}, s{S_DSTS}, s{S_OOB}")
+
+    def gen_streams(self, c, cfg, fast):
+        sl_prev, sl_next, sl_dma, par_cur, par_oth = self.slots(c)
         # ---- streams
         sdp = self.sdp_stream(sl_next, par_oth)
         dvdk = self.dvdk_stream(sl_prev, par_oth)
         d_reads, l_reads = self.stats_reads(sl_next, par_oth)
         valu = self.valu_stream(par_cur)
-        dma, dma_st = self.dma_stream(sl_dma, c)
+        dma, dma_st = self.dma_stream(sl_dma, c, fast)
         # ---- interleave: 32 MFMAs = dV/dK of stage it-1 first (their operands are oldest), then S/dP of stage it+1
         mf_items = [("t", x) for x in dvdk] + [("r", x) for x in sdp]
         nv, vi = len(valu), 0
@@ -292,7 +307,6 @@ class DKV(Gen):
             vi += 1
         for r in self.pre_reads((c + 1) % NRING, pre):
             self.emit(r)
-        return [set(x) for x in self.lds_q]
 
     def _emit_any(self, ins):
         if ins.kind == "raw":
@@ -481,17 +495,24 @@ class DKV(Gen):
             self.out, self.stats = [], {"nop_states": 0, "lgkm_waits": 0}
             carries[c] = self.gen_iteration(c, cfg, [])
         report = {}
+        use_fast = cfg.get("fast", True)
         for c in range(NRING):
             A(f"L_it{c}_%=:")
             if "bar" not in self.ko:
                 A("s_barrier")
+            if use_fast:                                            # FLO <= it < FEND: the mask-free copy of this slot phase
+                A(f"s_cmp_ge_i32 s{S_IT}, s{S_FLO}")
+                A(f"s_cbranch_scc0 L_gen{c}_%=")
+                A(f"s_cmp_lt_i32 s{S_IT}, s{S_FEND}")
+                A(f"s_cbranch_scc1 L_fb{c}_%=")
+                A(f"L_gen{c}_%=:")
             self.out, self.stats = [], {"nop_states": 0, "lgkm_waits": 0}
             left = self.gen_iteration(c, cfg, carries[(c - 1) % NRING])
             assert left == carries[c], "the carried LDS queue must not depend on its seed"
             report[c] = (dict(self.stats), len(self.out))
             L += self.out
             # ---- tail: advance both streams; the pieces of the PREVIOUS iteration must have landed before the next
-            # barrier (this iteration's stay in flight: 4 per wave, 5 on wave 0 which also fetches the statistics)
+            # barrier (this iteration's stay in flight: 4 per wave, 5 on the wave that also fetched the statistics)
             u = self.uid()
             for x in self.salu_advance():
                 A(x.replace("{u}", str(u)))
@@ -503,6 +524,31 @@ class DKV(Gen):
                 A("s_cbranch_scc0 L_done_%=")
             else:
                 A("s_cbranch_scc1 L_it0_%=")
+                A("s_branch L_done_%=")
+        if use_fast:
+            # ---- fast copies: same slot phases; entered from a generic copy's head (after its barrier), left into the
+            # next generic copy (which re-derives everything from `it`: VMT and DIT are restored on the way out)
+            for c in range(NRING):
+                A(f"L_f{c}_%=:")
+                if "bar" not in self.ko:
+                    A("s_barrier")
+                A(f"L_fb{c}_%=:")
+                self.out, self.stats = [], {"nop_states": 0, "lgkm_waits": 0}
+                left = self.gen_iteration(c, cfg, carries[(c - 1) % NRING], fast=True)
+                assert left == carries[c]
+                report[("fast", c)] = (dict(self.stats), len(self.out))
+                L += self.out
+                A(f"s_add_u32 s{S_DQS}, s{S_DQS}, s{S_QROW32}")
+                A(f"s_add_u32 s{S_DDOS}, s{S_DDOS}, s{S_DOROW32}")
+                A(f"s_add_u32 s{S_DSTS}, s{S_DSTS}, 128")
+                if "vmwait" not in self.ko:
+                    A("s_waitcnt vmcnt(4)")
+                A(f"s_add_u32 s{S_IT}, s{S_IT}, 1")
+                A(f"s_cmp_lt_i32 s{S_IT}, s{S_FEND}")
+                A(f"s_cbranch_scc1 L_f{(c + 1) % NRING}_%=")
+                A(f"s_add_u32 s{S_VMT}, s{S_MT0}, s{S_IT}")           # (no wrap inside the fast range: tile = mt0 + it)
+                A(f"s_add_u32 s{S_DIT}, s{S_IT}, 3")
+                A(f"s_branch L_it{(c + 1) % NRING}_%=")
         A("L_done_%=:")
         A("s_waitcnt vmcnt(0) lgkmcnt(0)")
         stamp(2)

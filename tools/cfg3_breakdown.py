@@ -3,7 +3,7 @@ import os, sys
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, os.path.join(ROOT, "flash-attention-v100_amd")); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import torch, flash_attn
-from flash_attn_mi355 import _lib
+from flash_attn_mi355 import _lib, flash_attn_interface as _fi
 from bench_configs import timeit
 g = torch.Generator().manual_seed(421)
 B, H, D, W = 64, 32, 64, 512

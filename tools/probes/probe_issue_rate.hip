@@ -65,6 +65,36 @@ __global__ void __launch_bounds__(512) k(unsigned long long* out, float* sink, i
   if (threadIdx.x == 0) out[blockIdx.x] = t1 - t0;
   sink[threadIdx.x] = c0[0] + c1[0] + c2[0] + c3[0] + c4[0] + c5[0] + c6[0] + c7[0] + x0 + x1 + x2 + (float)p0 + (float)p1 + ld[0];
 }
+// MFMA operand files: C/D in VGPRs or AGPRs, A / B from VGPRs or AGPRs (8 independent accumulators, one wave per SIMD)
+template <int MODE>
+__global__ void __launch_bounds__(256) kop(unsigned long long* out, float* sink, int iters) {
+  f16v c0 = {}, c1 = {}, c2 = {}, c3 = {}, c4 = {}, c5 = {}, c6 = {}, c7 = {};
+  s8v a = {1, 2, 3, 4, 5, 6, 7, 8}, b = {1, 1, 1, 1, 1, 1, 1, 1};
+  unsigned long long t0 = __builtin_readcyclecounter();
+  for (int i = 0; i < iters; ++i) {
+#define MFS(A_, B_, C_) asm volatile(REP8(MF(0) MF(1) MF(2) MF(3) MF(4) MF(5) MF(6) MF(7)) \
+        : "+" C_(c0), "+" C_(c1), "+" C_(c2), "+" C_(c3), "+" C_(c4), "+" C_(c5), "+" C_(c6), "+" C_(c7) : A_(a), B_(b));
+    if (MODE == 0) { MFS("v", "v", "v") }
+    if (MODE == 1) { MFS("a", "v", "v") }
+    if (MODE == 2) { MFS("a", "a", "v") }
+    if (MODE == 3) { MFS("v", "v", "a") }
+    if (MODE == 4) { MFS("a", "v", "a") }
+    if (MODE == 5) { MFS("a", "a", "a") }
+  }
+  unsigned long long t1 = __builtin_readcyclecounter();
+  if (threadIdx.x == 0) out[blockIdx.x] = t1 - t0;
+  sink[threadIdx.x] = c0[0] + c1[0] + c2[0] + c3[0] + c4[0] + c5[0] + c6[0] + c7[0];
+}
+template <int MODE> void run_op(const char* name) {
+  unsigned long long* d; float* s;
+  (void)hipMalloc(&d, 8 * 1024); (void)hipMalloc(&s, 4096);
+  const int iters = 2000;
+  hipLaunchKernelGGL(kop<MODE>, dim3(1), dim3(256), 0, 0, d, s, iters);
+  hipLaunchKernelGGL(kop<MODE>, dim3(1), dim3(256), 0, 0, d, s, iters);
+  unsigned long long h;
+  (void)hipMemcpy(&h, d, 8, hipMemcpyDeviceToHost);
+  printf("mfma operands %-28s: %6.2f ticks per mfma\n", name, (double)h / (iters * 64.0));
+}
 template <int P> void run(const char* name, int per_iter) {
   unsigned long long* d; float* s;
   (void)hipMalloc(&d, 8 * 1024); (void)hipMalloc(&s, 4096);
@@ -106,6 +136,8 @@ template <int P> void run_full(const char* name, int per_iter, int rnd) {
   printf("   MFMA rate: %.0f TFLOP/s dense bf16\n", flops / (ms * 1e-3) / 1e12);
 }
 int main() {
+  run_op<0>("A v, B v, C/D v"); run_op<1>("A a, B v, C/D v"); run_op<2>("A a, B a, C/D v");
+  run_op<3>("A v, B v, C/D a"); run_op<4>("A a, B v, C/D a"); run_op<5>("A a, B a, C/D a");
   run_full<0>("mfma only", 8, 0);
   run_full<0>("mfma only", 8, 1);
   run_full<6>("mfma + 3 fma", 4, 0);
