@@ -1297,8 +1297,38 @@ __global__ void __launch_bounds__(BWD_THREADS, OCC) fa_bwd_dq_kernel(const KArgs
             qf[ks] = okc ? *reinterpret_cast<const u32x4*>(qrow + 16 * ks) : z;
             dof[ks] = okc ? *reinterpret_cast<const u32x4*>(dorow + 16 * ks) : z;
         }
-        if (ok) {
-            const int64_t so = (int64_t)w.b * p.lse_batch_stride + (int64_t)w.h * p.lse_head_stride + sg.q_row0 + my_row;
+        const int64_t so = (int64_t)w.b * p.lse_batch_stride + (int64_t)w.h * p.lse_head_stride + sg.q_row0 + my_row;
+        if (a.fuse_pre) {
+            // D = rowsum(dO o O) here instead of in a preprocess launch (dense asm path: this kernel runs FIRST and
+            // leaves softmax_d and the dK/dV kernel's statistics behind): the lane holds half of its row's dO already
+            const int64_t ob_off = (int64_t)w.b * p.o_batch_stride;
+            const uint16_t* orow = reinterpret_cast<const uint16_t*>(p.o) + ob_off + (sg.q_row0 + my_row) * p.o_row_stride +
+                                   (int64_t)w.h * p.o_head_stride + 8 * g;
+            float acc = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KSTEPS; ++ks) {
+                u32x4 ov = {0, 0, 0, 0};
+                if (ok && 16 * ks + 8 * g < dv) ov = *reinterpret_cast<const u32x4*>(orow + 16 * ks);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc = fmaf(E::lo(ov[j]), E::lo(dof[ks][j]), acc);
+                    acc = fmaf(E::hi(ov[j]), E::hi(dof[ks][j]), acc);
+                }
+            }
+            acc += __shfl_xor(acc, 32, 64);
+            dsum = acc;
+            if (ok) {
+                const float lse = p.lse[so];
+                lse2 = lse * kLog2e;
+                if (g == 0) {
+                    p.softmax_d[so] = acc;
+                    const int64_t plane = (int64_t)p.batch * p.nheads_q * p.seqlen_q;
+                    const int64_t at = ((int64_t)w.b * p.nheads_q + w.h) * p.seqlen_q + my_row;
+                    a.stats_ws[at] = lse == -INFINITY ? INFINITY : lse2;
+                    a.stats_ws[plane + at] = -acc;
+                }
+            }
+        } else if (ok) {
             lse2 = p.lse[so] * kLog2e;
             dsum = p.softmax_d[so];
         }
@@ -1709,8 +1739,11 @@ template <typename T, int D>
 static int launch_bwd_td(const KArgs& a, hipStream_t stream) {
     const fa_params& p = a.p;
     const int g_bwd_phase_mask = p.bwd_phases ? p.bwd_phases : 7;      // per call (fa_params::bwd_phases)
+    // asm path (dense, D = 128, statistics workspace): no preprocess launch - the dQ kernel computes D in its prologue,
+    // runs first and leaves softmax_d + the statistics for the dK/dV kernel (saves one pass over dO and a launch)
+    const bool fused_pre = a.fuse_pre != 0;
     // 1. preprocess
-    if (g_bwd_phase_mask & 1) {
+    if ((g_bwd_phase_mask & 1) && !fused_pre) {
         const int cpr = D / 8, rows_per_block = 256 / cpr;
         const int64_t total_rows = p.cu_seqlens_q ? (int64_t)p.total_q : (int64_t)p.batch * p.seqlen_q;
         if (total_rows > 0) {
@@ -1718,10 +1751,11 @@ static int launch_bwd_td(const KArgs& a, hipStream_t stream) {
             hipLaunchKernelGGL(bwd_preprocess_kernel<T>, grid, dim3(256), 0, stream, a);
         }
     }
-    // 2. dK/dV
     const bool drop = p.p_dropout > 0.f;
     // causal ALiBi without softcap: the bias rides on one extra MFMA per sub-tile (BIAS = 2)
     const bool lin_alibi = p.alibi_slopes && p.softcap <= 0.f && (p.is_causal || p.window_right == 0);
+    // 2. dK/dV
+    auto launch_dkdv = [&]() {
     if (g_bwd_phase_mask & 2) {
         const int n_kblocks = (p.seqlen_k + DKV_BN - 1) / DKV_BN;
         const int n_kb_grid = (a.pair_qblocks && n_kblocks >= 2) ? (n_kblocks + 1) / 2 : n_kblocks;
@@ -1777,7 +1811,9 @@ static int launch_bwd_td(const KArgs& a, hipStream_t stream) {
         }
 #undef FA_LAUNCH_DKV
     }
+    };
     // 3. dQ
+    auto launch_dq = [&]() {
     if ((g_bwd_phase_mask & 4) && a.ds_ws) {
         if constexpr (D <= 128) {
             const int grid = work_grid(p.batch, p.nheads_q, p.nheads_k, a.n_qblocks);
@@ -1809,6 +1845,8 @@ static int launch_bwd_td(const KArgs& a, hipStream_t stream) {
         }
 #undef FA_LAUNCH_DQ
     }
+    };
+    if (fused_pre) { launch_dq(); launch_dkdv(); } else { launch_dkdv(); launch_dq(); }
     return 0;
 }
 
@@ -1816,6 +1854,7 @@ int launch_bwd(const KArgs& a_in, hipStream_t stream) {
     KArgs a = a_in;
     a.ds_ws = nullptr;
     a.stats_ws = nullptr;
+    a.fuse_pre = 0;
     const size_t need = bwd_ds_workspace_bytes(a.p);
     if (need > 0 && a.p.workspace && a.p.workspace_bytes >= need) {
         a.ds_ws = a.p.workspace;
@@ -1823,6 +1862,9 @@ int launch_bwd(const KArgs& a_in, hipStream_t stream) {
         a.ds_nkb = (a.p.seqlen_k + 31) / 32;
     } else if (bwd_asm_applicable(a) && a.p.workspace && a.p.workspace_bytes >= bwd_asm_workspace_bytes(a.p)) {
         a.stats_ws = reinterpret_cast<float*>(a.p.workspace);     // (without a workspace the hipcc kernels run)
+#ifndef FA_NO_FUSE_PRE
+        a.fuse_pre = 1;
+#endif
     }
     const bool bf = a.p.dtype == FA_BF16;
     switch (a.p.head_dim) {

@@ -329,6 +329,7 @@ struct KArgs {
     int ds_nqb, ds_nkb;            // ceil(seqlen_q / 32), ceil(seqlen_k / 32)
     // backward, asm dK/dV kernel (fa_bwd_asm.hip): row statistics written by the preprocess kernel, or NULL
     float* stats_ws;               // [2][B][Hq][Sq]: plane 0 = LSE log2(e) (+inf where LSE = -inf), plane 1 = -D
+    int fuse_pre;                  // the dQ kernel computes D = rowsum(dO o O) itself, runs first and writes softmax_d + stats_ws
 };
 
 // ---- ALiBi through the matrix pipe (causal-like masks: every visible key is at or left of the diagonal) ----

@@ -81,6 +81,13 @@ def test_full_size_config2_backward_sampled_rows():
             dp = vf[:i + 1] @ dof[i]
             ds = p * (dp - dsum[i])
             ref = (ds[:, None] * kf[:i + 1]).sum(0) * scale
+            if i == 0:
+                # one visible key: P = 1 and dP = D in exact arithmetic, i.e. dQ = 0.  dP comes out of the matrix pipe
+                # and D out of an fp32 dot product, so what is left is their summation-order difference: bound it by
+                # fp32 rounding of the cancelled terms instead of a relative error against zero
+                bound = 2.0 ** -18 * (abs(dp[0]) + abs(dsum[0])) * np.abs(kf[0]).max() * scale + 1e-12
+                assert np.abs(f64(dq[b, 0, h])).max() <= bound, (np.abs(f64(dq[b, 0, h])).max(), bound)
+                continue
             assert_close(f64(dq[b, i, h]), ref, dt, f"dq[{b},{i},{h}]", mult=2.0)
         for j in (0, 63, 64, 127, 128, 2048, 4000, 4095):
             s = (qf[j:] @ kf[j]) * scale                                         # queries j .. S-1 see key j
