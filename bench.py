@@ -349,7 +349,9 @@ def main():
             ach = alg[name] / (dur[name] * 1e-3) / 1e12
             kernels[name] = {"ms": round(dur[name], 4), "algorithmic_tflop": round(alg[name] / 1e12, 5),
                              "achieved": round(ach, 1), "frac": round(ach / PEAK_BF16_TFLOPS, 4)}
-        kernels["bwd_preprocess"] = {"ms": round(kern["bwd_preprocess"], 4)}
+        kernels["bwd_preprocess"] = {"ms": round(kern["bwd_preprocess"], 4),
+                                     "note": "no separate launch on the asm path (FA_BWD_ASM != 0): D = rowsum(dO o O) is computed in "
+                                             "the dQ kernel's prologue; this figure is the host cost of an empty call"}
         kernels["bwd_all"] = {"ms": round(kern["bwd_all"], 4),
                               "achieved": round(2.5 * ff / (kern["bwd_all"] * 1e-3) / 1e12, 1)}
         dom = max(("fwd", "bwd_dkdv", "bwd_dq"), key=lambda n: dur[n])

@@ -44,9 +44,14 @@ NT = 28
 V_S = (80, 112)          # S^T accumulators of qb0 / qb1: 32 regs each (kb0: 16, kb1: 16)
 V_P = (144, 160)         # packed P^T: 16 regs each (4 k-steps x 4)
 V_VF = 176               # V^T fragments: [ks][dblk] x 4 regs = 64
-V_DMAK_CUR, V_DMAV_CUR = 240, 241   # fast loop: DMA source voffsets of the tiles being fetched (advance by one tile per iteration)
-V_L2 = (242, 243)        # second row-sum chain per q-block
-V_THR = (244, 245)       # rescale threshold in raw score units: (m_run + 8) / c
+V_DMAK_CUR, V_DMAV_CUR = 68, 69     # fast loop: DMA source voffsets of the tiles being fetched (advance by one tile per iteration)
+V_L2 = (70, 71)          # second row-sum chain per q-block
+V_THR = (73, 74)         # rescale threshold in raw score units: (m_run + 8) / c
+# causal ALiBi variant (bias = beta (key - q - off) in raw score units, beta = slope / softmax_scale):
+V_BK = (77, 78)          # in/out: the integer n0 + 4g - q - off of the lane's row for the NEXT tile of q-block 0 / 1
+                         # (kept exact: a float tile term accumulated over 60+ tiles drifts by 1e-3 in the LSE)
+V_BETA = 79              # in (uniform): beta
+V_C0 = 240               # 16 regs: beta * ((r & 3) + 8 (r >> 2)), the start value of every S^T accumulator chain
 # AGPR
 A_O = (0, 64)            # O^T accumulators per q-block: [dblk] x 16
 A_Q = (128, 160)         # Q fragments per q-block: [ks] x 4
@@ -105,8 +110,9 @@ class Ins:
 
 
 class Gen:
-    def __init__(self, dtype):
+    def __init__(self, dtype, alibi=False):
         self.dtype = dtype
+        self.alibi = alibi
         self.mf = "v_mfma_f32_32x32x16_bf16" if dtype == "bf16" else "v_mfma_f32_32x32x16_f16"
         self.cvt = "v_cvt_pk_bf16_f32" if dtype == "bf16" else "v_cvt_pk_f16_f32"
         self.out = []          # final text lines
@@ -243,8 +249,12 @@ class Gen:
         out = []
         for ks in range(8):
             for kb in range(2):
-                out.append(self.mfma("v", V_S[qb] + 16 * kb, "a", A_KF + (kb * 8 + ks) * 4,
-                                     "a", A_Q[qb] + 4 * ks, ks == 0))
+                m = self.mfma("v", V_S[qb] + 16 * kb, "a", A_KF + (kb * 8 + ks) * 4, "a", A_Q[qb] + 4 * ks, ks == 0)
+                if ks == 0 and self.alibi:      # the chain starts from beta * (key position inside the 32-key block)
+                    d, a, b = V_S[qb] + 16 * kb, A_KF + (kb * 8) * 4, A_Q[qb]
+                    m = Ins(f"{self.mf} {vr(d, 16)}, {ar(a, 4)}, {ar(b, 4)}, {vr(V_C0, 16)}", "mfma",
+                            rl("a", a, 4) + rl("a", b, 4) + rl("v", V_C0, 16), rl("v", d, 16))
+                out.append(m)
         return out
 
     def pv_mfmas(self, qb):
@@ -280,28 +290,46 @@ class Gen:
         out = []
         s = [f"v{S + i}" for i in range(32)]
         # ---- row maximum over the lane's 32 keys: max3 tree
-        vals = list(s)
-        tn = 0
-        while len(vals) > 1:
-            nxt = []
-            i = 0
-            while i + 2 < len(vals):
-                t = f"v{T + tn}"
-                tn += 1
-                out.append(self.valu(f"v_max3_f32 {t}, {vals[i]}, {vals[i + 1]}, {vals[i + 2]}",
-                                     [vals[i], vals[i + 1], vals[i + 2]], [t]))
-                nxt.append(t)
-                i += 3
-            rest = vals[i:]
-            if len(rest) == 2 and not nxt:
-                t = f"v{T + tn}"
-                tn += 1
-                out.append(self.valu(f"v_max_f32 {t}, {rest[0]}, {rest[1]}", rest, [t]))
-                nxt.append(t)
-                rest = []
-            vals = nxt + rest
-        mx = vals[0]
-        assert tn <= 20
+        def max_tree(vals, tn):
+            while len(vals) > 1:
+                nxt = []
+                i = 0
+                while i + 2 < len(vals):
+                    t = f"v{T + tn}"
+                    tn += 1
+                    out.append(self.valu(f"v_max3_f32 {t}, {vals[i]}, {vals[i + 1]}, {vals[i + 2]}",
+                                         [vals[i], vals[i + 1], vals[i + 2]], [t]))
+                    nxt.append(t)
+                    i += 3
+                rest = vals[i:]
+                if len(rest) == 2 and not nxt:
+                    t = f"v{T + tn}"
+                    tn += 1
+                    out.append(self.valu(f"v_max_f32 {t}, {rest[0]}, {rest[1]}", rest, [t]))
+                    nxt.append(t)
+                    rest = []
+                vals = nxt + rest
+            return vals[0], tn
+        negms = None
+        if not self.alibi:
+            mx, tn = max_tree(list(s), 0)
+            assert tn <= 16
+        else:
+            # the two 32-key blocks carry different tile terms: max per block, then + beta (n0 + 32 kb + 4g - q - off)
+            dist, beta = f"v{V_BK[qb]}", f"v{V_BETA}"
+            mx0, tn = max_tree(list(s[:16]), 0)
+            mx1, tn = max_tree(list(s[16:]), tn)
+            assert tn <= 16
+            t0, bk1, t1, mx, bk = f"v{T}", f"v{T + 1}", f"v{T + 2}", f"v{T + 3}", f"v{T + 6}"
+            out.append(self.valu(f"v_cvt_f32_i32 {bk}, {dist}", [dist], [bk]))
+            out.append(self.valu(f"v_add_u32 {bk1}, 32, {dist}", [dist], [bk1]))
+            out.append(self.valu(f"v_mul_f32 {bk}, {beta}, {bk}", [beta, bk], [bk]))
+            out.append(self.valu(f"v_cvt_f32_i32 {bk1}, {bk1}", [bk1], [bk1]))
+            out.append(self.valu(f"v_add_f32 {t0}, {mx0}, {bk}", [mx0, bk], [t0]))
+            out.append(self.valu(f"v_mul_f32 {bk1}, {beta}, {bk1}", [beta, bk1], [bk1]))
+            out.append(self.valu(f"v_add_f32 {t1}, {mx1}, {bk1}", [mx1, bk1], [t1]))
+            out.append(self.valu(f"v_max_f32 {mx}, {t0}, {t1}", [t0, t1], [mx]))
+            negms = (f"v{T + 4}", f"v{T + 5}", bk, bk1)
         ta, td, tl = f"v{T + 20}", f"v{T + 21}", f"v{T + 22}"
         out.append(self.valu(f"v_mov_b32 {ta}, {mx}", [mx], [ta]))
         out.append(Ins(f"v_permlane32_swap_b32 {ta}, {mx}", "swap", [ta, mx], [ta, mx]))
@@ -313,6 +341,12 @@ class Gen:
         out.append(call)
         # ---- exp2(s c - m), row sum (two chains), pack
         negm = f"v{V_NEGM[qb]}"
+        negm_of = [negm, negm]
+        if negms:                                      # exponent = c (S + tile term) - m: one offset per 32-key block
+            n0_, n1_, bk, bk1 = negms
+            out.append(self.valu(f"v_fma_f32 {n0_}, s{S_C}, {bk}, {negm}", [bk, negm], [n0_]))
+            out.append(self.valu(f"v_fma_f32 {n1_}, s{S_C}, {bk1}, {negm}", [bk1, negm], [n1_]))
+            negm_of = [n0_, n1_]
         l0, l1 = f"v{V_L[qb]}", f"v{V_L2[qb]}"
         # software pipeline over the 32 elements: fma(r), exp(r-1), add(r-3), pack(pair) - transcendentals never sit
         # back to back (v_exp_f32 re-issues after ~8.5 cycles, a plain VALU after ~5: probe_trans_rate)
@@ -323,7 +357,8 @@ class Gen:
             return self.valu(f"{self.cvt} {dst}, {s[r - 1]}, {s[r]}", [s[r - 1], s[r]], [dst])
         for r in range(32 + 3):
             if r < 32:
-                out.append(self.valu(f"v_fma_f32 {s[r]}, {s[r]}, s{S_C}, {negm}", [s[r], negm], [s[r]]))
+                nm = negm_of[r // 16]
+                out.append(self.valu(f"v_fma_f32 {s[r]}, {s[r]}, s{S_C}, {nm}", [s[r], nm], [s[r]]))
             if 0 <= r - 1 < 32:
                 out.append(self.valu(f"v_exp_f32 {s[r - 1]}, {s[r - 1]}", [s[r - 1]], [s[r - 1]], kind="trans", w=1.6))
             if 0 <= r - 3 < 32:
@@ -332,6 +367,9 @@ class Gen:
                 out.append(self.valu(f"v_add_f32 {ll}, {ll}, {s[q]}", [ll, s[q]], [ll]))
                 if q % 2 == 1:
                     out.append(pack(q))
+        if negms:                                      # next tile: 64 keys further
+            dist = f"v{V_BK[qb]}"
+            out.append(self.valu(f"v_add_u32 {dist}, 64, {dist}", [dist], [dist]))
         return out
 
     _uid = 0
@@ -684,6 +722,11 @@ class Gen:
         for i in range(8):
             A(f"v_add_u32 v{V_KADDR + i}, s{S_R1}, v{V_KBASE + i}")
         A(f"v_add_u32 v{V_VADDR}, s{S_R0}, v{V_VBASE}")
+        if self.alibi:
+            import struct
+            for r in range(16):
+                cr = float((r & 3) + 8 * (r >> 2))
+                A(f"v_mul_f32 v{V_C0 + r}, 0x{struct.unpack('<I', struct.pack('<f', cr))[0]:08x}, v{V_BETA}")
         A("s_waitcnt vmcnt(8)")                          # Q and K(n_min) have landed
         stamp(1)
 
@@ -798,25 +841,26 @@ class Gen:
         A("s_barrier")                                   # every wave is done with the K / V ring
         T = V_T
         t = S_TMP
-        lane, wbase, rbase, goff = T + 20, T + 21, T + 22, T + 23
+        E = V_P[0]                 # eight lane-derived values in the (dead) P registers: v77..v79 belong to the ALiBi variant
+        lane, wbase, rbase, goff = E, E + 1, E + 2, E + 3
         A(f"v_mbcnt_lo_u32_b32 v{lane}, -1, 0")
         A(f"v_mbcnt_hi_u32_b32 v{lane}, -1, v{lane}")
-        A(f"v_and_b32 v{T + 24}, 31, v{lane}")                     # q row of the accumulator columns
-        A(f"v_lshrrev_b32 v{T + 25}, 5, v{lane}")                  # g
-        A(f"v_lshrrev_b32 v{T + 26}, 4, v{lane}")                  # lane >> 4: row of the lane's 16-byte chunk
-        A(f"v_and_b32 v{T + 27}, 15, v{lane}")
-        A(f"v_lshlrev_b32 v{T + 27}, 4, v{T + 27}")                # its column byte
+        A(f"v_and_b32 v{E + 4}, 31, v{lane}")                      # q row of the accumulator columns
+        A(f"v_lshrrev_b32 v{E + 5}, 5, v{lane}")                   # g
+        A(f"v_lshrrev_b32 v{E + 6}, 4, v{lane}")                   # lane >> 4: row of the lane's 16-byte chunk
+        A(f"v_and_b32 v{E + 7}, 15, v{lane}")
+        A(f"v_lshlrev_b32 v{E + 7}, 4, v{E + 7}")                  # its column byte
         A(f"s_mul_i32 s{t}, s{S_W1024}, {2 * EP_QB // 1024}")      # wave * 17408
-        A(f"v_mul_u32_u24 v{wbase}, {EP_PITCH}, v{T + 24}")
-        A(f"v_lshl_add_u32 v{wbase}, v{T + 25}, 3, v{wbase}")
+        A(f"v_mul_u32_u24 v{wbase}, {EP_PITCH}, v{E + 4}")
+        A(f"v_lshl_add_u32 v{wbase}, v{E + 5}, 3, v{wbase}")
         A(f"v_add_u32 v{wbase}, s{t}, v{wbase}")                   # write base: row * pitch + 8 g
-        A(f"v_mul_u32_u24 v{rbase}, {EP_PITCH}, v{T + 26}")
-        A(f"v_add3_u32 v{rbase}, v{rbase}, v{T + 27}, s{t}")       # read base: row * pitch + column byte
+        A(f"v_mul_u32_u24 v{rbase}, {EP_PITCH}, v{E + 6}")
+        A(f"v_add3_u32 v{rbase}, v{rbase}, v{E + 7}, s{t}")        # read base: row * pitch + column byte
         A(f"v_readfirstlane_b32 s{t + 1}, v{V_ORB}")
         A(f"v_readfirstlane_b32 s{t + 2}, v{V_R0}")
         A("s_nop 4")
-        A(f"v_add_u32 v{T + 26}, s{t + 2}, v{T + 26}")             # global row
-        A(f"v_mad_u32_u24 v{goff}, v{T + 26}, s{t + 1}, v{T + 27}")   # byte offset of the lane's chunk
+        A(f"v_add_u32 v{E + 6}, s{t + 2}, v{E + 6}")               # global row
+        A(f"v_mad_u32_u24 v{goff}, v{E + 6}, s{t + 1}, v{E + 7}")  # byte offset of the lane's chunk
         A(f"s_lshl_b32 s{t + 1}, s{t + 1}, 2")                     # 4 rows further
         A("s_nop 7")
         for qb in range(2):
@@ -875,9 +919,9 @@ DEFAULT_CFG = {
 }
 
 
-def clobbers():
+def clobbers(alibi=False):
     c = ["memory", "vcc", "scc", "m0"]
-    c += [f"v{i}" for i in range(37, 256)]      # (v16..v36 are inputs)
+    c += [f"v{i}" for i in range(37, 256) if not (alibi and i in (V_BK[0], V_BK[1], V_BETA))]      # (v16..v36 are inputs)
     c += [f"a{i}" for i in range(256)]
     c += [f"s{i}" for i in range(S_R0, S_LAST + 1)]
     return c
@@ -896,18 +940,20 @@ def main():
         cfg["dma_gaps"] = {int(k): v for k, v in cfg["dma_gaps"].items()}
     print("// GENERATED by gen_fwd_asm.py - do not edit.  See that script for the schedule and the register map.")
     print("#pragma once")
-    for dt in ("bf16", "f16"):
-        g = Gen(dt)
-        g.ko = ko
-        body, report = g.gen_body(cfg)
-        print(f"#define FA_FWD_ASM_BODY_{dt.upper()} \\")
-        for ln in body:
-            print(f'    "{ln}\\n" \\')
-        print('    ""')
-        for k, (st, n) in report.items():
-            print(f"// {dt} variant a0a1a2={k}: {n} lines, nop states {st['nop_states']}, lgkmcnt waits {st['lgkm_waits']}")
-    cl = ", ".join(f'"{c}"' for c in clobbers())
-    print(f"#define FA_FWD_ASM_CLOBBERS {cl}")
+    for alibi in (False, True):
+        tag = "ALIBI_" if alibi else ""
+        for dt in ("bf16", "f16"):
+            g = Gen(dt, alibi=alibi)
+            g.ko = ko
+            body, report = g.gen_body(cfg)
+            print(f"#define FA_FWD_ASM_{tag}BODY_{dt.upper()} \\")
+            for ln in body:
+                print(f'    "{ln}\\n" \\')
+            print('    ""')
+            for k, (st, n) in report.items():
+                print(f"// {dt} {tag}variant a0a1a2={k}: {n} lines, nop states {st['nop_states']}, lgkmcnt waits {st['lgkm_waits']}")
+        cl = ", ".join(f'"{c}"' for c in clobbers(alibi))
+        print(f"#define FA_FWD_ASM_{tag}CLOBBERS {cl}")
 
 
 if __name__ == "__main__":

@@ -157,6 +157,49 @@ def test_asm_forward_vs_oracle(case):
     _asm_case(case)
 
 
+ASM_ALIBI_CASES = [
+    # B, Sq, Sk, H, Hk, window, dtype, slopes per batch, slope scale
+    (2, 1024, 1024, 4, 4, (-1, 0), "bf16", False, 1.0),
+    (1, 2048, 2048, 8, 2, (-1, 0), "fp16", True, 1.0),           # GQA, (batch, head) slopes
+    (1, 700, 1300, 2, 2, (-1, 0), "bf16", False, 1.0),           # Sq < Sk: the bias counts from the shifted diagonal
+    (1, 1300, 700, 2, 2, (-1, 0), "fp16", False, 1.0),           # rows without keys
+    (1, 1536, 1536, 2, 2, (300, 0), "bf16", False, 1.0),         # causal band
+    (1, 4096, 4096, 2, 2, (-1, 0), "bf16", False, 8.0),          # steep slopes: tile terms of -10^4 and more far from the diagonal
+]
+
+
+@pytest.mark.parametrize("case", ASM_ALIBI_CASES, ids=lambda c: "-".join(map(str, c)))
+def test_asm_forward_causal_alibi_vs_oracle(case):
+    """Causal ALiBi on the hand-scheduled forward (the bias rides on the accumulator start values + one tile term):
+    same tolerances as without bias, LSE included."""
+    B, Sq, Sk, H, Hk, window, dt, per_batch, mult = case
+    q = rand16((B, Sq, H, 128), dt, 431)
+    k = rand16((B, Sk, Hk, 128), dt, 432)
+    v = rand16((B, Sk, Hk, 128), dt, 433)
+    base = (2.0 ** (-8.0 * (np.arange(H) + 1) / H)) * mult
+    sl = np.stack([base * (1.0 + 0.25 * b) for b in range(B)]) if per_batch else base
+    slopes = torch.tensor(sl, dtype=torch.float32, device="cuda")
+    out, lse, _ = _fa().flash_attn_func(q, k, v, causal=True, window_size=window, alibi_slopes=slopes, return_attn_probs=True)
+    t = lambda x: f64(x).transpose(0, 2, 1, 3)
+    o_ref, lse_ref, _ = oracle.attn_fwd(t(q), t(k), t(v), 128 ** -0.5, causal=True, window=window, alibi_slopes=sl)
+    assert_close(t(out), o_ref, dt, "out", mult=1.5)
+    assert_lse_close(f64(lse), lse_ref, "lse", atol=1e-4)
+    # and the compiler-scheduled kernel agrees (it adds the same bias through an extra MFMA)
+    code = ("import os, sys, torch; sys.path.insert(0, os.path.join(os.getcwd(), 'flash-attention-v100_amd')); import flash_attn; "
+            "d = torch.load(sys.argv[1]); o, l, _ = flash_attn.flash_attn_func(d['q'], d['k'], d['v'], causal=True, "
+            "window_size=d['w'], alibi_slopes=d['s'], return_attn_probs=True); torch.save({'o': o, 'l': l}, sys.argv[2])")
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        torch.save({"q": q, "k": k, "v": v, "w": window, "s": slopes}, os.path.join(td, "in.pt"))
+        r = subprocess.run([sys.executable, "-c", code, os.path.join(td, "in.pt"), os.path.join(td, "out.pt")], cwd=ROOT,
+                           env=dict(os.environ, FA_FWD_ASM="0"), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        ref = torch.load(os.path.join(td, "out.pt"))
+    assert_close(f64(out), f64(ref["o"]), dt, "asm vs compiler kernel", mult=1.0)
+    fin = torch.isfinite(ref["l"])
+    assert torch.equal(torch.isfinite(lse), fin) and (lse[fin] - ref["l"][fin]).abs().max().item() <= 2e-4
+
+
 def test_warp_specialised_forward_vs_oracle():
     """fa_fwd_ws.hip is opt-in (FA_FWD_WS=1, read once per process): run the same cases in a subprocess."""
     code = ("import os, sys; sys.path.insert(0, os.path.join(os.getcwd(), 'tests')); "
