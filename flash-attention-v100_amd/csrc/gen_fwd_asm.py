@@ -71,6 +71,9 @@ S_OOB = 53
 S_KSOFF, S_VSOFF = 54, 55
 S_TMP = 56               # s56..s59 temps
 S_N0 = 60                # tile start key for the mask routine
+S_TOP = 61               # ALiBi variant: tiles run from the diagonal DOWN (the running maximum is found in the first
+                         # tiles instead of climbing by 64 slope per tile and rescaling O every time): physical tile =
+                         # S_TOP - loop index, S_TOP = n_max - 1 (the variant is only used with n_min = 0)
 S_SUB = 62               # s[62:63] call target, s[64:65] return address
 S_RET = 64
 S_MASKFN = (66, 68)      # s[66:67] mask0, s[68:69] mask1
@@ -113,6 +116,7 @@ class Gen:
     def __init__(self, dtype, alibi=False):
         self.dtype = dtype
         self.alibi = alibi
+        self.reverse = alibi
         self.mf = "v_mfma_f32_32x32x16_bf16" if dtype == "bf16" else "v_mfma_f32_32x32x16_f16"
         self.cvt = "v_cvt_pk_bf16_f32" if dtype == "bf16" else "v_cvt_pk_f16_f32"
         self.out = []          # final text lines
@@ -369,7 +373,7 @@ class Gen:
                     out.append(pack(q))
         if negms:                                      # next tile: 64 keys further
             dist = f"v{V_BK[qb]}"
-            out.append(self.valu(f"v_add_u32 {dist}, 64, {dist}", [dist], [dist]))
+            out.append(self.valu(f"v_subrev_u32 {dist}, 64, {dist}", [dist], [dist]))      # tiles run downwards
         return out
 
     _uid = 0
@@ -386,11 +390,17 @@ class Gen:
         t0 = S_TMP
         offs = []
         offs.append(Ins(f"s_add_u32 s{t0}, s{S_J}, 4", "salu", [f"s{S_J}"], [f"s{t0}", "scc"], w=0.5))
-        offs.append(Ins(f"s_mul_i32 s{S_KSOFF}, s{t0}, s{S_KTILE}", "salu", [f"s{t0}"], [f"s{S_KSOFF}"], w=0.5))
+        tk = t0
+        if self.reverse:
+            tk = t0 + 1
+            offs.append(Ins(f"s_sub_u32 s{tk}, s{S_TOP}, s{t0}", "salu", [f"s{t0}"], [f"s{tk}", "scc"], w=0.5))
+        offs.append(Ins(f"s_mul_i32 s{S_KSOFF}, s{tk}, s{S_KTILE}", "salu", [f"s{tk}"], [f"s{S_KSOFF}"], w=0.5))
         offs.append(Ins(f"s_cmp_lt_i32 s{t0}, s{S_NMAX}", "salu", [f"s{t0}"], ["scc"], w=0.5))
         offs.append(Ins(f"s_cselect_b32 s{S_KSOFF}, s{S_KSOFF}, s{S_OOB}", "salu", ["scc", f"s{S_KSOFF}"], [f"s{S_KSOFF}"], w=0.5))
         offs.append(Ins(f"s_add_u32 s{t0}, s{S_J}, 3", "salu", [f"s{S_J}"], [f"s{t0}", "scc"], w=0.5))
-        offs.append(Ins(f"s_mul_i32 s{S_VSOFF}, s{t0}, s{S_VTILE}", "salu", [f"s{t0}"], [f"s{S_VSOFF}"], w=0.5))
+        if self.reverse:
+            offs.append(Ins(f"s_sub_u32 s{tk}, s{S_TOP}, s{t0}", "salu", [f"s{t0}"], [f"s{tk}", "scc"], w=0.5))
+        offs.append(Ins(f"s_mul_i32 s{S_VSOFF}, s{tk}, s{S_VTILE}", "salu", [f"s{tk}"], [f"s{S_VSOFF}"], w=0.5))
         offs.append(Ins(f"s_cmp_lt_i32 s{t0}, s{S_NMAX}", "salu", [f"s{t0}"], ["scc"], w=0.5))
         offs.append(Ins(f"s_cselect_b32 s{S_VSOFF}, s{S_VSOFF}, s{S_OOB}", "salu", ["scc", f"s{S_VSOFF}"], [f"s{S_VSOFF}"], w=0.5))
         offs.append(Ins(f"s_add_u32 s{t0 + 1}, s{S_R0}, s{S_W1024}", "salu", [], [f"s{t0 + 1}", "scc"], w=0.5))
@@ -420,7 +430,8 @@ class Gen:
                  Ins(f"buffer_load_dwordx4 v{V_DMAK_CUR}, {sr(S_KRS, 4)}, {so} offen lds", "dma",
                      ["m0", f"v{V_DMAK_CUR}"], [], w=4.0)]
             if jj == 3:
-                p.append(Ins(f"v_add_u32 v{V_DMAK_CUR}, s{S_KTILE}, v{V_DMAK_CUR}", "valu", [f"v{V_DMAK_CUR}"], [f"v{V_DMAK_CUR}"]))
+                op = "v_subrev_u32" if self.reverse else "v_add_u32"
+                p.append(Ins(f"{op} v{V_DMAK_CUR}, s{S_KTILE}, v{V_DMAK_CUR}", "valu", [f"v{V_DMAK_CUR}"], [f"v{V_DMAK_CUR}"]))
             g.append((p, "dma"))
         for jj in range(4):
             so = "0" if jj == 0 else f"s{S_VJ + jj - 1}"
@@ -428,7 +439,8 @@ class Gen:
                  Ins(f"buffer_load_dwordx4 v{V_DMAV_CUR}, {sr(S_VRS, 4)}, {so} offen lds", "dma",
                      ["m0", f"v{V_DMAV_CUR}"], [], w=4.0)]
             if jj == 3:
-                p.append(Ins(f"v_add_u32 v{V_DMAV_CUR}, s{S_VTILE}, v{V_DMAV_CUR}", "valu", [f"v{V_DMAV_CUR}"], [f"v{V_DMAV_CUR}"]))
+                op = "v_subrev_u32" if self.reverse else "v_add_u32"
+                p.append(Ins(f"{op} v{V_DMAV_CUR}, s{S_VTILE}, v{V_DMAV_CUR}", "valu", [f"v{V_DMAV_CUR}"], [f"v{V_DMAV_CUR}"]))
             g.append((p, "dma"))
         return g
 
@@ -451,6 +463,7 @@ class Gen:
         u = self.uid()
         lines = [
             f"s_add_u32 s{t}, s{S_J}, 1",
+        ] + ([f"s_sub_u32 s{t}, s{S_TOP}, s{t}"] if self.reverse else []) + [
             f"s_lshl_b32 s{S_N0}, s{t}, 6",
             f"s_add_u32 s{t}, s{S_N0}, 63",
             f"s_cmp_gt_i32 s{t}, s{S_HIMIN[qb]}",
@@ -658,7 +671,11 @@ class Gen:
         o = []
         rs, tb, s16, vo, reg = ((S_KRS, S_KTILE, S_K16, V_DMAK, 0) if which == "k" else
                                 (S_VRS, S_VTILE, S_V16, V_DMAV, LDS_VREGION))
-        o.append(f"s_mul_i32 s{tmp}, s{tile_s}, s{tb}")
+        if self.reverse:
+            o.append(f"s_sub_u32 s{tmp}, s{S_TOP}, s{tile_s}")
+            o.append(f"s_mul_i32 s{tmp}, s{tmp}, s{tb}")
+        else:
+            o.append(f"s_mul_i32 s{tmp}, s{tile_s}, s{tb}")
         o.append(f"s_cmp_lt_i32 s{tile_s}, s{S_NMAX}")
         o.append(f"s_cselect_b32 s{tmp}, s{tmp}, s{S_OOB}")
         o.append(f"s_add_u32 s{tmp + 1}, s{slot_s}, s{S_W1024}")
@@ -691,6 +708,8 @@ class Gen:
             A(f"s_add_u32 s{reg}, s{S_SUB}, {lab}_%=-L_pc_%=")
             A(f"s_addc_u32 s{reg + 1}, s{S_SUB + 1}, 0")
         A(f"s_mov_b32 s{S_J}, s{S_JIN}")
+        if self.reverse:
+            A(f"s_sub_u32 s{S_TOP}, s{S_NMAX}, 1")
         A(f"s_mov_b32 s{S_OOB}, 0x80000000")
         A(f"s_mov_b32 s{S_R0}, 0")
         A(f"s_mov_b32 s{S_R1}, {LDS_STAGE}")
@@ -746,9 +765,13 @@ class Gen:
             A(f"s_cmp_lt_i32 s{S_J}, s{S_FASTEND}")
             A("s_cbranch_scc0 L_generic_%=")
             A(f"s_add_u32 s{t1}, s{S_J}, 4")
+            if self.reverse:
+                A(f"s_sub_u32 s{t1}, s{S_TOP}, s{t1}")
             A(f"s_mul_i32 s{t1}, s{t1}, s{S_KTILE}")
             A(f"v_add_u32 v{V_DMAK_CUR}, s{t1}, v{V_DMAK}")
             A(f"s_add_u32 s{t1}, s{S_J}, 3")
+            if self.reverse:
+                A(f"s_sub_u32 s{t1}, s{S_TOP}, s{t1}")
             A(f"s_mul_i32 s{t1}, s{t1}, s{S_VTILE}")
             A(f"v_add_u32 v{V_DMAV_CUR}, s{t1}, v{V_DMAV}")
             A(f"s_cmp_eq_u32 s{S_R0}, 0")
