@@ -20,6 +20,7 @@
 #include <cstdlib>
 #include <type_traits>
 #include "fa_common.h"
+#include "fa_rope.h"
 
 namespace fa {
 
@@ -168,6 +169,32 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : FA_FWD_OCC)) fa_fw
         for (int ks = 0; ks < KSTEPS; ++ks) {
             u32x4 z = {0, 0, 0, 0};
             qf[ks] = (ok && 16 * ks + 8 * g < dv) ? *reinterpret_cast<const u32x4*>(qrow + 16 * ks) : z;
+        }
+        if (a.rope_q && ok) {
+            // kv-cache call with rotary tables: rotate the row in registers (no rotated-Q copy, no extra launch).  The
+            // partner chunk of the non-interleaved form (d +- rotary_dim / 2) is one more 16-byte load per chunk.
+            const int L = p.cache_seqlens ? p.cache_seqlens[w.b] : 0;
+            const int lp = p.cache_leftpad ? p.cache_leftpad[w.b] : 0;
+            const int local = (p.is_causal || p.window_left >= 0 || p.window_right >= 0) ? 1 : 0;
+            const int pos = L + lp + (local ? my_row : 0);                       // include/rotary.h:177,201-202
+            if (pos >= 0 && pos < p.seqlen_ro) {
+                const int half = p.rotary_dim >> 1;
+                const uint16_t* cosp = reinterpret_cast<const uint16_t*>(p.rotary_cos) + (int64_t)pos * half;
+                const uint16_t* sinp = reinterpret_cast<const uint16_t*>(p.rotary_sin) + (int64_t)pos * half;
+                const uint16_t* qrow0 = qp + (int64_t)my_row * p.q_row_stride;
+#pragma unroll
+                for (int ks = 0; ks < KSTEPS; ++ks) {
+                    const int d_base = 16 * ks + 8 * g;
+                    if (d_base < p.rotary_dim && d_base < dv) {
+                        u32x4 xp = qf[ks];
+                        if (!p.rotary_interleaved) {
+                            const int pd = d_base < half ? d_base + half : d_base - half;
+                            xp = *reinterpret_cast<const u32x4*>(qrow0 + pd);
+                        }
+                        rope_chunk<T>(qf[ks], xp, cosp, sinp, d_base, p.rotary_dim, p.rotary_interleaved != 0);
+                    }
+                }
+            }
         }
     }
 

@@ -93,45 +93,9 @@ __global__ void __launch_bounds__(256) kv_append_kernel(const KArgs a) {
     }
 }
 
-// Rotate q [B, Tq, Hq, D] into a contiguous workspace of the same shape.
-template <typename T>
-__global__ void __launch_bounds__(256) q_rope_kernel(const KArgs a, uint16_t* out, int local) {
-    const fa_params& p = a.p;
-    const int cpr = valid_cols(p) / 8;
-    const int64_t total = (int64_t)p.batch * p.seqlen_q * p.nheads_q * cpr;
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= total) return;
-    const int cc = idx % cpr;
-    int64_t t = idx / cpr;
-    const int h = t % p.nheads_q; t /= p.nheads_q;
-    const int i = t % p.seqlen_q;
-    const int b = t / p.seqlen_q;
-    const int L = p.cache_seqlens ? p.cache_seqlens[b] : 0;
-    const int lp = p.cache_leftpad ? p.cache_leftpad[b] : 0;
-    const int pos = L + lp + (local ? i : 0);          // include/rotary.h:177,201-202
-    const int d_base = cc * 8;
-    const uint16_t* qr = reinterpret_cast<const uint16_t*>(p.q) + (int64_t)b * p.q_batch_stride +
-                         (int64_t)i * p.q_row_stride + (int64_t)h * p.q_head_stride;
-    u32x4 x = *reinterpret_cast<const u32x4*>(qr + d_base);
-    if (d_base < p.rotary_dim && pos >= 0 && pos < p.seqlen_ro) {
-        const int half = p.rotary_dim >> 1;
-        u32x4 xp = x;
-        if (!p.rotary_interleaved) {
-            const int pd = d_base < half ? d_base + half : d_base - half;
-            xp = *reinterpret_cast<const u32x4*>(qr + pd);
-        }
-        const uint16_t* cosp = reinterpret_cast<const uint16_t*>(p.rotary_cos) + (int64_t)pos * half;
-        const uint16_t* sinp = reinterpret_cast<const uint16_t*>(p.rotary_sin) + (int64_t)pos * half;
-        rope_chunk<T>(x, xp, cosp, sinp, d_base, p.rotary_dim, p.rotary_interleaved != 0);
-    }
-    *reinterpret_cast<u32x4*>(out + idx * 8) = x;
-}
-
 size_t decode_workspace_bytes(const fa_params& p) {
     if (decode_applicable(p)) return decode_split_workspace_bytes(p);
-    size_t bytes = 0;
-    if (p.rotary_dim > 0) bytes += (size_t)p.batch * p.seqlen_q * p.nheads_q * valid_cols(p) * 2;
-    return bytes;
+    return 0;                       // the general path rotates Q inside fa_fwd_kernel (KArgs::rope_q): no scratch
 }
 
 int launch_decode(const KArgs& a_in, hipStream_t stream) {
@@ -157,20 +121,7 @@ int launch_decode(const KArgs& a_in, hipStream_t stream) {
         if (need > 0 && (!p.workspace || p.workspace_bytes < need)) return -1;
         return launch_decode_splitkv(a, p.workspace, stream);
     }
-    if (p.rotary_dim > 0) {
-        const size_t need = decode_workspace_bytes(p);
-        if (!p.workspace || p.workspace_bytes < need) return -1;
-        uint16_t* qrot = reinterpret_cast<uint16_t*>(p.workspace);
-        const int local = (p.is_causal || p.window_left >= 0 || p.window_right >= 0) ? 1 : 0;
-        const int64_t total = (int64_t)p.batch * p.seqlen_q * p.nheads_q * (valid_cols(p) / 8);
-        const int grid = (int)((total + 255) / 256);
-        if (bf) hipLaunchKernelGGL(q_rope_kernel<bf16_tag>, dim3(grid), dim3(256), 0, stream, a, qrot, local);
-        else    hipLaunchKernelGGL(q_rope_kernel<fp16_tag>, dim3(grid), dim3(256), 0, stream, a, qrot, local);
-        p.q = qrot;
-        p.q_head_stride = valid_cols(p);
-        p.q_row_stride = (int64_t)p.nheads_q * valid_cols(p);
-        p.q_batch_stride = (int64_t)p.seqlen_q * p.q_row_stride;
-    }
+    a.rope_q = p.rotary_dim > 0 ? 1 : 0;
     return launch_fwd(a, stream);
 }
 

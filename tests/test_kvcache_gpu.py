@@ -30,6 +30,10 @@ KCASES = [
     (2, 3, 4, 4, 64, 256, 3, "bf16", False, (100, -1), 64, True, False, False, False),     # window -> local rope
     (2, 1, 4, 4, 128, 256, 0, "fp16", False, (-1, -1), 0, True, True, False, True),        # no append, alibi
     (2, 130, 4, 2, 128, 512, 130, "bf16", True, (-1, -1), 128, True, False, False, False), # long chunk
+    # general path (T_q x group > 32): Q is rotated inside the forward kernel - NeoX partner chunks come from memory
+    (2, 70, 4, 2, 128, 512, 70, "fp16", True, (-1, -1), 64, False, False, True, False),    # NeoX, partial, leftpad
+    (2, 90, 4, 4, 64, 400, 90, "bf16", True, (-1, -1), 16, False, True, False, False),     # half = 8: partner in the other half-wave
+    (1, 200, 2, 2, 128, 600, 200, "fp16", False, (-1, -1), 128, False, False, False, False),  # no mask: one position for all rows
 ]
 
 
