@@ -564,7 +564,39 @@ __global__ void __launch_bounds__(GEMV_THREADS) fa_decode_gemv_fp8_kernel(const 
             vo = (int64_t)cb * p.v_batch_stride + (int64_t)pos * p.v_row_stride;
         }
     };
+    // lane part of a load address: key group row + the lane's 16 columns (kbase / vbase carry the columns and the head)
+    const uint32_t lane_k = (uint32_t)grp * (uint32_t)p.k_row_stride, lane_v = (uint32_t)grp * (uint32_t)p.v_row_stride;
     auto load_step = [&](int step, u32x4 (&kx)[4], u32x4 (&vx)[4]) {
+        // Fast path (every full step that does not straddle a page): ONE block-table entry and ONE row offset per
+        // step, both wave-uniform (scalar unit), lane-constant vector offsets - the general per-lane form below costs
+        // ~40 quarter-rate integer multiplies per step (64-bit page offsets), more than the dot products themselves.
+        const int j0 = step * GEMV_KEYS, pos0 = lp + j0;
+        bool uni = j0 + GEMV_KEYS <= seqlen_k;
+        int64_t kb = 0, vb = 0;
+        if (PAGED) {
+            const int pg0 = da.page_shift >= 0 ? (pos0 >> da.page_shift) : pos0 / p.page_block_size;
+            const int pg1 = da.page_shift >= 0 ? ((pos0 + GEMV_KEYS - 1) >> da.page_shift) : (pos0 + GEMV_KEYS - 1) / p.page_block_size;
+            uni = uni && pg0 == pg1;
+            if (uni) {
+                const int64_t phys = btab[pg0];
+                const int pr0 = pos0 - pg0 * p.page_block_size;
+                kb = phys * p.k_batch_stride + (int64_t)pr0 * p.k_row_stride;
+                vb = phys * p.v_batch_stride + (int64_t)pr0 * p.v_row_stride;
+            }
+        } else {
+            kb = (int64_t)cb * p.k_batch_stride + (int64_t)pos0 * p.k_row_stride;
+            vb = (int64_t)cb * p.v_batch_stride + (int64_t)pos0 * p.v_row_stride;
+        }
+        if (uni) {
+            const uint8_t* kr = kbase + kb;
+            const uint8_t* vr = vbase + vb;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                kx[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(kr + (int64_t)(8 * i) * p.k_row_stride + lane_k));
+                vx[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(vr + (int64_t)(8 * i) * p.v_row_stride + lane_v));
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int j = step * GEMV_KEYS + 8 * i + grp;
@@ -663,11 +695,214 @@ __global__ void __launch_bounds__(GEMV_THREADS) fa_decode_gemv_fp8_kernel(const 
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same matrix-vector decode, TOKEN-major: a workgroup owns a key range of ONE batch entry for ALL heads; a wave
+// instruction covers one token x 8 heads = 1 KiB of contiguous cache (heads are adjacent in a cache row), wave w takes
+// heads 8w .. 8w+7 (+32 per round).  tools/probes/probe_kv_stream.hip: with one workgroup per head (above) the 128-byte
+// pieces at 4 KiB stride stream at 6.1 TB/s even without any arithmetic; token-major streams at 7.1-7.2 TB/s.  Every
+// 8-lane group owns a head (no merge inside the workgroup); the key range is always split (grid = batch x splits).
+// ---------------------------------------------------------------------------------------------
+constexpr int GEMVT_KEYS = 4;                  // keys per wave step (x K and V loads)
+
+__host__ __device__ inline bool gemv_tm_applicable(const fa_params& p) {
+    return p.kv_dtype == FA_FP8_E4M3 && p.head_dim == 128 && p.head_dim_v == 0 && p.seqlen_q == 1 && p.nheads_q == p.nheads_k &&
+           p.nheads_k % 32 == 0 && p.k_head_stride == 128 && p.v_head_stride == 128;
+}
+
+template <typename T, bool PAGED>
+__global__ void __launch_bounds__(GEMV_THREADS) fa_decode_gemv_fp8_tm_kernel(const DecArgs da) {
+    using E = Elem<T>;
+    constexpr int D = 128;
+    const KArgs& a = da.a;
+    const fa_params& p = a.p;
+    const int b = blockIdx.x, split = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, grp = lane >> 3, sub = lane & 7;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    const int L = p.cache_seqlens ? p.cache_seqlens[b] : 0;
+    const int lp = p.cache_leftpad ? p.cache_leftpad[b] : 0;
+    const int cb = p.cache_batch_idx ? p.cache_batch_idx[b] : b;
+    const int seqlen_k = L + p.seqlen_new;
+    const int off = seqlen_k - 1;
+    const int wl = p.window_left;
+    const int wr = p.is_causal ? 0 : p.window_right;
+    int lo = 0, hi = seqlen_k - 1;
+    if (wr >= 0) { const int h2 = off + wr; hi = h2 < hi ? h2 : hi; }
+    if (wl >= 0) { const int l2 = off - wl; lo = l2 > lo ? l2 : lo; }
+    // key range of this split, in whole steps
+    const int n_keys = hi >= lo ? hi - lo + 1 : 0;
+    const int per_split = (((n_keys + da.n_splits - 1) / da.n_splits) + GEMVT_KEYS - 1) / GEMVT_KEYS * GEMVT_KEYS;
+    const int k_lo = lo + split * per_split;
+    int k_hi = k_lo + per_split; k_hi = k_hi < hi + 1 ? k_hi : hi + 1;              // exclusive
+
+    const int32_t* btab = PAGED ? p.block_table + (int64_t)b * p.block_table_batch_stride : nullptr;
+    const int half = p.rotary_dim >> 1;
+    const int pos_q = L + lp;
+    const uint16_t* cosp = reinterpret_cast<const uint16_t*>(p.rotary_cos) + (int64_t)pos_q * half;
+    const uint16_t* sinp = reinterpret_cast<const uint16_t*>(p.rotary_sin) + (int64_t)pos_q * half;
+    const float c = a.scale_log2e * p.k_descale;
+
+    for (int hg = wave; hg < p.nheads_k / 8; hg += 4) {
+        const int h = 8 * hg + grp;
+        // ---- q of the lane's head: 16 columns, RoPE, x scale ----
+        float qs[16];
+        {
+            const uint16_t* qrow = reinterpret_cast<const uint16_t*>(p.q) + (int64_t)b * p.q_batch_stride + (int64_t)h * p.q_head_stride;
+#pragma unroll
+            for (int cpart = 0; cpart < 2; ++cpart) {
+                const int d_base = 16 * sub + 8 * cpart;
+                u32x4 x = *reinterpret_cast<const u32x4*>(qrow + d_base);
+                if (p.rotary_dim > 0 && d_base < p.rotary_dim && pos_q >= 0 && pos_q < p.seqlen_ro) {
+                    u32x4 xp = x;
+                    if (!p.rotary_interleaved) {
+                        const int pd = d_base < half ? d_base + half : d_base - half;
+                        xp = *reinterpret_cast<const u32x4*>(qrow + pd);
+                    }
+                    rope_chunk<T>(x, xp, cosp, sinp, d_base, p.rotary_dim, p.rotary_interleaved != 0);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { qs[8 * cpart + 2 * i] = E::lo(x[i]) * c; qs[8 * cpart + 2 * i + 1] = E::hi(x[i]) * c; }
+            }
+        }
+        const uint32_t lane_off = (uint32_t)h * 128u + 16u * (uint32_t)sub;          // bytes inside a cache row
+        const uint8_t* kbase = reinterpret_cast<const uint8_t*>(p.k) + lane_off;
+        const uint8_t* vbase = reinterpret_cast<const uint8_t*>(p.v) + lane_off;
+
+        float o[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[i] = 0.f;
+        float m_run = -INFINITY, l_run = 0.f;
+
+        // A page (or the whole dense cache) is a SEGMENT of consecutive rows: its base is looked up once (the lookup
+        // needs a full wait on the memory queue - done per key it serialised every load, 4.7 TB/s), the loads inside a
+        // segment are address arithmetic on the scalar unit and stay two steps deep in flight.
+        const uint8_t* kseg = nullptr;
+        const uint8_t* vseg = nullptr;
+        int seg_n = 0;                                             // rows left in the current segment
+        auto load_step = [&](int t0, u32x4 (&kx)[GEMVT_KEYS], u32x4 (&vx)[GEMVT_KEYS]) {
+#pragma unroll
+            for (int i = 0; i < GEMVT_KEYS; ++i) {
+                int t = t0 + i;
+                t = t < seg_n ? t : seg_n - 1;                     // tail of the segment: reload its last row (masked below)
+                kx[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(kseg + (int64_t)t * p.k_row_stride));
+                vx[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(vseg + (int64_t)t * p.v_row_stride));
+            }
+        };
+        auto dot16 = [&](const u32x4& w) {
+            float acc = 0.f;
+#pragma unroll
+            for (int d4 = 0; d4 < 4; ++d4) {
+                const f32x2 a0 = __builtin_amdgcn_cvt_pk_f32_fp8(w[d4], false);
+                const f32x2 a1 = __builtin_amdgcn_cvt_pk_f32_fp8(w[d4], true);
+                acc = fmaf(a0[0], qs[4 * d4 + 0], acc); acc = fmaf(a0[1], qs[4 * d4 + 1], acc);
+                acc = fmaf(a1[0], qs[4 * d4 + 2], acc); acc = fmaf(a1[1], qs[4 * d4 + 3], acc);
+            }
+            return acc;
+        };
+        auto compute_step = [&](int j0, const u32x4 (&kx)[GEMVT_KEYS], const u32x4 (&vx)[GEMVT_KEYS]) {
+            float sv[GEMVT_KEYS];
+            float mx = m_run;
+#pragma unroll
+            for (int i = 0; i < GEMVT_KEYS; ++i) {
+                const float sd = grp8_sum(dot16(kx[i]));
+                sv[i] = (j0 + i < seg_n) ? sd : -INFINITY;
+                mx = fmaxf(mx, sv[i]);
+            }
+            const float m_use = (mx == -INFINITY) ? 0.f : mx;
+            const float alpha = fast_exp2(m_run - m_use);
+            m_run = mx;
+            float pw[GEMVT_KEYS], ps = 0.f;
+#pragma unroll
+            for (int i = 0; i < GEMVT_KEYS; ++i) { pw[i] = fast_exp2(sv[i] - m_use); ps += pw[i]; }
+            l_run = fmaf(l_run, alpha, ps);
+#pragma unroll
+            for (int x = 0; x < 16; ++x) o[x] *= alpha;
+#pragma unroll
+            for (int i = 0; i < GEMVT_KEYS; ++i) {
+#pragma unroll
+                for (int d4 = 0; d4 < 4; ++d4) {
+                    const f32x2 a0 = __builtin_amdgcn_cvt_pk_f32_fp8(vx[i][d4], false);
+                    const f32x2 a1 = __builtin_amdgcn_cvt_pk_f32_fp8(vx[i][d4], true);
+                    o[4 * d4 + 0] = fmaf(pw[i], a0[0], o[4 * d4 + 0]); o[4 * d4 + 1] = fmaf(pw[i], a0[1], o[4 * d4 + 1]);
+                    o[4 * d4 + 2] = fmaf(pw[i], a1[0], o[4 * d4 + 2]); o[4 * d4 + 3] = fmaf(pw[i], a1[1], o[4 * d4 + 3]);
+                }
+            }
+        };
+
+        // two register sets: the loads of the next step are in flight while a step is consumed
+        u32x4 kA[GEMVT_KEYS], vA[GEMVT_KEYS], kB[GEMVT_KEYS], vB[GEMVT_KEYS];
+        int j = k_lo;
+        while (j < k_hi) {
+            const int pos = lp + j;
+            int64_t ko, vo;
+            if (PAGED) {
+                const int pg = da.page_shift >= 0 ? (pos >> da.page_shift) : pos / p.page_block_size;
+                const int pr = pos - pg * p.page_block_size;
+                const int64_t phys = __builtin_amdgcn_readfirstlane(btab[pg]);
+                ko = phys * p.k_batch_stride + (int64_t)pr * p.k_row_stride;
+                vo = phys * p.v_batch_stride + (int64_t)pr * p.v_row_stride;
+                seg_n = p.page_block_size - pr;
+            } else {
+                ko = (int64_t)cb * p.k_batch_stride + (int64_t)pos * p.k_row_stride;
+                vo = (int64_t)cb * p.v_batch_stride + (int64_t)pos * p.v_row_stride;
+                seg_n = k_hi - j;
+            }
+            seg_n = seg_n < k_hi - j ? seg_n : k_hi - j;
+            kseg = kbase + ko;
+            vseg = vbase + vo;
+            load_step(0, kA, vA);
+            for (int t = 0; t < seg_n; t += 2 * GEMVT_KEYS) {
+                if (t + GEMVT_KEYS < seg_n) load_step(t + GEMVT_KEYS, kB, vB);
+                compute_step(t, kA, vA);
+                if (t + GEMVT_KEYS < seg_n) {
+                    if (t + 2 * GEMVT_KEYS < seg_n) load_step(t + 2 * GEMVT_KEYS, kA, vA);
+                    compute_step(t + GEMVT_KEYS, kB, vB);
+                }
+            }
+            j += seg_n;
+        }
+
+        // ---- this group's head: normalised partial (or final) output ----
+        const float inv = l_run > 0.f ? p.v_descale / l_run : 0.f;
+        const float lse = l_run > 0.f ? (m_run + fast_log2(l_run)) * kLn2 : -INFINITY;
+        if (da.n_splits == 1) {
+            uint16_t* op = reinterpret_cast<uint16_t*>(p.o) + (int64_t)b * p.o_batch_stride + (int64_t)h * p.o_head_stride + 16 * sub;
+            u32x4 w0, w1;
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                w0[x] = E::pack2(o[2 * x] * inv, o[2 * x + 1] * inv);
+                w1[x] = E::pack2(o[8 + 2 * x] * inv, o[8 + 2 * x + 1] * inv);
+            }
+            *reinterpret_cast<u32x4*>(op) = w0;
+            *reinterpret_cast<u32x4*>(op + 8) = w1;
+            if (sub == 0) p.lse[(int64_t)b * p.lse_batch_stride + (int64_t)h * p.lse_head_stride] = lse;
+        } else {
+            const int64_t prow = ((int64_t)split * p.batch + b) * p.nheads_q + h;
+            float* dst = da.o_partial + prow * D + 16 * sub;
+#pragma unroll
+            for (int x = 0; x < 16; x += 4) {
+                f32x4 w = {o[x] * inv, o[x + 1] * inv, o[x + 2] * inv, o[x + 3] * inv};
+                *reinterpret_cast<f32x4*>(dst + x) = w;
+            }
+            if (sub == 0) da.lse_partial[prow] = lse;
+        }
+    }
+}
+
 // ---- host ---------------------------------------------------------------------------------------
 bool decode_applicable(const fa_params& p) {
     if (p.alibi_slopes || p.softcap > 0.f) return false;
     const int G = p.nheads_q / p.nheads_k;
     return p.seqlen_q * G <= 32 && (p.head_dim == 64 || p.head_dim == 128) && p.head_dim_v == 0;
+}
+
+static int device_cu_count() {
+    static const int n = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        return v;
+    }();
+    return n;
 }
 
 int decode_num_splits(const fa_params& p) {
@@ -676,6 +911,36 @@ int decode_num_splits(const fa_params& p) {
     const int max_tiles = (p.seqlen_k + DEC_BN - 1) / DEC_BN;
     int s = 1;
     while (units * s < 512 && s < 32 && max_tiles / (s * 2) >= 8) s *= 2;       // >= 8 tiles (256 keys) per split
+    // The streaming fp8 kernel keeps three workgroups per CU resident: with 4096 units on 256 CUs the grid runs 5.33
+    // "rounds" and the last one is a third full (11 % of the time at a third of the rate).  Split the key range so that
+    // the grid is a near-multiple of what is resident; the partials cost 4 MB and one tiny combine launch.
+    if (gemv_tm_applicable(p)) {
+        // token-major streaming kernel: grid = batch x splits.  Measured at config 4
+        // (tools/decode_splits_probe.py): one workgroup per CU in ONE round is best, every doubling
+        // beyond costs ~2 %, a partial last round costs its idle share - pick the split count with the best of both.
+        const double resident = 1.0 * device_cu_count();   // (one workgroup per CU streams best: 2 splits 7.0 TB/s, 4 splits 6.8, 12 splits 6.4)
+        const int cap = p.seqlen_k / 64 > 0 ? (p.seqlen_k / 64 < 64 ? p.seqlen_k / 64 : 64) : 1;
+        int best = 1;
+        double best_score = -1.0;
+        for (int k = 1; k <= cap; ++k) {
+            const double r = p.batch * (double)k / resident;
+            const double eff = r / (double)(int64_t)(r + 0.999999);
+            double pen = 0.0;
+            for (int t = k; t > 1; t >>= 1) pen += 0.02;
+            const double score = eff - pen;
+            if (score > best_score + 1e-9) { best_score = score; best = k; }
+        }
+        return best;
+    }
+    const bool gemv = p.kv_dtype == FA_FP8_E4M3 && p.head_dim == 128 && p.seqlen_q == 1 && p.nheads_q == p.nheads_k;
+    if (gemv && s == 1) {
+        const double resident = 3.0 * device_cu_count();
+        auto eff = [&](int k) { const double r = units * (double)k / resident; return r / (double)(int64_t)(r + 0.999999); };
+        for (int k = 1; k <= 8; ++k) {
+            if (k > 1 && max_tiles / k < 16) break;                             // >= 512 keys per split
+            if (eff(k) >= 0.94) { s = k; break; }
+        }
+    }
     return s;
 }
 
@@ -696,7 +961,12 @@ static int launch_decode_td(DecArgs& da, hipStream_t stream) {
     if constexpr (D == 128) {
         // one query row per kv-head and an fp8 cache: the streaming matrix-vector kernel
         if (kv8 && da.rows == 1 && da.group == 1) {
-            if (paged) hipLaunchKernelGGL((fa_decode_gemv_fp8_kernel<T, true>), grid, dim3(GEMV_THREADS), 0, stream, da);
+            if (gemv_tm_applicable(p)) {
+                dim3 grid_tm(p.batch, da.n_splits);
+                if (paged) hipLaunchKernelGGL((fa_decode_gemv_fp8_tm_kernel<T, true>), grid_tm, dim3(GEMV_THREADS), 0, stream, da);
+                else       hipLaunchKernelGGL((fa_decode_gemv_fp8_tm_kernel<T, false>), grid_tm, dim3(GEMV_THREADS), 0, stream, da);
+            }
+            else if (paged) hipLaunchKernelGGL((fa_decode_gemv_fp8_kernel<T, true>), grid, dim3(GEMV_THREADS), 0, stream, da);
             else       hipLaunchKernelGGL((fa_decode_gemv_fp8_kernel<T, false>), grid, dim3(GEMV_THREADS), 0, stream, da);
             if (da.n_splits > 1) {
                 const int64_t total = (int64_t)p.batch * p.nheads_q * p.seqlen_q * (D / 8);

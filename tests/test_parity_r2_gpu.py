@@ -445,15 +445,18 @@ def test_context_parallel_two_shards_on_one_gpu(causal):
 
 
 # ------------------------------------------------------------------------------------------------ fp8 matrix-vector decode
+@pytest.mark.parametrize("H", [4, 32, 64])
 @pytest.mark.parametrize("paged,window,interleaved,use_lp,splits", [
     (True, (-1, -1), False, False, 0), (False, (-1, -1), True, True, 0), (True, (300, -1), False, False, 4),
     (False, (-1, -1), False, False, 3), (True, (-1, -1), True, True, 1)])
-def test_decode_fp8_gemv_kernel(paged, window, interleaved, use_lp, splits):
-    """fa_decode_gemv_fp8_kernel (one query row per kv-head, fp8 cache: BASELINE config 4's kernel) vs the oracle:
-    paged / dense caches, cache_batch_idx, left pad, windows, both RoPE styles, split-KV, ragged cache lengths."""
+def test_decode_fp8_gemv_kernel(paged, window, interleaved, use_lp, splits, H):
+    """The streaming matrix-vector decode kernels (one query row per kv-head, fp8 cache: BASELINE config 4) vs the oracle:
+    H = 4 takes the head-major kernel (fa_decode_gemv_fp8_kernel), H = 32 / 64 the token-major one
+    (fa_decode_gemv_fp8_tm_kernel: one or two rounds of eight heads per wave); paged / dense caches, cache_batch_idx,
+    left pad, windows, both RoPE styles, split-KV (heuristic, explicit, none), ragged cache lengths incl. length 1."""
     fa = _fa()
     dt = "bf16"
-    B, H, D, page = 5, 4, 128, 256
+    B, D, page = 5, 128, 256
     kd, vd = 0.05, 0.04
     Smax = 1100
     g = torch.Generator().manual_seed(3)
