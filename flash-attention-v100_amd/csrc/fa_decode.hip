@@ -704,19 +704,33 @@ __global__ void __launch_bounds__(GEMV_THREADS) fa_decode_gemv_fp8_kernel(const 
 // ---------------------------------------------------------------------------------------------
 constexpr int GEMVT_KEYS = 4;                  // keys per wave step (x K and V loads)
 
+// (16-bit caches: 16 lanes per head, a wave instruction = one token x 4 heads; the kernel is the same)
 __host__ __device__ inline bool gemv_tm_applicable(const fa_params& p) {
-    return p.kv_dtype == FA_FP8_E4M3 && p.head_dim == 128 && p.head_dim_v == 0 && p.seqlen_q == 1 && p.nheads_q == p.nheads_k &&
-           p.nheads_k % 32 == 0 && p.k_head_stride == 128 && p.v_head_stride == 128;
+    const bool kv8 = p.kv_dtype == FA_FP8_E4M3;
+    if (!kv8 && p.kv_dtype != p.dtype) return false;
+    return p.head_dim == 128 && p.head_dim_v == 0 && p.seqlen_q == 1 && p.nheads_q == p.nheads_k &&
+           p.nheads_k % (kv8 ? 32 : 16) == 0 && p.k_head_stride == 128 && p.v_head_stride == 128 &&
+           !p.alibi_slopes && p.softcap <= 0.f;
 }
 
-template <typename T, bool PAGED>
-__global__ void __launch_bounds__(GEMV_THREADS) fa_decode_gemv_fp8_tm_kernel(const DecArgs da) {
+__device__ __forceinline__ float grp16_sum(float x) {
+    x = grp8_sum(x);
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x140, 0xf, 0xf, false));   // row mirror
+    return x;
+}
+
+template <typename T, bool PAGED, bool KV8>
+__global__ void __launch_bounds__(GEMV_THREADS) fa_decode_gemv_tm_kernel(const DecArgs da) {
     using E = Elem<T>;
     constexpr int D = 128;
+    constexpr int LPH = KV8 ? 8 : 16;          // lanes per head (16 bytes of the head's row each)
+    constexpr int HPW = 64 / LPH;              // heads per wave instruction
+    constexpr int CPL = KV8 ? 16 : 8;          // head-dim columns per lane
+    constexpr int ES = KV8 ? 1 : 2;            // bytes per cache element
     const KArgs& a = da.a;
     const fa_params& p = a.p;
     const int b = blockIdx.x, split = blockIdx.y;
-    const int tid = threadIdx.x, lane = tid & 63, grp = lane >> 3, sub = lane & 7;
+    const int tid = threadIdx.x, lane = tid & 63, grp = lane / LPH, sub = lane % LPH;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
     const int L = p.cache_seqlens ? p.cache_seqlens[b] : 0;
@@ -742,15 +756,15 @@ __global__ void __launch_bounds__(GEMV_THREADS) fa_decode_gemv_fp8_tm_kernel(con
     const uint16_t* sinp = reinterpret_cast<const uint16_t*>(p.rotary_sin) + (int64_t)pos_q * half;
     const float c = a.scale_log2e * p.k_descale;
 
-    for (int hg = wave; hg < p.nheads_k / 8; hg += 4) {
-        const int h = 8 * hg + grp;
-        // ---- q of the lane's head: 16 columns, RoPE, x scale ----
-        float qs[16];
+    for (int hg = wave; hg < p.nheads_k / HPW; hg += 4) {
+        const int h = HPW * hg + grp;
+        // ---- q of the lane's head: CPL columns, RoPE, x scale ----
+        float qs[CPL];
         {
             const uint16_t* qrow = reinterpret_cast<const uint16_t*>(p.q) + (int64_t)b * p.q_batch_stride + (int64_t)h * p.q_head_stride;
 #pragma unroll
-            for (int cpart = 0; cpart < 2; ++cpart) {
-                const int d_base = 16 * sub + 8 * cpart;
+            for (int cpart = 0; cpart < CPL / 8; ++cpart) {
+                const int d_base = CPL * sub + 8 * cpart;
                 u32x4 x = *reinterpret_cast<const u32x4*>(qrow + d_base);
                 if (p.rotary_dim > 0 && d_base < p.rotary_dim && pos_q >= 0 && pos_q < p.seqlen_ro) {
                     u32x4 xp = x;
@@ -764,13 +778,13 @@ __global__ void __launch_bounds__(GEMV_THREADS) fa_decode_gemv_fp8_tm_kernel(con
                 for (int i = 0; i < 4; ++i) { qs[8 * cpart + 2 * i] = E::lo(x[i]) * c; qs[8 * cpart + 2 * i + 1] = E::hi(x[i]) * c; }
             }
         }
-        const uint32_t lane_off = (uint32_t)h * 128u + 16u * (uint32_t)sub;          // bytes inside a cache row
+        const uint32_t lane_off = (uint32_t)h * (128u * ES) + 16u * (uint32_t)sub;   // bytes inside a cache row
         const uint8_t* kbase = reinterpret_cast<const uint8_t*>(p.k) + lane_off;
         const uint8_t* vbase = reinterpret_cast<const uint8_t*>(p.v) + lane_off;
 
-        float o[16];
+        float o[CPL];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) o[i] = 0.f;
+        for (int i = 0; i < CPL; ++i) o[i] = 0.f;
         float m_run = -INFINITY, l_run = 0.f;
 
         // A page (or the whole dense cache) is a SEGMENT of consecutive rows: its base is looked up once (the lookup
@@ -784,18 +798,22 @@ __global__ void __launch_bounds__(GEMV_THREADS) fa_decode_gemv_fp8_tm_kernel(con
             for (int i = 0; i < GEMVT_KEYS; ++i) {
                 int t = t0 + i;
                 t = t < seg_n ? t : seg_n - 1;                     // tail of the segment: reload its last row (masked below)
-                kx[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(kseg + (int64_t)t * p.k_row_stride));
-                vx[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(vseg + (int64_t)t * p.v_row_stride));
+                kx[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(kseg + (int64_t)t * p.k_row_stride * ES));
+                vx[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(vseg + (int64_t)t * p.v_row_stride * ES));
             }
         };
         auto dot16 = [&](const u32x4& w) {
             float acc = 0.f;
 #pragma unroll
             for (int d4 = 0; d4 < 4; ++d4) {
-                const f32x2 a0 = __builtin_amdgcn_cvt_pk_f32_fp8(w[d4], false);
-                const f32x2 a1 = __builtin_amdgcn_cvt_pk_f32_fp8(w[d4], true);
-                acc = fmaf(a0[0], qs[4 * d4 + 0], acc); acc = fmaf(a0[1], qs[4 * d4 + 1], acc);
-                acc = fmaf(a1[0], qs[4 * d4 + 2], acc); acc = fmaf(a1[1], qs[4 * d4 + 3], acc);
+                if constexpr (KV8) {
+                    const f32x2 a0 = __builtin_amdgcn_cvt_pk_f32_fp8(w[d4], false);
+                    const f32x2 a1 = __builtin_amdgcn_cvt_pk_f32_fp8(w[d4], true);
+                    acc = fmaf(a0[0], qs[4 * d4 + 0], acc); acc = fmaf(a0[1], qs[4 * d4 + 1], acc);
+                    acc = fmaf(a1[0], qs[4 * d4 + 2], acc); acc = fmaf(a1[1], qs[4 * d4 + 3], acc);
+                } else {
+                    acc = fmaf(E::lo(w[d4]), qs[2 * d4 + 0], acc); acc = fmaf(E::hi(w[d4]), qs[2 * d4 + 1], acc);
+                }
             }
             return acc;
         };
@@ -804,7 +822,7 @@ __global__ void __launch_bounds__(GEMV_THREADS) fa_decode_gemv_fp8_tm_kernel(con
             float mx = m_run;
 #pragma unroll
             for (int i = 0; i < GEMVT_KEYS; ++i) {
-                const float sd = grp8_sum(dot16(kx[i]));
+                const float sd = KV8 ? grp8_sum(dot16(kx[i])) : grp16_sum(dot16(kx[i]));
                 sv[i] = (j0 + i < seg_n) ? sd : -INFINITY;
                 mx = fmaxf(mx, sv[i]);
             }
@@ -816,15 +834,20 @@ __global__ void __launch_bounds__(GEMV_THREADS) fa_decode_gemv_fp8_tm_kernel(con
             for (int i = 0; i < GEMVT_KEYS; ++i) { pw[i] = fast_exp2(sv[i] - m_use); ps += pw[i]; }
             l_run = fmaf(l_run, alpha, ps);
 #pragma unroll
-            for (int x = 0; x < 16; ++x) o[x] *= alpha;
+            for (int x = 0; x < CPL; ++x) o[x] *= alpha;
 #pragma unroll
             for (int i = 0; i < GEMVT_KEYS; ++i) {
 #pragma unroll
                 for (int d4 = 0; d4 < 4; ++d4) {
-                    const f32x2 a0 = __builtin_amdgcn_cvt_pk_f32_fp8(vx[i][d4], false);
-                    const f32x2 a1 = __builtin_amdgcn_cvt_pk_f32_fp8(vx[i][d4], true);
-                    o[4 * d4 + 0] = fmaf(pw[i], a0[0], o[4 * d4 + 0]); o[4 * d4 + 1] = fmaf(pw[i], a0[1], o[4 * d4 + 1]);
-                    o[4 * d4 + 2] = fmaf(pw[i], a1[0], o[4 * d4 + 2]); o[4 * d4 + 3] = fmaf(pw[i], a1[1], o[4 * d4 + 3]);
+                    if constexpr (KV8) {
+                        const f32x2 a0 = __builtin_amdgcn_cvt_pk_f32_fp8(vx[i][d4], false);
+                        const f32x2 a1 = __builtin_amdgcn_cvt_pk_f32_fp8(vx[i][d4], true);
+                        o[4 * d4 + 0] = fmaf(pw[i], a0[0], o[4 * d4 + 0]); o[4 * d4 + 1] = fmaf(pw[i], a0[1], o[4 * d4 + 1]);
+                        o[4 * d4 + 2] = fmaf(pw[i], a1[0], o[4 * d4 + 2]); o[4 * d4 + 3] = fmaf(pw[i], a1[1], o[4 * d4 + 3]);
+                    } else {
+                        o[2 * d4 + 0] = fmaf(pw[i], E::lo(vx[i][d4]), o[2 * d4 + 0]);
+                        o[2 * d4 + 1] = fmaf(pw[i], E::hi(vx[i][d4]), o[2 * d4 + 1]);
+                    }
                 }
             }
         };
@@ -839,12 +862,12 @@ __global__ void __launch_bounds__(GEMV_THREADS) fa_decode_gemv_fp8_tm_kernel(con
                 const int pg = da.page_shift >= 0 ? (pos >> da.page_shift) : pos / p.page_block_size;
                 const int pr = pos - pg * p.page_block_size;
                 const int64_t phys = __builtin_amdgcn_readfirstlane(btab[pg]);
-                ko = phys * p.k_batch_stride + (int64_t)pr * p.k_row_stride;
-                vo = phys * p.v_batch_stride + (int64_t)pr * p.v_row_stride;
+                ko = (phys * p.k_batch_stride + (int64_t)pr * p.k_row_stride) * ES;
+                vo = (phys * p.v_batch_stride + (int64_t)pr * p.v_row_stride) * ES;
                 seg_n = p.page_block_size - pr;
             } else {
-                ko = (int64_t)cb * p.k_batch_stride + (int64_t)pos * p.k_row_stride;
-                vo = (int64_t)cb * p.v_batch_stride + (int64_t)pos * p.v_row_stride;
+                ko = ((int64_t)cb * p.k_batch_stride + (int64_t)pos * p.k_row_stride) * ES;
+                vo = ((int64_t)cb * p.v_batch_stride + (int64_t)pos * p.v_row_stride) * ES;
                 seg_n = k_hi - j;
             }
             seg_n = seg_n < k_hi - j ? seg_n : k_hi - j;
@@ -866,21 +889,20 @@ __global__ void __launch_bounds__(GEMV_THREADS) fa_decode_gemv_fp8_tm_kernel(con
         const float inv = l_run > 0.f ? p.v_descale / l_run : 0.f;
         const float lse = l_run > 0.f ? (m_run + fast_log2(l_run)) * kLn2 : -INFINITY;
         if (da.n_splits == 1) {
-            uint16_t* op = reinterpret_cast<uint16_t*>(p.o) + (int64_t)b * p.o_batch_stride + (int64_t)h * p.o_head_stride + 16 * sub;
-            u32x4 w0, w1;
+            uint16_t* op = reinterpret_cast<uint16_t*>(p.o) + (int64_t)b * p.o_batch_stride + (int64_t)h * p.o_head_stride + CPL * sub;
 #pragma unroll
-            for (int x = 0; x < 4; ++x) {
-                w0[x] = E::pack2(o[2 * x] * inv, o[2 * x + 1] * inv);
-                w1[x] = E::pack2(o[8 + 2 * x] * inv, o[8 + 2 * x + 1] * inv);
+            for (int c8 = 0; c8 < CPL / 8; ++c8) {
+                u32x4 w0;
+#pragma unroll
+                for (int x = 0; x < 4; ++x) w0[x] = E::pack2(o[8 * c8 + 2 * x] * inv, o[8 * c8 + 2 * x + 1] * inv);
+                *reinterpret_cast<u32x4*>(op + 8 * c8) = w0;
             }
-            *reinterpret_cast<u32x4*>(op) = w0;
-            *reinterpret_cast<u32x4*>(op + 8) = w1;
             if (sub == 0) p.lse[(int64_t)b * p.lse_batch_stride + (int64_t)h * p.lse_head_stride] = lse;
         } else {
             const int64_t prow = ((int64_t)split * p.batch + b) * p.nheads_q + h;
-            float* dst = da.o_partial + prow * D + 16 * sub;
+            float* dst = da.o_partial + prow * D + CPL * sub;
 #pragma unroll
-            for (int x = 0; x < 16; x += 4) {
+            for (int x = 0; x < CPL; x += 4) {
                 f32x4 w = {o[x] * inv, o[x + 1] * inv, o[x + 2] * inv, o[x + 3] * inv};
                 *reinterpret_cast<f32x4*>(dst + x) = w;
             }
@@ -963,11 +985,24 @@ static int launch_decode_td(DecArgs& da, hipStream_t stream) {
         if (kv8 && da.rows == 1 && da.group == 1) {
             if (gemv_tm_applicable(p)) {
                 dim3 grid_tm(p.batch, da.n_splits);
-                if (paged) hipLaunchKernelGGL((fa_decode_gemv_fp8_tm_kernel<T, true>), grid_tm, dim3(GEMV_THREADS), 0, stream, da);
-                else       hipLaunchKernelGGL((fa_decode_gemv_fp8_tm_kernel<T, false>), grid_tm, dim3(GEMV_THREADS), 0, stream, da);
+                if (paged) hipLaunchKernelGGL((fa_decode_gemv_tm_kernel<T, true, true>), grid_tm, dim3(GEMV_THREADS), 0, stream, da);
+                else       hipLaunchKernelGGL((fa_decode_gemv_tm_kernel<T, false, true>), grid_tm, dim3(GEMV_THREADS), 0, stream, da);
             }
             else if (paged) hipLaunchKernelGGL((fa_decode_gemv_fp8_kernel<T, true>), grid, dim3(GEMV_THREADS), 0, stream, da);
             else       hipLaunchKernelGGL((fa_decode_gemv_fp8_kernel<T, false>), grid, dim3(GEMV_THREADS), 0, stream, da);
+            if (da.n_splits > 1) {
+                const int64_t total = (int64_t)p.batch * p.nheads_q * p.seqlen_q * (D / 8);
+                hipLaunchKernelGGL(decode_combine_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, da);
+            }
+            return 0;
+        }
+    }
+    if constexpr (D == 128) {
+        // 16-bit cache, one query row per kv-head: the same token-major streaming kernel (16 lanes per head)
+        if (!kv8 && da.rows == 1 && da.group == 1 && gemv_tm_applicable(p)) {
+            dim3 grid_tm(p.batch, da.n_splits);
+            if (paged) hipLaunchKernelGGL((fa_decode_gemv_tm_kernel<T, true, false>), grid_tm, dim3(GEMV_THREADS), 0, stream, da);
+            else       hipLaunchKernelGGL((fa_decode_gemv_tm_kernel<T, false, false>), grid_tm, dim3(GEMV_THREADS), 0, stream, da);
             if (da.n_splits > 1) {
                 const int64_t total = (int64_t)p.batch * p.nheads_q * p.seqlen_q * (D / 8);
                 hipLaunchKernelGGL(decode_combine_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, da);

