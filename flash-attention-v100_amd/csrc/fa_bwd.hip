@@ -442,13 +442,13 @@ __global__ void __launch_bounds__(BWD_THREADS, 1) fa_bwd_dkdv_kernel(const KArgs
             dsv[r] = dsr;
         }
         if (need_mask) {
-            const int lo_t = qlo - q0 - 4 * g;
-            const uint32_t width = (uint32_t)(qhi - qlo);
-            const bool empty = qhi < qlo;
+            const bool empty = qhi < qlo;                  // folded into the operands (see fa_fwd.hip)
+            const int lo_t = empty ? 0x3fffffff : qlo - q0 - 4 * g;
+            const uint32_t width = empty ? 0u : (uint32_t)(qhi - qlo);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int cpos = (r & 3) + 8 * (r >> 2);
-                if (empty || (uint32_t)(cpos - lo_t) > width) { pv[r] = 0.f; dsv[r] = 0.f; }
+                if ((uint32_t)(cpos - lo_t) > width) { pv[r] = 0.f; dsv[r] = 0.f; }
             }
         }
         // k-step t of phase bk covers regs 8t .. 8t+7
@@ -976,9 +976,9 @@ __global__ void __launch_bounds__(BWD_THREADS, D <= 64 ? FA_DKV2_OCC64 : 2) fa_b
         }
         // ---- P, dS ----
         const bool need_mask = key_tail || (q0 < w_qlo_max) || (q0 + 31 > w_qhi_min);
-        const int lo_t = qlo - q0 - 4 * g;
-        const uint32_t width = (uint32_t)(qhi - qlo);
-        const bool empty = qhi < qlo;
+        const bool empty = qhi < qlo;                      // folded into the operands (see fa_fwd.hip)
+        const int lo_t = empty ? 0x3fffffff : qlo - q0 - 4 * g;
+        const uint32_t width = empty ? 0u : (uint32_t)(qhi - qlo);
         u32x4 pf[2], dsf[2];
         const int sidx = 16 * g;                             // byte index of lane 4 g for ds_bpermute
         (void)sidx;
@@ -1047,7 +1047,7 @@ __global__ void __launch_bounds__(BWD_THREADS, D <= 64 ? FA_DKV2_OCC64 : 2) fa_b
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int cpos = (r & 3) + 8 * (r >> 2);
-                if (empty || (uint32_t)(cpos - lo_t) > width) { pv[r] = 0.f; dsv[r] = 0.f; }
+                if ((uint32_t)(cpos - lo_t) > width) { pv[r] = 0.f; dsv[r] = 0.f; }
             }
         }
 #pragma unroll
@@ -1434,13 +1434,13 @@ __global__ void __launch_bounds__(BWD_THREADS, OCC) fa_bwd_dq_kernel(const KArgs
                 dsv[r] = dsr;
             }
             if (need_mask) {
-                const int lo_t = lo - n0 - kb * 32 - 4 * g;
-                const uint32_t width = (uint32_t)(hi - lo);
-                const bool empty = hi < lo;
+                const bool empty = hi < lo;                // folded into the operands (see fa_fwd.hip)
+                const int lo_t = empty ? 0x3fffffff : lo - n0 - kb * 32 - 4 * g;
+                const uint32_t width = empty ? 0u : (uint32_t)(hi - lo);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int cpos = (r & 3) + 8 * (r >> 2);
-                    if (empty || (uint32_t)(cpos - lo_t) > width) dsv[r] = 0.f;
+                    if ((uint32_t)(cpos - lo_t) > width) dsv[r] = 0.f;
                 }
             }
             // dQ^T += K^T dS^T

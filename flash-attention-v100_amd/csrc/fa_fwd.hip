@@ -170,6 +170,7 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : FA_FWD_OCC)) fa_fw
             u32x4 z = {0, 0, 0, 0};
             qf[ks] = (ok && 16 * ks + 8 * g < dv) ? *reinterpret_cast<const u32x4*>(qrow + 16 * ks) : z;
         }
+#ifndef FA_NO_ROPE_Q
         if (a.rope_q && ok) {
             // kv-cache call with rotary tables: rotate the row in registers (no rotated-Q copy, no extra launch).  The
             // partner chunk of the non-interleaved form (d +- rotary_dim / 2) is one more 16-byte load per chunk.
@@ -196,6 +197,7 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : FA_FWD_OCC)) fa_fw
                 }
             }
         }
+#endif
     }
 
     // ---- staging ---------------------------------------------------------------------------
@@ -437,15 +439,17 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : FA_FWD_OCC)) fa_fw
         if (need_mask) {
             // the key of register (kb, r) is n0 + 4 g + c with c a compile-time constant: one unsigned
             // compare of (c - lo_t) against the band width instead of rebuilding j per element
-            const int lo_t = lo - n0 - 4 * g;
-            const uint32_t width = (uint32_t)(hi - lo);                    // hi < lo (empty row) -> huge: see below
+            // (an empty row, hi < lo, is folded into the operands: width 0 against a position that never matches -
+            // a separate `empty ||` cost one scalar OR per element)
             const bool empty = hi < lo;
+            const int lo_t = empty ? 0x3fffffff : lo - n0 - 4 * g;
+            const uint32_t width = empty ? 0u : (uint32_t)(hi - lo);
 #pragma unroll
             for (int kb = 0; kb < FWD_NKB; ++kb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int cpos = kb * 32 + (r & 3) + 8 * (r >> 2);
-                    if (empty || (uint32_t)(cpos - lo_t) > width) sacc[kb][r] = -INFINITY;
+                    if ((uint32_t)(cpos - lo_t) > width) sacc[kb][r] = -INFINITY;
                 }
         }
         // ---- online softmax (log2 domain) with deferred rescale ----
