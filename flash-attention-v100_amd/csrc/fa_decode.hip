@@ -36,6 +36,7 @@ struct DecArgs {
     int group;                 // G
     int local;                 // RoPE position advances with the query row (causal / window)
     int page_shift;            // log2(page_block_size) or -1
+    int ksub;                  // token-major kernel: waves per head group = partial rows per grid split (1, 2, 4)
     float* o_partial;          // [n_splits, B, Hq, T_q, D] fp32 (n_splits > 1)
     float* lse_partial;        // [n_splits, B, Hq, T_q]
 };
@@ -702,15 +703,25 @@ __global__ void __launch_bounds__(GEMV_THREADS) fa_decode_gemv_fp8_kernel(const 
 // pieces at 4 KiB stride stream at 6.1 TB/s even without any arithmetic; token-major streams at 7.1-7.2 TB/s.  Every
 // 8-lane group owns a head (no merge inside the workgroup); the key range is always split (grid = batch x splits).
 // ---------------------------------------------------------------------------------------------
-constexpr int GEMVT_KEYS = 4;                  // keys per wave step (x K and V loads)
-
-// (16-bit caches: 16 lanes per head, a wave instruction = one token x 4 heads; the kernel is the same)
+// GQA: the lane group of a kv-head keeps G query rows (their q chunks, running (m, l) and output columns): the cache
+// row is converted once and used G times.  Few kv-heads (fewer head groups than waves): the waves that share a head
+// group take contiguous sub-ranges of the split's keys and write their own partial rows (KSUB per split), so the
+// combine kernel sees n_splits x KSUB partials.
+__host__ __device__ inline int gemv_tm_hpw(const fa_params& p) { return p.kv_dtype == FA_FP8_E4M3 ? 8 : 4; }
+__host__ __device__ inline int gemv_tm_ksub(const fa_params& p) {
+    const int n_hg = p.nheads_k / gemv_tm_hpw(p);
+    return n_hg >= 4 || n_hg == 3 ? 1 : (n_hg == 2 ? 2 : 4);
+}
 __host__ __device__ inline bool gemv_tm_applicable(const fa_params& p) {
     const bool kv8 = p.kv_dtype == FA_FP8_E4M3;
     if (!kv8 && p.kv_dtype != p.dtype) return false;
-    return p.head_dim == 128 && p.head_dim_v == 0 && p.seqlen_q == 1 && p.nheads_q == p.nheads_k &&
-           p.nheads_k % (kv8 ? 32 : 16) == 0 && p.k_head_stride == 128 && p.v_head_stride == 128 &&
-           !p.alibi_slopes && p.softcap <= 0.f;
+    if (p.head_dim != 128 || p.head_dim_v != 0 || p.seqlen_q != 1 || p.alibi_slopes || p.softcap > 0.f) return false;
+    if (p.nheads_k < 1 || p.nheads_q % p.nheads_k) return false;
+    const int G = p.nheads_q / p.nheads_k;
+    // (16-bit caches with a GQA group: the kernel works - tested up to G = 8 - but the MFMA decode kernel is faster there:
+    //  5.4 vs 5.2 TB/s at H 32/8; with fp8 the VALU kernel wins up to G = 4: 4.0 vs 3.7 TB/s)
+    if (!(G == 1 || (kv8 && (G == 2 || G == 4)))) return false;
+    return p.nheads_k % gemv_tm_hpw(p) == 0 && p.k_head_stride == 128 && p.v_head_stride == 128;
 }
 
 __device__ __forceinline__ float grp16_sum(float x) {
@@ -719,19 +730,25 @@ __device__ __forceinline__ float grp16_sum(float x) {
     return x;
 }
 
-template <typename T, bool PAGED, bool KV8>
+template <typename T, bool PAGED, bool KV8, int G>
 __global__ void __launch_bounds__(GEMV_THREADS) fa_decode_gemv_tm_kernel(const DecArgs da) {
     using E = Elem<T>;
     constexpr int D = 128;
     constexpr int LPH = KV8 ? 8 : 16;          // lanes per head (16 bytes of the head's row each)
-    constexpr int HPW = 64 / LPH;              // heads per wave instruction
+    constexpr int HPW = 64 / LPH;              // kv-heads per wave instruction
     constexpr int CPL = KV8 ? 16 : 8;          // head-dim columns per lane
     constexpr int ES = KV8 ? 1 : 2;            // bytes per cache element
+    constexpr int KPS = (G * CPL >= 64) ? 2 : 4;   // keys per wave step (x K and V loads): register budget
     const KArgs& a = da.a;
     const fa_params& p = a.p;
-    const int b = blockIdx.x, split = blockIdx.y;
+    const int b = blockIdx.x, split = blockIdx.y, n_grid_splits = gridDim.y;
     const int tid = threadIdx.x, lane = tid & 63, grp = lane / LPH, sub = lane % LPH;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n_hg = p.nheads_k / HPW;
+    const int ksub_n = da.ksub;                                   // waves per head group (1, 2 or 4)
+    const int hg0 = ksub_n == 1 ? wave : wave % n_hg;
+    const int ksub = ksub_n == 1 ? 0 : wave / n_hg;
+    const int hg_step = ksub_n == 1 ? 4 : n_hg;                   // (with sub-ranges every head group has its waves: one round)
 
     const int L = p.cache_seqlens ? p.cache_seqlens[b] : 0;
     const int lp = p.cache_leftpad ? p.cache_leftpad[b] : 0;
@@ -743,11 +760,13 @@ __global__ void __launch_bounds__(GEMV_THREADS) fa_decode_gemv_tm_kernel(const D
     int lo = 0, hi = seqlen_k - 1;
     if (wr >= 0) { const int h2 = off + wr; hi = h2 < hi ? h2 : hi; }
     if (wl >= 0) { const int l2 = off - wl; lo = l2 > lo ? l2 : lo; }
-    // key range of this split, in whole steps
+    // key range of this (split, sub-range), in whole steps
     const int n_keys = hi >= lo ? hi - lo + 1 : 0;
-    const int per_split = (((n_keys + da.n_splits - 1) / da.n_splits) + GEMVT_KEYS - 1) / GEMVT_KEYS * GEMVT_KEYS;
-    const int k_lo = lo + split * per_split;
-    int k_hi = k_lo + per_split; k_hi = k_hi < hi + 1 ? k_hi : hi + 1;              // exclusive
+    const int n_parts = n_grid_splits * ksub_n;
+    const int per_part = (((n_keys + n_parts - 1) / n_parts) + KPS - 1) / KPS * KPS;
+    const int part = split * ksub_n + ksub;
+    const int k_lo = lo + part * per_part;
+    int k_hi = k_lo + per_part; k_hi = k_hi < hi + 1 ? k_hi : hi + 1;              // exclusive
 
     const int32_t* btab = PAGED ? p.block_table + (int64_t)b * p.block_table_batch_stride : nullptr;
     const int half = p.rotary_dim >> 1;
@@ -756,12 +775,13 @@ __global__ void __launch_bounds__(GEMV_THREADS) fa_decode_gemv_tm_kernel(const D
     const uint16_t* sinp = reinterpret_cast<const uint16_t*>(p.rotary_sin) + (int64_t)pos_q * half;
     const float c = a.scale_log2e * p.k_descale;
 
-    for (int hg = wave; hg < p.nheads_k / HPW; hg += 4) {
-        const int h = HPW * hg + grp;
-        // ---- q of the lane's head: CPL columns, RoPE, x scale ----
-        float qs[CPL];
-        {
-            const uint16_t* qrow = reinterpret_cast<const uint16_t*>(p.q) + (int64_t)b * p.q_batch_stride + (int64_t)h * p.q_head_stride;
+    for (int hg = hg0; hg < n_hg; hg += hg_step) {
+        const int h = HPW * hg + grp;                             // kv-head of this lane group
+        // ---- q rows of the head's group: CPL columns each, RoPE, x scale ----
+        float qs[G][CPL];
+#pragma unroll
+        for (int gi = 0; gi < G; ++gi) {
+            const uint16_t* qrow = reinterpret_cast<const uint16_t*>(p.q) + (int64_t)b * p.q_batch_stride + (int64_t)(h * G + gi) * p.q_head_stride;
 #pragma unroll
             for (int cpart = 0; cpart < CPL / 8; ++cpart) {
                 const int d_base = CPL * sub + 8 * cpart;
@@ -775,85 +795,93 @@ __global__ void __launch_bounds__(GEMV_THREADS) fa_decode_gemv_tm_kernel(const D
                     rope_chunk<T>(x, xp, cosp, sinp, d_base, p.rotary_dim, p.rotary_interleaved != 0);
                 }
 #pragma unroll
-                for (int i = 0; i < 4; ++i) { qs[8 * cpart + 2 * i] = E::lo(x[i]) * c; qs[8 * cpart + 2 * i + 1] = E::hi(x[i]) * c; }
+                for (int i = 0; i < 4; ++i) { qs[gi][8 * cpart + 2 * i] = E::lo(x[i]) * c; qs[gi][8 * cpart + 2 * i + 1] = E::hi(x[i]) * c; }
             }
         }
         const uint32_t lane_off = (uint32_t)h * (128u * ES) + 16u * (uint32_t)sub;   // bytes inside a cache row
         const uint8_t* kbase = reinterpret_cast<const uint8_t*>(p.k) + lane_off;
         const uint8_t* vbase = reinterpret_cast<const uint8_t*>(p.v) + lane_off;
 
-        float o[CPL];
+        float o[G][CPL];
+        float m_run[G], l_run[G];
 #pragma unroll
-        for (int i = 0; i < CPL; ++i) o[i] = 0.f;
-        float m_run = -INFINITY, l_run = 0.f;
+        for (int gi = 0; gi < G; ++gi) {
+            m_run[gi] = -INFINITY; l_run[gi] = 0.f;
+#pragma unroll
+            for (int i = 0; i < CPL; ++i) o[gi][i] = 0.f;
+        }
 
         // A page (or the whole dense cache) is a SEGMENT of consecutive rows: its base is looked up once (the lookup
         // needs a full wait on the memory queue - done per key it serialised every load, 4.7 TB/s), the loads inside a
-        // segment are address arithmetic on the scalar unit and stay two steps deep in flight.
+        // segment are address arithmetic on the scalar unit and stay a step deep in flight.
         const uint8_t* kseg = nullptr;
         const uint8_t* vseg = nullptr;
-        int seg_n = 0;                                             // rows left in the current segment
-        auto load_step = [&](int t0, u32x4 (&kx)[GEMVT_KEYS], u32x4 (&vx)[GEMVT_KEYS]) {
+        int seg_n = 0;                                             // rows in the current segment
+        auto load_step = [&](int t0, u32x4 (&kx)[KPS], u32x4 (&vx)[KPS]) {
 #pragma unroll
-            for (int i = 0; i < GEMVT_KEYS; ++i) {
+            for (int i = 0; i < KPS; ++i) {
                 int t = t0 + i;
                 t = t < seg_n ? t : seg_n - 1;                     // tail of the segment: reload its last row (masked below)
                 kx[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(kseg + (int64_t)t * p.k_row_stride * ES));
                 vx[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(vseg + (int64_t)t * p.v_row_stride * ES));
             }
         };
-        auto dot16 = [&](const u32x4& w) {
-            float acc = 0.f;
+        auto unpack = [&](const u32x4& w, float (&f)[CPL]) {       // one cache chunk -> fp32, once for all G rows
 #pragma unroll
             for (int d4 = 0; d4 < 4; ++d4) {
                 if constexpr (KV8) {
                     const f32x2 a0 = __builtin_amdgcn_cvt_pk_f32_fp8(w[d4], false);
                     const f32x2 a1 = __builtin_amdgcn_cvt_pk_f32_fp8(w[d4], true);
-                    acc = fmaf(a0[0], qs[4 * d4 + 0], acc); acc = fmaf(a0[1], qs[4 * d4 + 1], acc);
-                    acc = fmaf(a1[0], qs[4 * d4 + 2], acc); acc = fmaf(a1[1], qs[4 * d4 + 3], acc);
+                    f[4 * d4 + 0] = a0[0]; f[4 * d4 + 1] = a0[1]; f[4 * d4 + 2] = a1[0]; f[4 * d4 + 3] = a1[1];
                 } else {
-                    acc = fmaf(E::lo(w[d4]), qs[2 * d4 + 0], acc); acc = fmaf(E::hi(w[d4]), qs[2 * d4 + 1], acc);
+                    f[2 * d4 + 0] = E::lo(w[d4]); f[2 * d4 + 1] = E::hi(w[d4]);
                 }
             }
-            return acc;
         };
-        auto compute_step = [&](int j0, const u32x4 (&kx)[GEMVT_KEYS], const u32x4 (&vx)[GEMVT_KEYS]) {
-            float sv[GEMVT_KEYS];
-            float mx = m_run;
+        auto compute_step = [&](int j0, const u32x4 (&kx)[KPS], const u32x4 (&vx)[KPS]) {
+            float sv[G][KPS];
 #pragma unroll
-            for (int i = 0; i < GEMVT_KEYS; ++i) {
-                const float sd = KV8 ? grp8_sum(dot16(kx[i])) : grp16_sum(dot16(kx[i]));
-                sv[i] = (j0 + i < seg_n) ? sd : -INFINITY;
-                mx = fmaxf(mx, sv[i]);
-            }
-            const float m_use = (mx == -INFINITY) ? 0.f : mx;
-            const float alpha = fast_exp2(m_run - m_use);
-            m_run = mx;
-            float pw[GEMVT_KEYS], ps = 0.f;
+            for (int i = 0; i < KPS; ++i) {
+                float kf[CPL];
+                unpack(kx[i], kf);
 #pragma unroll
-            for (int i = 0; i < GEMVT_KEYS; ++i) { pw[i] = fast_exp2(sv[i] - m_use); ps += pw[i]; }
-            l_run = fmaf(l_run, alpha, ps);
+                for (int gi = 0; gi < G; ++gi) {
+                    float acc = 0.f;
 #pragma unroll
-            for (int x = 0; x < CPL; ++x) o[x] *= alpha;
-#pragma unroll
-            for (int i = 0; i < GEMVT_KEYS; ++i) {
-#pragma unroll
-                for (int d4 = 0; d4 < 4; ++d4) {
-                    if constexpr (KV8) {
-                        const f32x2 a0 = __builtin_amdgcn_cvt_pk_f32_fp8(vx[i][d4], false);
-                        const f32x2 a1 = __builtin_amdgcn_cvt_pk_f32_fp8(vx[i][d4], true);
-                        o[4 * d4 + 0] = fmaf(pw[i], a0[0], o[4 * d4 + 0]); o[4 * d4 + 1] = fmaf(pw[i], a0[1], o[4 * d4 + 1]);
-                        o[4 * d4 + 2] = fmaf(pw[i], a1[0], o[4 * d4 + 2]); o[4 * d4 + 3] = fmaf(pw[i], a1[1], o[4 * d4 + 3]);
-                    } else {
-                        o[2 * d4 + 0] = fmaf(pw[i], E::lo(vx[i][d4]), o[2 * d4 + 0]);
-                        o[2 * d4 + 1] = fmaf(pw[i], E::hi(vx[i][d4]), o[2 * d4 + 1]);
-                    }
+                    for (int x = 0; x < CPL; ++x) acc = fmaf(kf[x], qs[gi][x], acc);
+                    const float sd = KV8 ? grp8_sum(acc) : grp16_sum(acc);
+                    sv[gi][i] = (j0 + i < seg_n) ? sd : -INFINITY;
                 }
+            }
+            float pw[G][KPS];
+#pragma unroll
+            for (int gi = 0; gi < G; ++gi) {
+                float mx = m_run[gi];
+#pragma unroll
+                for (int i = 0; i < KPS; ++i) mx = fmaxf(mx, sv[gi][i]);
+                const float m_use = (mx == -INFINITY) ? 0.f : mx;
+                const float alpha = fast_exp2(m_run[gi] - m_use);
+                m_run[gi] = mx;
+                float ps = 0.f;
+#pragma unroll
+                for (int i = 0; i < KPS; ++i) { pw[gi][i] = fast_exp2(sv[gi][i] - m_use); ps += pw[gi][i]; }
+                l_run[gi] = fmaf(l_run[gi], alpha, ps);
+#pragma unroll
+                for (int x = 0; x < CPL; ++x) o[gi][x] *= alpha;
+            }
+#pragma unroll
+            for (int i = 0; i < KPS; ++i) {
+                float vf[CPL];
+                unpack(vx[i], vf);
+#pragma unroll
+                for (int gi = 0; gi < G; ++gi)
+#pragma unroll
+                    for (int x = 0; x < CPL; ++x) o[gi][x] = fmaf(pw[gi][i], vf[x], o[gi][x]);
             }
         };
 
         // two register sets: the loads of the next step are in flight while a step is consumed
-        u32x4 kA[GEMVT_KEYS], vA[GEMVT_KEYS], kB[GEMVT_KEYS], vB[GEMVT_KEYS];
+        u32x4 kA[KPS], vA[KPS], kB[KPS], vB[KPS];
         int j = k_lo;
         while (j < k_hi) {
             const int pos = lp + j;
@@ -874,39 +902,43 @@ __global__ void __launch_bounds__(GEMV_THREADS) fa_decode_gemv_tm_kernel(const D
             kseg = kbase + ko;
             vseg = vbase + vo;
             load_step(0, kA, vA);
-            for (int t = 0; t < seg_n; t += 2 * GEMVT_KEYS) {
-                if (t + GEMVT_KEYS < seg_n) load_step(t + GEMVT_KEYS, kB, vB);
+            for (int t = 0; t < seg_n; t += 2 * KPS) {
+                if (t + KPS < seg_n) load_step(t + KPS, kB, vB);
                 compute_step(t, kA, vA);
-                if (t + GEMVT_KEYS < seg_n) {
-                    if (t + 2 * GEMVT_KEYS < seg_n) load_step(t + 2 * GEMVT_KEYS, kA, vA);
-                    compute_step(t + GEMVT_KEYS, kB, vB);
+                if (t + KPS < seg_n) {
+                    if (t + 2 * KPS < seg_n) load_step(t + 2 * KPS, kA, vA);
+                    compute_step(t + KPS, kB, vB);
                 }
             }
             j += seg_n;
         }
 
-        // ---- this group's head: normalised partial (or final) output ----
-        const float inv = l_run > 0.f ? p.v_descale / l_run : 0.f;
-        const float lse = l_run > 0.f ? (m_run + fast_log2(l_run)) * kLn2 : -INFINITY;
-        if (da.n_splits == 1) {
-            uint16_t* op = reinterpret_cast<uint16_t*>(p.o) + (int64_t)b * p.o_batch_stride + (int64_t)h * p.o_head_stride + CPL * sub;
+        // ---- the lane group's q-heads: normalised partial (or final) output ----
 #pragma unroll
-            for (int c8 = 0; c8 < CPL / 8; ++c8) {
-                u32x4 w0;
+        for (int gi = 0; gi < G; ++gi) {
+            const int hq = h * G + gi;
+            const float inv = l_run[gi] > 0.f ? p.v_descale / l_run[gi] : 0.f;
+            const float lse = l_run[gi] > 0.f ? (m_run[gi] + fast_log2(l_run[gi])) * kLn2 : -INFINITY;
+            if (da.n_splits == 1) {
+                uint16_t* op = reinterpret_cast<uint16_t*>(p.o) + (int64_t)b * p.o_batch_stride + (int64_t)hq * p.o_head_stride + CPL * sub;
 #pragma unroll
-                for (int x = 0; x < 4; ++x) w0[x] = E::pack2(o[8 * c8 + 2 * x] * inv, o[8 * c8 + 2 * x + 1] * inv);
-                *reinterpret_cast<u32x4*>(op + 8 * c8) = w0;
+                for (int c8 = 0; c8 < CPL / 8; ++c8) {
+                    u32x4 w0;
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) w0[x] = E::pack2(o[gi][8 * c8 + 2 * x] * inv, o[gi][8 * c8 + 2 * x + 1] * inv);
+                    *reinterpret_cast<u32x4*>(op + 8 * c8) = w0;
+                }
+                if (sub == 0) p.lse[(int64_t)b * p.lse_batch_stride + (int64_t)hq * p.lse_head_stride] = lse;
+            } else {
+                const int64_t prow = ((int64_t)part * p.batch + b) * p.nheads_q + hq;
+                float* dst = da.o_partial + prow * D + CPL * sub;
+#pragma unroll
+                for (int x = 0; x < CPL; x += 4) {
+                    f32x4 w = {o[gi][x] * inv, o[gi][x + 1] * inv, o[gi][x + 2] * inv, o[gi][x + 3] * inv};
+                    *reinterpret_cast<f32x4*>(dst + x) = w;
+                }
+                if (sub == 0) da.lse_partial[prow] = lse;
             }
-            if (sub == 0) p.lse[(int64_t)b * p.lse_batch_stride + (int64_t)h * p.lse_head_stride] = lse;
-        } else {
-            const int64_t prow = ((int64_t)split * p.batch + b) * p.nheads_q + h;
-            float* dst = da.o_partial + prow * D + CPL * sub;
-#pragma unroll
-            for (int x = 0; x < CPL; x += 4) {
-                f32x4 w = {o[x] * inv, o[x + 1] * inv, o[x + 2] * inv, o[x + 3] * inv};
-                *reinterpret_cast<f32x4*>(dst + x) = w;
-            }
-            if (sub == 0) da.lse_partial[prow] = lse;
         }
     }
 }
@@ -966,8 +998,13 @@ int decode_num_splits(const fa_params& p) {
     return s;
 }
 
+// partial (O, LSE) rows per (batch, head): grid splits x the token-major kernel's key sub-ranges
+static int decode_num_partials(const fa_params& p) {
+    return decode_num_splits(p) * (gemv_tm_applicable(p) ? gemv_tm_ksub(p) : 1);
+}
+
 size_t decode_split_workspace_bytes(const fa_params& p) {
-    const int s = decode_num_splits(p);
+    const int s = decode_num_partials(p);
     if (s <= 1) return 0;
     const size_t rows = (size_t)p.batch * p.nheads_q * p.seqlen_q;
     return (size_t)s * rows * (p.head_dim + 1) * sizeof(float);
@@ -981,28 +1018,27 @@ static int launch_decode_td(DecArgs& da, hipStream_t stream) {
     dim3 grid(p.batch * p.nheads_k, da.n_splits);
     const size_t smem = DecSmem<D>::TOTAL;
     if constexpr (D == 128) {
-        // one query row per kv-head and an fp8 cache: the streaming matrix-vector kernel
-        if (kv8 && da.rows == 1 && da.group == 1) {
-            if (gemv_tm_applicable(p)) {
-                dim3 grid_tm(p.batch, da.n_splits);
-                if (paged) hipLaunchKernelGGL((fa_decode_gemv_tm_kernel<T, true, true>), grid_tm, dim3(GEMV_THREADS), 0, stream, da);
-                else       hipLaunchKernelGGL((fa_decode_gemv_tm_kernel<T, false, true>), grid_tm, dim3(GEMV_THREADS), 0, stream, da);
-            }
-            else if (paged) hipLaunchKernelGGL((fa_decode_gemv_fp8_kernel<T, true>), grid, dim3(GEMV_THREADS), 0, stream, da);
-            else       hipLaunchKernelGGL((fa_decode_gemv_fp8_kernel<T, false>), grid, dim3(GEMV_THREADS), 0, stream, da);
+        // one query position, heads adjacent in the cache rows: the token-major streaming kernel (fp8 and 16-bit caches, GQA)
+        if (gemv_tm_applicable(p)) {
+            dim3 grid_tm(p.batch, da.n_splits / da.ksub);
+#define FA_LAUNCH_TM(KV8_, G_)                                                                                      \
+            do {                                                                                                    \
+                if (paged) hipLaunchKernelGGL((fa_decode_gemv_tm_kernel<T, true, KV8_, G_>), grid_tm, dim3(GEMV_THREADS), 0, stream, da);  \
+                else       hipLaunchKernelGGL((fa_decode_gemv_tm_kernel<T, false, KV8_, G_>), grid_tm, dim3(GEMV_THREADS), 0, stream, da); \
+            } while (0)
+            if (kv8) { if (da.group == 1) FA_LAUNCH_TM(true, 1); else if (da.group == 2) FA_LAUNCH_TM(true, 2); else FA_LAUNCH_TM(true, 4); }
+            else FA_LAUNCH_TM(false, 1);
+#undef FA_LAUNCH_TM
             if (da.n_splits > 1) {
                 const int64_t total = (int64_t)p.batch * p.nheads_q * p.seqlen_q * (D / 8);
                 hipLaunchKernelGGL(decode_combine_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, da);
             }
             return 0;
         }
-    }
-    if constexpr (D == 128) {
-        // 16-bit cache, one query row per kv-head: the same token-major streaming kernel (16 lanes per head)
-        if (!kv8 && da.rows == 1 && da.group == 1 && gemv_tm_applicable(p)) {
-            dim3 grid_tm(p.batch, da.n_splits);
-            if (paged) hipLaunchKernelGGL((fa_decode_gemv_tm_kernel<T, true, false>), grid_tm, dim3(GEMV_THREADS), 0, stream, da);
-            else       hipLaunchKernelGGL((fa_decode_gemv_tm_kernel<T, false, false>), grid_tm, dim3(GEMV_THREADS), 0, stream, da);
+        // fp8 cache, one query row per kv-head, a head layout the token-major kernel does not take: one workgroup per head
+        if (kv8 && da.rows == 1 && da.group == 1) {
+            if (paged) hipLaunchKernelGGL((fa_decode_gemv_fp8_kernel<T, true>), grid, dim3(GEMV_THREADS), 0, stream, da);
+            else       hipLaunchKernelGGL((fa_decode_gemv_fp8_kernel<T, false>), grid, dim3(GEMV_THREADS), 0, stream, da);
             if (da.n_splits > 1) {
                 const int64_t total = (int64_t)p.batch * p.nheads_q * p.seqlen_q * (D / 8);
                 hipLaunchKernelGGL(decode_combine_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, da);
@@ -1034,7 +1070,8 @@ int launch_decode_splitkv(const KArgs& a, void* ws, hipStream_t stream) {
     da.group = p.nheads_q / p.nheads_k;
     da.rows = p.seqlen_q * da.group;
     da.local = (p.is_causal || p.window_left >= 0 || p.window_right >= 0) ? 1 : 0;
-    da.n_splits = decode_num_splits(p);
+    da.n_splits = decode_num_partials(p);             // (token-major kernel: grid splits x key sub-ranges; else the grid's y)
+    da.ksub = gemv_tm_applicable(p) ? gemv_tm_ksub(p) : 1;
     da.page_shift = -1;
     if (p.block_table && (p.page_block_size & (p.page_block_size - 1)) == 0) {
         int sft = 0; while ((1 << sft) < p.page_block_size) ++sft;

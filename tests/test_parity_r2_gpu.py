@@ -445,15 +445,16 @@ def test_context_parallel_two_shards_on_one_gpu(causal):
 
 
 # ------------------------------------------------------------------------------------------------ fp8 matrix-vector decode
-@pytest.mark.parametrize("H", [4, 32, 64])
+@pytest.mark.parametrize("H,Hk", [(4, 4), (32, 32), (64, 64), (32, 8), (16, 8), (64, 16)])
 @pytest.mark.parametrize("paged,window,interleaved,use_lp,splits", [
     (True, (-1, -1), False, False, 0), (False, (-1, -1), True, True, 0), (True, (300, -1), False, False, 4),
     (False, (-1, -1), False, False, 3), (True, (-1, -1), True, True, 1)])
-def test_decode_fp8_gemv_kernel(paged, window, interleaved, use_lp, splits, H):
-    """The streaming matrix-vector decode kernels (one query row per kv-head, fp8 cache: BASELINE config 4) vs the oracle:
-    H = 4 takes the head-major kernel (fa_decode_gemv_fp8_kernel), H = 32 / 64 the token-major one
-    (fa_decode_gemv_fp8_tm_kernel: one or two rounds of eight heads per wave); paged / dense caches, cache_batch_idx,
-    left pad, windows, both RoPE styles, split-KV (heuristic, explicit, none), ragged cache lengths incl. length 1."""
+def test_decode_fp8_gemv_kernel(paged, window, interleaved, use_lp, splits, H, Hk):
+    """The streaming matrix-vector decode kernels (one query position, fp8 cache: BASELINE config 4) vs the oracle:
+    4 heads take the head-major kernel (fa_decode_gemv_fp8_kernel), 8 or more kv-heads the token-major one
+    (fa_decode_gemv_tm_kernel: eight kv-heads per wave instruction; GQA groups of 2 and 4; with 8 or 16 kv-heads the
+    waves share head groups and split the keys); paged / dense caches, cache_batch_idx, left pad, windows, both RoPE
+    styles, split-KV (heuristic, explicit, none), ragged cache lengths incl. length 1."""
     fa = _fa()
     dt = "bf16"
     B, D, page = 5, 128, 256
@@ -463,16 +464,16 @@ def test_decode_fp8_gemv_kernel(paged, window, interleaved, use_lp, splits, H):
     seqlens = torch.tensor([Smax - 30, 1, 255, 256, 700], dtype=torch.int32)
     lp = torch.tensor([0, 5, 17, 3, 0], dtype=torch.int32) if use_lp else None
     q = rand16((B, 1, H, D), dt, 1)
-    knew = rand16((B, 1, H, D), dt, 4); vnew = rand16((B, 1, H, D), dt, 5)
+    knew = rand16((B, 1, Hk, D), dt, 4); vnew = rand16((B, 1, Hk, D), dt, 5)
     if paged:
         pps = (Smax + page - 1) // page
         nblk = B * pps
-        kc16 = rand16((nblk, page, H, D), dt, 2, scale=1.5); vc16 = rand16((nblk, page, H, D), dt, 3, scale=1.5)
+        kc16 = rand16((nblk, page, Hk, D), dt, 2, scale=1.5); vc16 = rand16((nblk, page, Hk, D), dt, 3, scale=1.5)
         bt = torch.randperm(nblk, generator=g).reshape(B, pps).to(torch.int32)
         bidx = None
         cap = pps * page
     else:
-        kc16 = rand16((B + 2, Smax, H, D), dt, 2, scale=1.5); vc16 = rand16((B + 2, Smax, H, D), dt, 3, scale=1.5)
+        kc16 = rand16((B + 2, Smax, Hk, D), dt, 2, scale=1.5); vc16 = rand16((B + 2, Smax, Hk, D), dt, 3, scale=1.5)
         bt = None
         bidx = torch.tensor([6, 0, 3, 1, 5], dtype=torch.int32)
         cap = Smax
@@ -497,12 +498,15 @@ def test_decode_fp8_gemv_kernel(paged, window, interleaved, use_lp, splits, H):
 
 
 @pytest.mark.parametrize("dt", ["fp16", "bf16"])
-@pytest.mark.parametrize("H,paged,window,interleaved,use_lp,splits", [
-    (16, True, (-1, -1), False, False, 0), (32, False, (-1, -1), True, True, 0), (16, True, (300, -1), False, True, 3),
-    (48, False, (-1, -1), False, False, 1), (32, True, (-1, -1), True, False, 5)])
-def test_decode_token_major_16bit_cache(H, paged, window, interleaved, use_lp, splits, dt):
-    """fa_decode_gemv_tm_kernel on 16-bit caches (one query row per kv-head, heads a multiple of 16: 16 lanes per head,
-    a wave instruction = one token x 4 heads) vs the oracle; same coverage as the fp8 cases."""
+@pytest.mark.parametrize("H,Hk,paged,window,interleaved,use_lp,splits", [
+    (16, 16, True, (-1, -1), False, False, 0), (32, 32, False, (-1, -1), True, True, 0), (16, 16, True, (300, -1), False, True, 3),
+    (48, 48, False, (-1, -1), False, False, 1), (32, 32, True, (-1, -1), True, False, 5),
+    (32, 8, True, (-1, -1), False, True, 0), (32, 4, False, (-1, -1), True, False, 2), (8, 4, True, (200, -1), False, False, 1),
+    (12, 12, False, (-1, -1), False, False, 0), (16, 8, True, (-1, -1), True, True, 3)])
+def test_decode_token_major_16bit_cache(H, Hk, paged, window, interleaved, use_lp, splits, dt):
+    """fa_decode_gemv_tm_kernel on 16-bit caches (one query row per kv-head; 16 lanes per head, a wave instruction = one
+    token x 4 heads; 12 heads: three head groups, one wave idle) vs the oracle; same coverage as the fp8 cases.  The GQA
+    shapes in the list take fa_decode_kernel (faster for 16-bit caches with a group) - same expectations."""
     fa = _fa()
     B, D, page = 5, 128, 256
     Smax = 1100
@@ -510,16 +514,16 @@ def test_decode_token_major_16bit_cache(H, paged, window, interleaved, use_lp, s
     seqlens = torch.tensor([Smax - 30, 1, 255, 256, 700], dtype=torch.int32)
     lp = torch.tensor([0, 5, 17, 3, 0], dtype=torch.int32) if use_lp else None
     q = rand16((B, 1, H, D), dt, 1)
-    knew = rand16((B, 1, H, D), dt, 4); vnew = rand16((B, 1, H, D), dt, 5)
+    knew = rand16((B, 1, Hk, D), dt, 4); vnew = rand16((B, 1, Hk, D), dt, 5)
     if paged:
         pps = (Smax + page - 1) // page
         nblk = B * pps
-        kc = rand16((nblk, page, H, D), dt, 2); vc = rand16((nblk, page, H, D), dt, 3)
+        kc = rand16((nblk, page, Hk, D), dt, 2); vc = rand16((nblk, page, Hk, D), dt, 3)
         bt = torch.randperm(nblk, generator=g).reshape(B, pps).to(torch.int32)
         bidx = None
         cap = pps * page
     else:
-        kc = rand16((B + 2, Smax, H, D), dt, 2); vc = rand16((B + 2, Smax, H, D), dt, 3)
+        kc = rand16((B + 2, Smax, Hk, D), dt, 2); vc = rand16((B + 2, Smax, Hk, D), dt, 3)
         bt = None
         bidx = torch.tensor([6, 0, 3, 1, 5], dtype=torch.int32)
         cap = Smax
