@@ -210,6 +210,36 @@ def test_warp_specialised_forward_vs_oracle():
     assert r.returncode == 0 and "WS-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+# ------------------------------------------------------------------------------------------------ asm forward, packed sequences
+@pytest.mark.parametrize("lens_q,lens_k,H,Hk,causal,window,alibi,dt,use_su", [
+    ([1000, 257, 64, 2048, 513], None, 4, 2, True, (-1, -1), False, "bf16", False),
+    ([700, 1, 300, 1500], [900, 40, 300, 1100], 2, 2, True, (-1, -1), False, "fp16", False),      # seqlen_q != seqlen_k per sequence
+    ([512, 768, 1024], None, 4, 4, False, (-1, -1), False, "bf16", True),                         # seqused_k
+    ([300, 2000, 999], None, 2, 1, False, (200, 100), False, "fp16", False),                      # two-sided window
+    ([1500, 260, 1100], None, 4, 2, True, (-1, -1), True, "bf16", False),                         # causal ALiBi variant
+])
+def test_asm_forward_varlen_vs_oracle(lens_q, lens_k, H, Hk, causal, window, alibi, dt, use_su):
+    """flash_attn_varlen_func at D = 128 with an average length >= 256 runs the hand-scheduled forward over the flat list
+    of 256-row blocks (per-sequence row offsets, lengths and bottom-right alignment); LSE layout [H, T_q]."""
+    lens_k = lens_k or lens_q
+    cu_q = torch.tensor(np.concatenate([[0], np.cumsum(lens_q)]), dtype=torch.int32, device="cuda")
+    cu_k = torch.tensor(np.concatenate([[0], np.cumsum(lens_k)]), dtype=torch.int32, device="cuda")
+    q = rand16((sum(lens_q), H, 128), dt, 451); k = rand16((sum(lens_k), Hk, 128), dt, 452); v = rand16((sum(lens_k), Hk, 128), dt, 453)
+    sl = (2.0 ** (-8.0 * (np.arange(H) + 1) / H)) if alibi else None
+    su = np.array([max(1, n - 37 * (i + 1)) for i, n in enumerate(lens_k)]) if use_su else None
+    kw = {}
+    if alibi:
+        kw["alibi_slopes"] = torch.tensor(sl, dtype=torch.float32, device="cuda")
+    if use_su:
+        kw["seqused_k"] = torch.tensor(su, dtype=torch.int32, device="cuda")
+    out, lse, _ = _fa().flash_attn_varlen_func(q, k, v, cu_q, cu_k, max(lens_q), max(lens_k), causal=causal, window_size=window,
+                                               return_attn_probs=True, **kw)
+    o_ref, lse_ref = oracle.varlen_fwd(f64(q), f64(k), f64(v), cu_q.cpu().numpy(), cu_k.cpu().numpy(), max(lens_q), max(lens_k),
+                                       128 ** -0.5, causal=causal, window=window, alibi_slopes=sl, seqused_k=su)
+    assert_close(f64(out), o_ref, dt, "out", mult=1.5)
+    assert_lse_close(f64(lse), lse_ref, "lse", atol=1e-4)
+
+
 # ------------------------------------------------------------------------------------------------ varlen op extras
 def test_varlen_seqused_k_zero_tensors_and_out():
     import flash_attn_mi355.torch_ops  # noqa: F401  (registers torch.ops.flash_attn_mi355.*)
