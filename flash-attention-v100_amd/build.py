@@ -14,8 +14,9 @@ CSRC = os.path.join(HERE, "csrc")
 OUT_DIR = os.path.join(HERE, "flash_attn_mi355")
 LIB = os.path.join(OUT_DIR, "libfa_mi355.so")
 SOURCES = ["fa_api.hip", "fa_fwd.hip", "fa_fwd_asm.hip", "fa_fwd_ws.hip", "fa_bwd.hip", "fa_bwd_asm.hip", "fa_kvcache.hip", "fa_decode.hip", "fa_rows.hip"]
-GENERATED = [("gen_fwd_asm.py", "fa_fwd_asm_gen.h"), ("gen_fwd_ws.py", "fa_fwd_ws_gen.h"),
-             ("gen_bwd_dkdv_asm.py", "fa_bwd_asm_gen.h")]      # (generator, header): hand-scheduled asm bodies
+GENERATED = [("gen_fwd_asm.py", "fa_fwd_asm_gen.h", []), ("gen_fwd_asm.py", "fa_fwd64_asm_gen.h", ["--d=64"]),
+             ("gen_fwd_ws.py", "fa_fwd_ws_gen.h", []),
+             ("gen_bwd_dkdv_asm.py", "fa_bwd_asm_gen.h", [])]  # (generator, header, arguments): hand-scheduled asm bodies
 ASM_SOURCES = ("fa_fwd_asm.hip", "fa_fwd_ws.hip", "fa_bwd_asm.hip")   # kernels whose body is one hand-scheduled asm statement
 RESOURCES = os.path.join(OUT_DIR, "kernel_resources.json")              # their register / scratch use, checked at build time
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"),
@@ -40,10 +41,10 @@ def _digest(paths):
 
 def _generate():
     """Re-run a kernel-body generator when its header is missing or older than the script."""
-    for gen, hdr in GENERATED:
+    for gen, hdr, gargs in GENERATED:
         g, h = os.path.join(CSRC, gen), os.path.join(CSRC, hdr)
         if not os.path.exists(h) or os.path.getmtime(h) < os.path.getmtime(g):
-            txt = subprocess.run([sys.executable, g], check=True, stdout=subprocess.PIPE, cwd=CSRC).stdout
+            txt = subprocess.run([sys.executable, g] + gargs, check=True, stdout=subprocess.PIPE, cwd=CSRC).stdout
             with open(h, "wb") as f:
                 f.write(txt)
 

@@ -84,8 +84,33 @@ S_VJ = 78                # s78..s80
 S_LAST = 80
 S_RC, S_FASTLO, S_FASTEND = 81, 82, 83     # in: 1 / c; fast-loop iteration range [lo, end)
 
-LDS_STAGE = 16384        # one K (or V) tile
+# ----------------------------------------------------------------------------- head dimension (128 or 64)
+HD = 128
+KS = 8                   # 16-column k-steps of S^T = K Q^T
+DB = 4                   # 32-row d-blocks of O^T
+ROWB = 256               # bytes per K / V row
+NP = 4                   # 1-KiB LDS-DMA pieces per wave and tile
+LDS_STAGE = 16384        # one K (or V) tile: 64 keys
 LDS_VREGION = 3 * LDS_STAGE
+VQ = 1024                # bytes of one key-quad in the blocked V image ([key / 4][dblk][4][32])
+EP_PITCH = 272           # epilogue: O row + 16 bytes (bank-conflict-free 8-byte writes)
+EP_ROWS = 4              # rows per 1-KiB store instruction
+
+
+def set_dim(d):
+    """D = 64: half the k-steps and d-blocks, 128-byte rows (8 rows per DMA piece, 2 pieces per wave and tile)."""
+    global HD, KS, DB, ROWB, NP, LDS_STAGE, LDS_VREGION, VQ, A_O, A_Q, EP_PITCH, EP_ROWS
+    assert d in (64, 128)
+    HD, KS, DB, ROWB = d, d // 16, d // 32, 2 * d
+    LDS_STAGE = 64 * ROWB
+    LDS_VREGION = 3 * LDS_STAGE
+    NP = LDS_STAGE // 4096
+    VQ = 4 * ROWB
+    A_O = (0, 16 * DB)
+    A_Q = (128, 128 + 4 * KS)
+    EP_PITCH = ROWB + 16
+    EP_ROWS = 1024 // ROWB
+
 
 
 def vr(b, n=1):
@@ -130,7 +155,7 @@ class Gen:
         self.now = 0
         self.last = {}
         for qb in (0, 1):
-            for r in rl("v", V_S[qb], 32) + rl("a", A_O[qb], 64):
+            for r in rl("v", V_S[qb], 32) + rl("a", A_O[qb], 16 * DB):
                 self.last[r] = (-mfma_age, "mfma", None)
         self.lds_q = []        # outstanding LDS reads: list of sets of written regs, in issue order
         self.srcc_rd = {}      # reg -> state index of the last MFMA reading it as srcC
@@ -251,11 +276,11 @@ class Gen:
     def qk_mfmas(self, qb):
         """S^T[kb] (+)= K[kb][ks] Q_qb[ks]^T, ks-major so that consecutive MFMAs alternate accumulators."""
         out = []
-        for ks in range(8):
+        for ks in range(KS):
             for kb in range(2):
-                m = self.mfma("v", V_S[qb] + 16 * kb, "a", A_KF + (kb * 8 + ks) * 4, "a", A_Q[qb] + 4 * ks, ks == 0)
+                m = self.mfma("v", V_S[qb] + 16 * kb, "a", A_KF + (kb * KS + ks) * 4, "a", A_Q[qb] + 4 * ks, ks == 0)
                 if ks == 0 and self.alibi:      # the chain starts from beta * (key position inside the 32-key block)
-                    d, a, b = V_S[qb] + 16 * kb, A_KF + (kb * 8) * 4, A_Q[qb]
+                    d, a, b = V_S[qb] + 16 * kb, A_KF + (kb * KS) * 4, A_Q[qb]
                     m = Ins(f"{self.mf} {vr(d, 16)}, {ar(a, 4)}, {ar(b, 4)}, {vr(V_C0, 16)}", "mfma",
                             rl("a", a, 4) + rl("a", b, 4) + rl("v", V_C0, 16), rl("v", d, 16))
                 out.append(m)
@@ -265,22 +290,23 @@ class Gen:
         """O^T[dblk] += V^T[dblk][ks] P_qb[ks]^T."""
         out = []
         for ks in range(4):
-            for d in range(4):
-                out.append(self.mfma("a", A_O[qb] + 16 * d, "v", V_VF + (ks * 4 + d) * 4,
+            for d in range(DB):
+                out.append(self.mfma("a", A_O[qb] + 16 * d, "v", V_VF + (ks * DB + d) * 4,
                                      "v", V_P[qb] + 4 * ks, False))
         return out
 
     def k_read(self, kb, ks, fast=None):
-        b = A_KF + (kb * 8 + ks) * 4
-        areg, off = (V_KADDR + ks, kb * 8192) if fast is None else (V_KBASE + ks, fast[1] + kb * 8192)
+        b = A_KF + (kb * KS + ks) * 4
+        half = 32 * ROWB                       # 32 keys
+        areg, off = (V_KADDR + ks, kb * half) if fast is None else (V_KBASE + ks, fast[1] + kb * half)
         return Ins(f"ds_read_b128 {ar(b, 4)}, v{areg} offset:{off}", "lds", [f"v{areg}"], rl("a", b, 4))
 
     def v_reads(self, d, ks, fast=None):
-        b = V_VF + (ks * 4 + d) * 4
-        areg, off = (V_VADDR, ks * 4096 + d * 256) if fast is None else (V_VBASE, fast[0] + ks * 4096 + d * 256)
-        assert off + 2048 < 65536
+        b = V_VF + (ks * DB + d) * 4
+        areg, off = (V_VADDR, ks * 4 * VQ + d * 256) if fast is None else (V_VBASE, fast[0] + ks * 4 * VQ + d * 256)
+        assert off + 2 * VQ < 65536
         return [Ins(f"ds_read_b64_tr_b16 {vr(b, 2)}, v{areg} offset:{off}", "lds", [f"v{areg}"], rl("v", b, 2)),
-                Ins(f"ds_read_b64_tr_b16 {vr(b + 2, 2)}, v{areg} offset:{off + 2048}", "lds", [f"v{areg}"],
+                Ins(f"ds_read_b64_tr_b16 {vr(b + 2, 2)}, v{areg} offset:{off + 2 * VQ}", "lds", [f"v{areg}"],
                     rl("v", b + 2, 2))]
 
     def valu(self, txt, rd, wr, kind="valu", w=1.0):
@@ -406,13 +432,13 @@ class Gen:
         offs.append(Ins(f"s_add_u32 s{t0 + 1}, s{S_R0}, s{S_W1024}", "salu", [], [f"s{t0 + 1}", "scc"], w=0.5))
         offs.append(Ins(f"s_add_u32 s{t0 + 2}, s{S_R2}, s{S_W1024}", "salu", [], [f"s{t0 + 2}", "scc"], w=0.5))
         g.append((offs, "offs"))
-        for jj in range(4):
+        for jj in range(NP):
             p = [Ins(f"s_add_u32 m0, s{t0 + 1}, {4096 * jj}", "salu", [f"s{t0 + 1}"], ["m0", "scc"], w=0.5),
                  Ins(f"buffer_load_dwordx4 v{V_DMAK}, {sr(S_KRS, 4)}, s{S_KSOFF} offen lds", "dma",
                      ["m0", f"v{V_DMAK}", f"s{S_KSOFF}"], [], w=4.0),
                  Ins(f"s_add_u32 s{S_KSOFF}, s{S_KSOFF}, s{S_K16}", "salu", [f"s{S_KSOFF}"], [f"s{S_KSOFF}", "scc"], w=0.5)]
             g.append((p, "dma"))
-        for jj in range(4):
+        for jj in range(NP):
             p = [Ins(f"s_add_u32 m0, s{t0 + 2}, {LDS_VREGION + 4096 * jj}", "salu", [f"s{t0 + 2}"], ["m0", "scc"], w=0.5),
                  Ins(f"buffer_load_dwordx4 v{V_DMAV}, {sr(S_VRS, 4)}, s{S_VSOFF} offen lds", "dma",
                      ["m0", f"v{V_DMAV}", f"s{S_VSOFF}"], [], w=4.0),
@@ -424,21 +450,21 @@ class Gen:
         """Fast loop: K(j+4) -> slot r0, V(j+3) -> slot r2; the source tile is in the voffset registers."""
         r0, r1, r2 = fast
         g = []
-        for jj in range(4):
+        for jj in range(NP):
             so = "0" if jj == 0 else f"s{S_KJ + jj - 1}"
             p = [Ins(f"s_add_u32 m0, s{S_W1024}, {r0 + 4096 * jj}", "salu", [], ["m0", "scc"], w=0.5),
                  Ins(f"buffer_load_dwordx4 v{V_DMAK_CUR}, {sr(S_KRS, 4)}, {so} offen lds", "dma",
                      ["m0", f"v{V_DMAK_CUR}"], [], w=4.0)]
-            if jj == 3:
+            if jj == NP - 1:
                 op = "v_subrev_u32" if self.reverse else "v_add_u32"
                 p.append(Ins(f"{op} v{V_DMAK_CUR}, s{S_KTILE}, v{V_DMAK_CUR}", "valu", [f"v{V_DMAK_CUR}"], [f"v{V_DMAK_CUR}"]))
             g.append((p, "dma"))
-        for jj in range(4):
+        for jj in range(NP):
             so = "0" if jj == 0 else f"s{S_VJ + jj - 1}"
             p = [Ins(f"s_add_u32 m0, s{S_W1024}, {LDS_VREGION + r2 + 4096 * jj}", "salu", [], ["m0", "scc"], w=0.5),
                  Ins(f"buffer_load_dwordx4 v{V_DMAV_CUR}, {sr(S_VRS, 4)}, {so} offen lds", "dma",
                      ["m0", f"v{V_DMAV_CUR}"], [], w=4.0)]
-            if jj == 3:
+            if jj == NP - 1:
                 op = "v_subrev_u32" if self.reverse else "v_add_u32"
                 p.append(Ins(f"{op} v{V_DMAV_CUR}, s{S_VTILE}, v{V_DMAV_CUR}", "valu", [f"v{V_DMAV_CUR}"], [f"v{V_DMAV_CUR}"]))
             g.append((p, "dma"))
@@ -447,7 +473,7 @@ class Gen:
     def addr_update(self):
         """Read addresses of the NEXT iteration: K read slot R1' = R2, V read slot R0' = R1; then rotate."""
         ka = [Ins(f"v_add_u32 v{V_KADDR + i}, s{S_R2}, v{V_KBASE + i}", "valu", [f"v{V_KBASE + i}"], [f"v{V_KADDR + i}"])
-              for i in range(8)]
+              for i in range(KS)]
         va = [Ins(f"v_add_u32 v{V_VADDR}, s{S_R1}, v{V_VBASE}", "valu", [f"v{V_VBASE}"], [f"v{V_VADDR}"])]
         t = S_TMP + 3
         rot = [Ins(f"s_mov_b32 s{t}, s{S_R0}", "salu", [], [f"s{t}"], w=0.5),
@@ -483,22 +509,22 @@ class Gen:
         # ---- streams
         mf1 = (self.qk_mfmas(1) if a1 else []) + (self.pv_mfmas(1) if a0 else [])
         mf2 = (self.qk_mfmas(0) if a2 else []) + (self.pv_mfmas(0) if a1 else [])
-        n1_qk = 16 if a1 else 0
-        n2_qk = 16 if a2 else 0
+        n1_qk = 2 * KS if a1 else 0
+        n2_qk = 2 * KS if a2 else 0
         # LDS reads: (ready = global MFMA index after which the register is free, deadline = global index of the
         # first MFMA that consumes it, Ins)
         lds = []
         nm1 = len(mf1)
         if a2:
-            for ks in range(8):
+            for ks in range(KS):
                 for kb in range(2):
                     p = ks * 2 + kb
                     ready = p if a1 else -1          # after QK1 MFMA p of phase 1
                     lds.append([ready, nm1 + p, self.k_read(kb, ks, fast)])
         if a1:
             for ks in range(4):
-                for d in range(4):
-                    q = ks * 4 + d
+                for d in range(DB):
+                    q = ks * DB + d
                     ready = (n1_qk + q) if a0 else -1
                     for ins in self.v_reads(d, ks, fast):
                         lds.append([ready, nm1 + n2_qk + q, ins])
@@ -635,7 +661,7 @@ class Gen:
         o.append(f"v_mul_f32 v{V_L2[qb]}, v{V_L2[qb]}, {al}")
         o.append(f"v_add_f32 v{V_THR[qb]}, 0x41000000, {mnew}")               # (m_run + 8) / c
         o.append(f"v_mul_f32 v{V_THR[qb]}, s{S_RC}, v{V_THR[qb]}")
-        for i in range(0, 64, 4):
+        for i in range(0, 16 * DB, 4):
             for e in range(4):
                 o.append(f"v_accvgpr_read_b32 v{T + 4 + e}, a{A_O[qb] + i + e}")
             for e in range(4):
@@ -679,7 +705,7 @@ class Gen:
         o.append(f"s_cmp_lt_i32 s{tile_s}, s{S_NMAX}")
         o.append(f"s_cselect_b32 s{tmp}, s{tmp}, s{S_OOB}")
         o.append(f"s_add_u32 s{tmp + 1}, s{slot_s}, s{S_W1024}")
-        for jj in range(4):
+        for jj in range(NP):
             o.append(f"s_add_u32 m0, s{tmp + 1}, {reg + 4096 * jj}")
             o.append("s_nop 0")
             o.append(f"buffer_load_dwordx4 v{vo}, {sr(rs, 4)}, s{tmp} offen lds")
@@ -720,7 +746,7 @@ class Gen:
         A("s_barrier")                                   # previous pass: every wave is done with the LDS ring
         # ---- Q fragments -> AGPRs
         for qb in range(2):
-            for ks in range(8):
+            for ks in range(KS):
                 A(f"buffer_load_dwordx4 {ar(A_Q[qb] + 4 * ks, 4)}, v{V_QOFF[qb]}, {sr(S_QRS, 4)}, 0 offen offset:{32 * ks}")
         # ---- first tiles: K(n_min) -> R1, V(n_min) -> R1, K(n_min+1) -> R2      (n_min = j_start + 2)
         t = S_TMP
@@ -730,7 +756,7 @@ class Gen:
         A(f"s_add_u32 s{t}, s{S_J}, 3")
         L += self.gen_dma_tile("k", t, S_R2, t + 1)
         # ---- state
-        for i in range(128):
+        for i in range(2 * 16 * DB):
             A(f"v_accvgpr_write_b32 a{i}, 0")
         for qb in range(2):
             A(f"v_mov_b32 v{V_MRUN[qb]}, 0xff800000")
@@ -738,7 +764,7 @@ class Gen:
             A(f"v_mov_b32 v{V_L[qb]}, 0")
             A(f"v_mov_b32 v{V_L2[qb]}, 0")
             A(f"v_mov_b32 v{V_THR[qb]}, 0xff800000")
-        for i in range(8):
+        for i in range(KS):
             A(f"v_add_u32 v{V_KADDR + i}, s{S_R1}, v{V_KBASE + i}")
         A(f"v_add_u32 v{V_VADDR}, s{S_R0}, v{V_VBASE}")
         if self.alibi:
@@ -746,7 +772,7 @@ class Gen:
             for r in range(16):
                 cr = float((r & 3) + 8 * (r >> 2))
                 A(f"v_mul_f32 v{V_C0 + r}, 0x{struct.unpack('<I', struct.pack('<f', cr))[0]:08x}, v{V_BETA}")
-        A("s_waitcnt vmcnt(8)")                          # Q and K(n_min) have landed
+        A(f"s_waitcnt vmcnt({2 * NP})")                  # Q and K(n_min) have landed
         stamp(1)
 
         # ---- iteration loop + dispatch
@@ -811,7 +837,7 @@ class Gen:
             self.gen_iteration(a0, a1, a2, cfg)
             report[(a0, a1, a2)] = (dict(self.stats), len(self.out))
             L += self.out
-            A("s_waitcnt vmcnt(8)")
+            A(f"s_waitcnt vmcnt({2 * NP})")
             A(f"s_add_u32 s{S_J}, s{S_J}, 1")
             A(f"s_cmp_lt_i32 s{S_J}, s{S_NMAX}")
             A("s_cbranch_scc1 L_top_%=")
@@ -831,7 +857,7 @@ class Gen:
                 self.gen_iteration(1, 1, 1, cfg, fast=sl)
                 report[("fast", c)] = (dict(self.stats), len(self.out))
                 L += self.out
-                A("s_waitcnt vmcnt(8)")
+                A(f"s_waitcnt vmcnt({2 * NP})")
                 A(f"s_add_u32 s{S_J}, s{S_J}, 1")
                 A(f"s_cmp_lt_i32 s{S_J}, s{S_FASTEND}")
                 if c < 2:
@@ -845,7 +871,7 @@ class Gen:
                 A(f"s_mov_b32 s{S_R0}, {n0}")
                 A(f"s_mov_b32 s{S_R1}, {n1}")
                 A(f"s_mov_b32 s{S_R2}, {n2}")
-                for i in range(8):
+                for i in range(KS):
                     A(f"v_add_u32 v{V_KADDR + i}, {n1}, v{V_KBASE + i}")
                 A(f"v_add_u32 v{V_VADDR}, {n0}, v{V_VBASE}")
                 A("s_branch L_top_%=")
@@ -857,7 +883,9 @@ class Gen:
             L += self.gen_rescale_routine(qb)
         # ---- epilogue: O / l -> 16 bit, LSE.  O goes through a wave-private LDS image ([64 rows][256 B + 16]) so that the
         # stores cover whole 256-byte rows (4 rows per instruction) instead of 8-byte shreds of 32 rows
-        EP_PITCH, EP_QB = 272, 32 * 272
+        EP_QB = 32 * EP_PITCH
+        assert (2 * EP_QB) % 1024 == 0
+        rsh = {4: 4, 8: 3}[EP_ROWS]                      # lane -> (row, 16-byte chunk) of a 1-KiB store
         A("L_done_%=:")
         A("s_waitcnt vmcnt(0) lgkmcnt(0)")
         stamp(2)
@@ -870,8 +898,8 @@ class Gen:
         A(f"v_mbcnt_hi_u32_b32 v{lane}, -1, v{lane}")
         A(f"v_and_b32 v{E + 4}, 31, v{lane}")                      # q row of the accumulator columns
         A(f"v_lshrrev_b32 v{E + 5}, 5, v{lane}")                   # g
-        A(f"v_lshrrev_b32 v{E + 6}, 4, v{lane}")                   # lane >> 4: row of the lane's 16-byte chunk
-        A(f"v_and_b32 v{E + 7}, 15, v{lane}")
+        A(f"v_lshrrev_b32 v{E + 6}, {rsh}, v{lane}")               # row of the lane's 16-byte chunk
+        A(f"v_and_b32 v{E + 7}, {(1 << rsh) - 1}, v{lane}")
         A(f"v_lshlrev_b32 v{E + 7}, 4, v{E + 7}")                  # its column byte
         A(f"s_mul_i32 s{t}, s{S_W1024}, {2 * EP_QB // 1024}")      # wave * 17408
         A(f"v_mul_u32_u24 v{wbase}, {EP_PITCH}, v{E + 4}")
@@ -884,7 +912,7 @@ class Gen:
         A("s_nop 4")
         A(f"v_add_u32 v{E + 6}, s{t + 2}, v{E + 6}")               # global row
         A(f"v_mad_u32_u24 v{goff}, v{E + 6}, s{t + 1}, v{E + 7}")  # byte offset of the lane's chunk
-        A(f"s_lshl_b32 s{t + 1}, s{t + 1}, 2")                     # 4 rows further
+        A(f"s_lshl_b32 s{t + 1}, s{t + 1}, {2 if EP_ROWS == 4 else 3}")   # EP_ROWS rows further
         A("s_nop 7")
         for qb in range(2):
             l, mrun = f"v{V_L[qb]}", f"v{V_MRUN[qb]}"
@@ -902,7 +930,7 @@ class Gen:
             A(f"v_add_f32 {lse}, {lse}, {mrun}")
             A(f"v_mul_f32 {lse}, 0x3f317218, {lse}")
             A(f"buffer_store_dword {lse}, v{V_LSEOFF[qb]}, {sr(S_LRS, 4)}, 0 offen")
-            for d in range(4):
+            for d in range(DB):
                 for r4 in range(4):
                     base = A_O[qb] + 16 * d + 4 * r4
                     tt = T + 8 + 4 * (r4 & 1)
@@ -916,11 +944,12 @@ class Gen:
                     A(f"ds_write_b64 v{wbase}, {vr(pk, 2)} offset:{qb * EP_QB + 64 * d + 16 * r4}")
         A("s_waitcnt lgkmcnt(0)")
         A(f"s_mov_b32 s{t + 3}, 0")
+        NST = 32 // EP_ROWS                              # store instructions per q-block
         for qb in range(2):
-            for j in range(8):
-                A(f"ds_read_b128 {vr(V_S[0] + 4 * j, 4)}, v{rbase} offset:{qb * EP_QB + 4 * EP_PITCH * j}")
-            for j in range(8):
-                A(f"s_waitcnt lgkmcnt({7 - j})")
+            for j in range(NST):
+                A(f"ds_read_b128 {vr(V_S[0] + 4 * j, 4)}, v{rbase} offset:{qb * EP_QB + EP_ROWS * EP_PITCH * j}")
+            for j in range(NST):
+                A(f"s_waitcnt lgkmcnt({NST - 1 - j})")
                 A(f"buffer_store_dwordx4 {vr(V_S[0] + 4 * j, 4)}, v{goff}, {sr(S_ORS, 4)}, s{t + 3} offen")
                 A(f"s_add_u32 s{t + 3}, s{t + 3}, s{t + 1}")
             A("s_nop 1")
@@ -953,6 +982,12 @@ def clobbers(alibi=False):
 def main():
     cfg = dict(DEFAULT_CFG)
     ko = frozenset()
+    prefix = "FA_FWD_ASM"
+    for a in sys.argv[1:]:
+        if a == "--d=64":                                      # fa_fwd64_asm_gen.h: the D = 64 bodies
+            set_dim(64)
+            prefix = "FA_FWD64_ASM"
+            cfg["dma_gaps"] = {2: [5, 7, 9, 11, 13]}           # offsets + 2 K + 2 V pieces in a 16-MFMA phase
     for a in sys.argv[1:]:
         if a.startswith("--ko="):
             ko = frozenset(x for x in a[5:].split(",") if x)
@@ -963,20 +998,21 @@ def main():
         cfg["dma_gaps"] = {int(k): v for k, v in cfg["dma_gaps"].items()}
     print("// GENERATED by gen_fwd_asm.py - do not edit.  See that script for the schedule and the register map.")
     print("#pragma once")
+    print(f"#define {prefix}_LDS_BYTES {6 * LDS_STAGE}")
     for alibi in (False, True):
         tag = "ALIBI_" if alibi else ""
         for dt in ("bf16", "f16"):
             g = Gen(dt, alibi=alibi)
             g.ko = ko
             body, report = g.gen_body(cfg)
-            print(f"#define FA_FWD_ASM_{tag}BODY_{dt.upper()} \\")
+            print(f"#define {prefix}_{tag}BODY_{dt.upper()} \\")
             for ln in body:
                 print(f'    "{ln}\\n" \\')
             print('    ""')
             for k, (st, n) in report.items():
                 print(f"// {dt} {tag}variant a0a1a2={k}: {n} lines, nop states {st['nop_states']}, lgkmcnt waits {st['lgkm_waits']}")
         cl = ", ".join(f'"{c}"' for c in clobbers(alibi))
-        print(f"#define FA_FWD_ASM_{tag}CLOBBERS {cl}")
+        print(f"#define {prefix}_{tag}CLOBBERS {cl}")
 
 
 if __name__ == "__main__":

@@ -137,17 +137,17 @@ ASM_CASES = [
 ]
 
 
-def _asm_case(case):
+def _asm_case(case, D=128):
     B, Sq, Sk, H, Hk, causal, window, dt, spike = case
-    q = rand16((B, Sq, H, 128), dt, 421)
-    k = rand16((B, Sk, Hk, 128), dt, 422)
-    v = rand16((B, Sk, Hk, 128), dt, 423)
+    q = rand16((B, Sq, H, D), dt, 421)
+    k = rand16((B, Sk, Hk, D), dt, 422)
+    v = rand16((B, Sk, Hk, D), dt, 423)
     if spike:
         for tile in range(3, Sk // 64, 5):
             k[:, 64 * tile + 7] *= 6.0
     out, lse, _ = _fa().flash_attn_func(q, k, v, causal=causal, window_size=window, return_attn_probs=True)
     t = lambda x: f64(x).transpose(0, 2, 1, 3)
-    o_ref, lse_ref, _ = oracle.attn_fwd(t(q), t(k), t(v), 128 ** -0.5, causal=causal, window=window)
+    o_ref, lse_ref, _ = oracle.attn_fwd(t(q), t(k), t(v), D ** -0.5, causal=causal, window=window)
     assert_close(t(out), o_ref, dt, "out", mult=1.5)
     assert_lse_close(f64(lse), lse_ref, "lse", atol=2e-5)
 
@@ -155,6 +155,17 @@ def _asm_case(case):
 @pytest.mark.parametrize("case", ASM_CASES, ids=lambda c: "-".join(map(str, c)))
 def test_asm_forward_vs_oracle(case):
     _asm_case(case)
+
+
+def test_asm_forward_head_dim_64_vs_oracle():
+    """The D = 64 bodies of the same generator (half the k-steps / d-blocks, 128-byte K / V rows, 8-row DMA pieces) are
+    opt-in (FA_FWD_ASM64=1, read once per process: not faster than the compiler kernel): same cases in a subprocess."""
+    code = ("import os, sys; sys.path.insert(0, os.path.join(os.getcwd(), 'tests')); "
+            "sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), 'flash-attention-v100_amd')); "
+            "import test_parity_r2_gpu as t; [t._asm_case(c, D=64) for c in t.ASM_CASES]; print('ASM64-OK')")
+    env = dict(os.environ, FA_FWD_ASM64="1")
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ASM64-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 ASM_ALIBI_CASES = [
