@@ -718,10 +718,22 @@ __host__ __device__ inline bool gemv_tm_applicable(const fa_params& p) {
     if (p.head_dim != 128 || p.head_dim_v != 0 || p.seqlen_q != 1 || p.alibi_slopes || p.softcap > 0.f) return false;
     if (p.nheads_k < 1 || p.nheads_q % p.nheads_k) return false;
     const int G = p.nheads_q / p.nheads_k;
-    // (16-bit caches with a GQA group: the kernel works - tested up to G = 8 - but the MFMA decode kernel is faster there:
-    //  5.4 vs 5.2 TB/s at H 32/8; with fp8 the VALU kernel wins up to G = 4: 4.0 vs 3.7 TB/s)
-    if (!(G == 1 || (kv8 && (G == 2 || G == 4)))) return false;
+    // (GQA groups up to 4: VALU-bound - H 32/8: fp8 4.0 vs 3.7 TB/s on the MFMA kernel, fp16 5.6 vs 5.4)
+    if (!(G == 1 || G == 2 || G == 4)) return false;
     return p.nheads_k % gemv_tm_hpw(p) == 0 && p.k_head_stride == 128 && p.v_head_stride == 128;
+}
+
+// acc + a.lo * b.lo + a.hi * b.hi on packed 16-bit pairs, fp32 accumulate: one VALU op per two elements (v_dot2_f32_f16 /
+// v_dot2_f32_bf16).  Through the builtins, not inline asm: the result feeds a DPP sum, and the compiler only inserts
+// the VALU -> DPP wait states behind instructions it knows.
+template <typename T> __device__ __forceinline__ float dot2_acc(uint32_t a, uint32_t b, float acc);
+template <> __device__ __forceinline__ float dot2_acc<fp16_tag>(uint32_t a, uint32_t b, float acc) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    return __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, a), __builtin_bit_cast(h2, b), acc, false);
+}
+template <> __device__ __forceinline__ float dot2_acc<bf16_tag>(uint32_t a, uint32_t b, float acc) {
+    typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(b2, a), __builtin_bit_cast(b2, b), acc, false);
 }
 
 __device__ __forceinline__ float grp16_sum(float x) {
@@ -779,6 +791,7 @@ __global__ void __launch_bounds__(GEMV_THREADS) fa_decode_gemv_tm_kernel(const D
         const int h = HPW * hg + grp;                             // kv-head of this lane group
         // ---- q rows of the head's group: CPL columns each, RoPE, x scale ----
         float qs[G][CPL];
+        uint32_t qh[G][4];                                        // 16-bit caches: the row's packed pairs (v_dot2), scaled after the sum
 #pragma unroll
         for (int gi = 0; gi < G; ++gi) {
             const uint16_t* qrow = reinterpret_cast<const uint16_t*>(p.q) + (int64_t)b * p.q_batch_stride + (int64_t)(h * G + gi) * p.q_head_stride;
@@ -796,8 +809,13 @@ __global__ void __launch_bounds__(GEMV_THREADS) fa_decode_gemv_tm_kernel(const D
                 }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) { qs[gi][8 * cpart + 2 * i] = E::lo(x[i]) * c; qs[gi][8 * cpart + 2 * i + 1] = E::hi(x[i]) * c; }
+                if constexpr (!KV8) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) qh[gi][i] = x[i];
+                }
             }
         }
+        (void)qh;
         const uint32_t lane_off = (uint32_t)h * (128u * ES) + 16u * (uint32_t)sub;   // bytes inside a cache row
         const uint8_t* kbase = reinterpret_cast<const uint8_t*>(p.k) + lane_off;
         const uint8_t* vbase = reinterpret_cast<const uint8_t*>(p.v) + lane_off;
@@ -842,15 +860,26 @@ __global__ void __launch_bounds__(GEMV_THREADS) fa_decode_gemv_tm_kernel(const D
             float sv[G][KPS];
 #pragma unroll
             for (int i = 0; i < KPS; ++i) {
-                float kf[CPL];
-                unpack(kx[i], kf);
+                if constexpr (KV8) {
+                    float kf[CPL];
+                    unpack(kx[i], kf);
 #pragma unroll
-                for (int gi = 0; gi < G; ++gi) {
-                    float acc = 0.f;
+                    for (int gi = 0; gi < G; ++gi) {
+                        float acc = 0.f;
 #pragma unroll
-                    for (int x = 0; x < CPL; ++x) acc = fmaf(kf[x], qs[gi][x], acc);
-                    const float sd = KV8 ? grp8_sum(acc) : grp16_sum(acc);
-                    sv[gi][i] = (j0 + i < seg_n) ? sd : -INFINITY;
+                        for (int x = 0; x < CPL; ++x) acc = fmaf(kf[x], qs[gi][x], acc);
+                        const float sd = grp8_sum(acc);
+                        sv[gi][i] = (j0 + i < seg_n) ? sd : -INFINITY;
+                    }
+                } else {
+#pragma unroll
+                    for (int gi = 0; gi < G; ++gi) {
+                        float acc = 0.f;
+#pragma unroll
+                        for (int x = 0; x < 4; ++x) acc = dot2_acc<T>(kx[i][x], qh[gi][x], acc);
+                        const float sd = grp16_sum(acc) * c;
+                        sv[gi][i] = (j0 + i < seg_n) ? sd : -INFINITY;
+                    }
                 }
             }
             float pw[G][KPS];
@@ -1027,7 +1056,7 @@ static int launch_decode_td(DecArgs& da, hipStream_t stream) {
                 else       hipLaunchKernelGGL((fa_decode_gemv_tm_kernel<T, false, KV8_, G_>), grid_tm, dim3(GEMV_THREADS), 0, stream, da); \
             } while (0)
             if (kv8) { if (da.group == 1) FA_LAUNCH_TM(true, 1); else if (da.group == 2) FA_LAUNCH_TM(true, 2); else FA_LAUNCH_TM(true, 4); }
-            else FA_LAUNCH_TM(false, 1);
+            else { if (da.group == 1) FA_LAUNCH_TM(false, 1); else if (da.group == 2) FA_LAUNCH_TM(false, 2); else FA_LAUNCH_TM(false, 4); }
 #undef FA_LAUNCH_TM
             if (da.n_splits > 1) {
                 const int64_t total = (int64_t)p.batch * p.nheads_q * p.seqlen_q * (D / 8);

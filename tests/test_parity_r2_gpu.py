@@ -546,8 +546,8 @@ def test_decode_fp8_gemv_kernel(paged, window, interleaved, use_lp, splits, H, H
     (12, 12, False, (-1, -1), False, False, 0), (16, 8, True, (-1, -1), True, True, 3)])
 def test_decode_token_major_16bit_cache(H, Hk, paged, window, interleaved, use_lp, splits, dt):
     """fa_decode_gemv_tm_kernel on 16-bit caches (one query row per kv-head; 16 lanes per head, a wave instruction = one
-    token x 4 heads; 12 heads: three head groups, one wave idle) vs the oracle; same coverage as the fp8 cases.  The GQA
-    shapes in the list take fa_decode_kernel (faster for 16-bit caches with a group) - same expectations."""
+    token x 4 heads; GQA groups 2 and 4 through v_dot2; 12 heads: three head groups, one wave idle; group 8 falls back to
+    fa_decode_kernel) vs the oracle; same coverage as the fp8 cases."""
     fa = _fa()
     B, D, page = 5, 128, 256
     Smax = 1100
