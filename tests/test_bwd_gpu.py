@@ -69,6 +69,14 @@ CASES = [
     (1, 4, 4, 640, 640, 128, "bf16", False, (200, 0), 0.0, True),     # window_right == 0
     (1, 4, 4, 320, 320, 128, "bf16", False, (-1, -1), 0.0, True),     # general path (keys right of the diagonal)
     (1, 2, 2, 1500, 1500, 128, "fp16", True, (-1, -1), 0.0, True),    # long distances: tile term split three ways
+    # hand-scheduled dK/dV kernel (D = 128, no bias): edges of its stage pipeline, masks and key-block pairing
+    (1, 2, 2, 520, 300, 128, "bf16", True, (-1, -1), 0.0, False),     # Sq > Sk: rows without keys, key blocks without rows
+    (1, 2, 2, 300, 520, 128, "fp16", True, (-1, -1), 0.0, False),     # Sq < Sk: shifted diagonal
+    (2, 2, 1, 1, 700, 128, "bf16", False, (-1, -1), 0.0, False),      # one query row: a single (mostly empty) stage
+    (1, 2, 2, 700, 2, 128, "fp16", False, (-1, -1), 0.0, False),      # two keys (with one key dQ = 0 exactly: P (dP - D) cancels)
+    (1, 2, 2, 31, 1000, 128, "bf16", True, (-1, -1), 0.0, False),     # less than one stage of rows, eight key blocks
+    (1, 4, 1, 1000, 1000, 128, "fp16", False, (64, 32), 0.0, False),  # two-sided window, four q-heads per kv-head
+    (1, 2, 2, 1300, 1300, 128, "bf16", True, (-1, -1), 0.0, False),   # 11 key blocks: mirrored pairs + the middle one
     # softcap only (constants-folded variant in all kernels; Gemma-2 style)
     (2, 8, 2, 333, 333, 128, "bf16", True, (-1, -1), 50.0, False),
     (1, 4, 4, 200, 450, 64, "fp16", True, (128, 0), 20.0, False),

@@ -134,6 +134,10 @@ ASM_CASES = [
     (1, 1024, 1500, 2, 2, False, (100, 50), "bf16", False),      # two-sided window
     (1, 2048, 2048, 2, 2, True, (-1, -1), "bf16", True),         # late rescales of the running maximum
     (1, 2048, 2048, 2, 2, False, (-1, -1), "fp16", True),
+    (2, 300, 1, 2, 1, False, (-1, -1), "bf16", False),           # a single key
+    (1, 256, 17, 2, 2, False, (-1, -1), "fp16", False),          # less than one key tile
+    (1, 200, 65, 2, 2, True, (-1, -1), "bf16", False),           # one tile + 1 key, most rows without keys
+    (1, 1024, 1024, 2, 2, False, (0, 0), "bf16", False),         # window (0, 0): one visible key per row
 ]
 
 
