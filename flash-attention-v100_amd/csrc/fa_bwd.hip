@@ -1322,8 +1322,10 @@ __global__ void __launch_bounds__(BWD_THREADS, OCC) fa_bwd_dq_kernel(const KArgs
                 lse2 = lse * kLog2e;
                 if (g == 0) {
                     p.softmax_d[so] = acc;
-                    const int64_t plane = (int64_t)p.batch * p.nheads_q * p.seqlen_q;
-                    const int64_t at = ((int64_t)w.b * p.nheads_q + w.h) * p.seqlen_q + my_row;
+                    // dense: [B][H][Sq] planes; packed sequences: [H][total_q]
+                    const int64_t plane = p.cu_seqlens_q ? (int64_t)p.nheads_q * p.total_q : (int64_t)p.batch * p.nheads_q * p.seqlen_q;
+                    const int64_t at = p.cu_seqlens_q ? (int64_t)w.h * p.total_q + sg.q_row0 + my_row
+                                                      : ((int64_t)w.b * p.nheads_q + w.h) * p.seqlen_q + my_row;
                     a.stats_ws[at] = lse == -INFINITY ? INFINITY : lse2;
                     a.stats_ws[plane + at] = -acc;
                 }
@@ -1721,6 +1723,7 @@ static KArgs bwd_probe_args(const fa_params& p) {
     memset(&a, 0, sizeof(a));
     a.p = p;
     a.has_bias = (p.alibi_slopes != nullptr) || (p.softcap > 0.f);
+    a.flat_blocks = p.cu_seqlens_q ? 1 : 0;           // (packed sequences run through the flat work lists unless FA_VARLEN_GRID=1)
     return a;
 }
 size_t bwd_workspace_bytes(const fa_params& p) {
@@ -1864,6 +1867,8 @@ int launch_bwd(const KArgs& a_in, hipStream_t stream) {
         a.stats_ws = reinterpret_cast<float*>(a.p.workspace);     // (without a workspace the hipcc kernels run)
 #ifndef FA_NO_FUSE_PRE
         a.fuse_pre = 1;
+#else
+        if (a.p.cu_seqlens_q) a.stats_ws = nullptr;      // (A/B build: the preprocess kernel only knows the dense statistics layout)
 #endif
     }
     const bool bf = a.p.dtype == FA_BF16;

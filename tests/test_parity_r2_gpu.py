@@ -255,6 +255,37 @@ def test_asm_forward_varlen_vs_oracle(lens_q, lens_k, H, Hk, causal, window, ali
     assert_lse_close(f64(lse), lse_ref, "lse", atol=1e-4)
 
 
+@pytest.mark.parametrize("lens_q,lens_k,H,Hk,causal,window,dt", [
+    ([1000, 257, 64, 700], None, 4, 2, True, (-1, -1), "bf16"),
+    ([300, 1, 900], [500, 40, 900], 2, 2, True, (-1, -1), "fp16"),          # seqlen_q != seqlen_k per sequence
+    ([512, 130, 1024], None, 4, 1, False, (-1, -1), "bf16"),                # four q-heads per kv-head
+    ([400, 1300], None, 2, 2, False, (150, 60), "fp16"),                    # two-sided window
+])
+def test_asm_backward_varlen_vs_oracle(lens_q, lens_k, H, Hk, causal, window, dt):
+    """flash_attn_varlen_func backward at D = 128: the hand-scheduled dK/dV kernel over the flat list of key blocks, the
+    statistics ([H][T] planes) written by the dQ kernel; vs the per-sequence dense oracle."""
+    lens_k = lens_k or lens_q
+    cu_q = torch.tensor(np.concatenate([[0], np.cumsum(lens_q)]), dtype=torch.int32, device="cuda")
+    cu_k = torch.tensor(np.concatenate([[0], np.cumsum(lens_k)]), dtype=torch.int32, device="cuda")
+    q = rand16((sum(lens_q), H, 128), dt, 461).requires_grad_(True)
+    k = rand16((sum(lens_k), Hk, 128), dt, 462).requires_grad_(True)
+    v = rand16((sum(lens_k), Hk, 128), dt, 463).requires_grad_(True)
+    do = rand16((sum(lens_q), H, 128), dt, 464)
+    out = _fa().flash_attn_varlen_func(q, k, v, cu_q, cu_k, max(lens_q), max(lens_k), causal=causal, window_size=window)
+    dq, dk, dv = torch.autograd.grad(out, (q, k, v), do)
+    cq, ck = cu_q.cpu().numpy(), cu_k.cpu().numpy()
+    for i in range(len(lens_q)):
+        sq, sk = slice(cq[i], cq[i + 1]), slice(ck[i], ck[i + 1])
+        t = lambda x, sl: f64(x[sl]).transpose(1, 0, 2)[None]                 # [1, H, S, D]
+        o_ref, lse_ref, _ = oracle.attn_fwd(t(q, sq), t(k, sk), t(v, sk), 128 ** -0.5, causal=causal, window=window)
+        dq_r, dk_r, dv_r, _ = oracle.attn_bwd(t(do, sq), t(q, sq), t(k, sk), t(v, sk), o_ref, lse_ref.astype(np.float64),
+                                              128 ** -0.5, causal=causal, window=window)
+        if np.abs(dq_r).max() > 0:
+            assert_close(t(dq, sq), dq_r, dt, f"dq[{i}]", mult=2.0)
+        assert_close(t(dk, sk), dk_r, dt, f"dk[{i}]", mult=2.0)
+        assert_close(t(dv, sk), dv_r, dt, f"dv[{i}]", mult=2.0)
+
+
 # ------------------------------------------------------------------------------------------------ varlen op extras
 def test_varlen_seqused_k_zero_tensors_and_out():
     import flash_attn_mi355.torch_ops  # noqa: F401  (registers torch.ops.flash_attn_mi355.*)

@@ -1,4 +1,4 @@
-"""flash_attn_varlen_func forward at D = 128 (packed training batches): the asm forward vs FA_FWD_ASM=0."""
+"""flash_attn_varlen_func forward / backward at D = 128 (packed training batches): the asm kernels vs FA_FWD_ASM=0 FA_BWD_ASM=0."""
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "flash-attention-v100_amd"))
 import torch, flash_attn
@@ -17,4 +17,13 @@ for (B, lo, hi, H, Hk) in ((32, 512, 4097, 16, 16), (64, 256, 2049, 32, 8)):
     e.record(); torch.cuda.synchronize()
     ms = s.elapsed_time(e) / 10
     fl = 4.0 * 128 * H * sum(int(L) * (int(L) + 1) // 2 for L in lens)
-    print(f"B{B} lens {lo}..{hi - 1} ({T} tokens) H{H}/{Hk} causal: {ms:.3f} ms  {fl / ms / 1e9:.0f} TFLOP/s", flush=True)
+    q.requires_grad_(True); k.requires_grad_(True); v.requires_grad_(True)
+    o = fn(); do = torch.randn_like(o)
+    bw = lambda: torch.autograd.grad(o, (q, k, v), do, retain_graph=True)
+    for _ in range(3): bw()
+    torch.cuda.synchronize()
+    s.record()
+    for _ in range(10): bw()
+    e.record(); torch.cuda.synchronize()
+    msb = s.elapsed_time(e) / 10
+    print(f"B{B} lens {lo}..{hi - 1} ({T} tokens) H{H}/{Hk} causal: fwd {ms:.3f} ms  {fl / ms / 1e9:.0f} TFLOP/s | bwd {msb:.3f} ms  {2.5 * fl / msb / 1e9:.0f} TFLOP/s", flush=True)
