@@ -1,0 +1,363 @@
+"""Seeded random differential testing of the HIP path against the oracle (checker only).
+
+Shapes are drawn around the tile edges of the kernels (multiples of 32 / 64 / 128 / 256, +-1), features are drawn
+independently (causal / one- and two-sided windows, GQA / MQA, ALiBi, softcap, dropout, head dims 32..256, ragged and
+empty sequences, paged caches, rotary, left padding), sizes stay where the fp64 oracle finishes in well under a second.
+
+  pytest runs a fixed sample (tests/test_fuzz_gpu.py);  more:   python tests/fuzz_cases.py --seed 7 --n 400
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "flash-attention-v100_amd"))
+
+import oracle                                                     # noqa: E402
+from util import DT, TOL_FRO, TOL_MAXREL, f64, rand16             # noqa: E402
+
+EDGES = (1, 2, 31, 32, 33, 63, 64, 65, 96, 127, 128, 129, 191, 192, 193, 255, 256, 257, 320, 383, 384, 385, 511, 512,
+         513, 640, 767, 768, 769)
+HEAD_DIMS = (32, 64, 64, 64, 96, 128, 128, 128, 128, 160, 192, 256)
+
+
+def _fa():
+    import flash_attn
+    return flash_attn
+
+
+LONG_EDGES = (1023, 1024, 1025, 1536, 1791, 1792, 2047, 2048, 2049, 2304, 3071, 3072, 3073, 4095, 4096, 4097)
+
+
+def _len(rng, hi=769):
+    if hi > 1024:                           # long shapes: the hand-scheduled kernels' loops, key-block pairing, fast ranges
+        return int(rng.choice(LONG_EDGES)) if rng.random() < 0.6 else int(rng.integers(256, hi + 1))
+    return int(rng.choice(EDGES)) if rng.random() < 0.7 else int(rng.integers(1, hi + 1))
+
+
+def _mask(rng, sq, sk):
+    """(causal, window)"""
+    r = rng.random()
+    if r < 0.35:
+        return True, (-1, -1)
+    if r < 0.55:
+        return False, (-1, -1)
+    if r < 0.7:
+        return False, (int(rng.integers(0, max(sk, 2))), 0)
+    if r < 0.85:
+        return False, (int(rng.integers(0, max(sk, 2))), int(rng.integers(0, max(sk, 2))))
+    if r < 0.93:
+        return True, (int(rng.integers(0, max(sk, 2))), -1)
+    return False, (-1, int(rng.integers(0, max(sk, 2))))
+
+
+def _features(rng, hq):
+    softcap = float(rng.choice([10.0, 30.0, 50.0])) if rng.random() < 0.15 else 0.0
+    slopes = None
+    if rng.random() < 0.25:
+        slopes = torch.tensor([float(2.0 ** (-8.0 * (i + 1) / hq)) * float(rng.choice([1.0, 4.0])) for i in range(hq)],
+                              dtype=torch.float32, device="cuda")
+    return softcap, slopes
+
+
+def _gen_state():
+    g = torch.cuda.default_generators[torch.cuda.current_device()]
+    return g.initial_seed(), g.get_offset()
+
+
+def _check(got, ref, dt, name, mult, desc, absfloor=2e-3):
+    # (a reference that cancels to ~0 still sees the 16-bit rounding of O in D = dO . O: bound by the element tolerance)
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    assert got.shape == ref.shape, (name, got.shape, ref.shape, desc)
+    assert np.isfinite(got).all(), f"{name}: non-finite values  [{desc}]"
+    d = np.abs(got - ref)
+    if d.size == 0:
+        return
+    rmax, rfro = np.abs(ref).max(), np.sqrt((ref ** 2).sum())
+    # references that cancel to (almost) nothing - one visible key, P (dP - D) = 0 - only get an absolute bound
+    if rmax < absfloor:
+        assert d.max() <= TOL_MAXREL[dt] * mult, f"{name}: |ref| ~ 0, max-abs {d.max():.3e}  [{desc}]"
+        return
+    mr, fro = d.max() / rmax, np.sqrt((d ** 2).sum()) / rfro
+    assert mr <= TOL_MAXREL[dt] * mult and fro <= TOL_FRO[dt] * mult, \
+        f"{name}: max-rel {mr:.3e} (tol {TOL_MAXREL[dt] * mult:.1e}) fro {fro:.3e} (tol {TOL_FRO[dt] * mult:.1e})  [{desc}]"
+
+
+def _check_lse(got, ref, name, desc, atol=2e-3):
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    inf_ref = np.isneginf(ref)
+    assert (np.isneginf(got) == inf_ref).all(), f"{name}: -inf pattern differs  [{desc}]"
+    d = np.abs(got[~inf_ref] - ref[~inf_ref])
+    assert d.size == 0 or d.max() <= atol, f"{name}: max abs diff {d.max():.3e}  [{desc}]"
+
+
+# ------------------------------------------------------------------------------------------------ dense fwd + bwd
+def dense_case(rng, idx, long=False):
+    B = int(rng.integers(1, 3))
+    Hk = int(rng.choice([1, 2, 4]))
+    Hq = Hk * int(rng.choice([1, 1, 2, 4]))
+    D = int(rng.choice(HEAD_DIMS))
+    Sq, Sk = _len(rng), _len(rng)
+    if long:
+        B, Hk = 1, 1
+        Hq = int(rng.choice([1, 1, 2]))
+        D = int(rng.choice([64, 128, 128, 128, 128, 256]))
+        Sq, Sk = _len(rng, 4097), _len(rng, 4097)
+    if rng.random() < 0.5:
+        Sk = Sq
+    dt = str(rng.choice(["fp16", "bf16"]))
+    causal, window = _mask(rng, Sq, Sk)
+    softcap, slopes = _features(rng, Hq)
+    pdrop = float(rng.choice([0.1, 0.3])) if rng.random() < 0.12 else 0.0
+    if pdrop:
+        softcap = 0.0                       # the op rejects softcap + dropout, as the reference's does
+    bwd = rng.random() < 0.8
+    desc = f"dense{'_long' if long else ''}#{idx} B{B} Hq{Hq} Hk{Hk} Sq{Sq} Sk{Sk} D{D} {dt} causal={causal} window={window} softcap={softcap} " \
+           f"alibi={slopes is not None} dropout={pdrop} bwd={bwd}"
+    s = 1000 + 10 * idx
+    q = rand16((B, Sq, Hq, D), dt, s + 1).requires_grad_(True)
+    k = rand16((B, Sk, Hk, D), dt, s + 2).requires_grad_(True)
+    v = rand16((B, Sk, Hk, D), dt, s + 3).requires_grad_(True)
+    do = rand16((B, Sq, Hq, D), dt, s + 4)
+    seed, offset = _gen_state()
+    out, lse, _ = _fa().flash_attn_func(q, k, v, dropout_p=pdrop, causal=causal, window_size=window, softcap=softcap,
+                                        alibi_slopes=slopes, return_attn_probs=True)
+    t = lambda x: f64(x).transpose(0, 2, 1, 3)
+    kw = dict(causal=causal, window=window, softcap=softcap, alibi_slopes=None if slopes is None else f64(slopes))
+    if pdrop:
+        kw.update(dropout_p=pdrop, seed=seed, offset=offset)
+    o_ref, lse_ref, _ = oracle.attn_fwd(t(q), t(k), t(v), D ** -0.5, **kw)
+    m = 1.5 if pdrop else 1.0
+    _check(t(out), o_ref, dt, "out", m, desc)
+    _check_lse(f64(lse), lse_ref, "lse", desc)
+    if bwd:
+        dq, dk, dv = torch.autograd.grad(out, (q, k, v), do)
+        g = oracle.attn_bwd(t(do), t(q), t(k), t(v), o_ref, lse_ref.astype(np.float64), D ** -0.5, **kw)
+        m = 3.0 if pdrop else 2.0
+        _check(t(dq), g[0], dt, "dq", m, desc)
+        _check(t(dk), g[1], dt, "dk", m, desc)
+        _check(t(dv), g[2], dt, "dv", m, desc)
+    return desc
+
+
+# ------------------------------------------------------------------------------------------------ varlen fwd + bwd
+def varlen_case(rng, idx, long=False):
+    B = int(rng.integers(1, 6))
+    Hk = int(rng.choice([1, 2, 4]))
+    Hq = Hk * int(rng.choice([1, 1, 2, 4]))
+    D = int(rng.choice(HEAD_DIMS))
+    dt = str(rng.choice(["fp16", "bf16"]))
+    hi = 400
+    if long:                                # >= 256 rows per sequence on average: the flat work lists of the asm kernels
+        B, Hk, hi = int(rng.integers(1, 4)), 1, 1400
+        Hq = int(rng.choice([1, 2]))
+        D = int(rng.choice([64, 128, 128, 128]))
+    lens_q = [0 if rng.random() < 0.1 else (int(rng.integers(200, hi)) if long else _len(rng, hi)) for _ in range(B)]
+    if rng.random() < 0.6:
+        lens_k = list(lens_q)
+    else:
+        lens_k = [0 if rng.random() < 0.05 else (int(rng.integers(1, hi)) if long else _len(rng, hi)) for _ in range(B)]
+    if sum(lens_q) == 0:
+        lens_q[0] = 17
+        lens_k[0] = max(lens_k[0], 5)
+    if sum(lens_k) == 0:
+        lens_k[0] = 9
+    paged = rng.random() < 0.2
+    causal, window = _mask(rng, max(lens_q), max(lens_k))
+    softcap, slopes = _features(rng, Hq)
+    used = None                             # seqused_k (forward only): keys actually used of each sequence
+    if rng.random() < 0.15:
+        used = [int(rng.integers(0, l + 1)) for l in lens_k]
+    bwd = (not paged) and used is None and rng.random() < 0.8
+    desc = f"varlen{'_long' if long else ''}#{idx} lens_q={lens_q} lens_k={lens_k} Hq{Hq} Hk{Hk} D{D} {dt} causal={causal} window={window} " \
+           f"softcap={softcap} alibi={slopes is not None} paged={paged} seqused_k={used} bwd={bwd}"
+    s = 5000 + 10 * idx
+    Tq, Tk = sum(lens_q), sum(lens_k)
+    cu = lambda l: torch.tensor(np.concatenate([[0], np.cumsum(l)]), dtype=torch.int32, device="cuda")
+    cu_q, cu_k = cu(lens_q), cu(lens_k)
+    mq, mk = max(lens_q), max(lens_k)
+    q = rand16((Tq, Hq, D), dt, s + 1).requires_grad_(bwd)
+    do = rand16((Tq, Hq, D), dt, s + 4)
+    kw = dict(causal=causal, window=window, softcap=softcap, alibi_slopes=None if slopes is None else f64(slopes))
+    extra = {}
+    if used is not None:
+        extra["seqused_k"] = torch.tensor(used, dtype=torch.int32, device="cuda")
+        kw["seqused_k"] = np.asarray(used, dtype=np.int32)
+    if paged:
+        page = int(rng.choice([64, 128, 256]))
+        per = [(l + page - 1) // page for l in lens_k]
+        total = sum(per) + 2
+        perm = torch.randperm(total, generator=torch.Generator().manual_seed(s)).tolist()
+        bt = torch.zeros((B, max(max(per), 1)), dtype=torch.int32)
+        it = iter(perm)
+        for b in range(B):
+            for j in range(per[b]):
+                bt[b, j] = next(it)
+        k = rand16((total, page, Hk, D), dt, s + 2)
+        v = rand16((total, page, Hk, D), dt, s + 3)
+        out, lse, _ = _fa().flash_attn_varlen_func(q, k, v, cu_q, cu_k, mq, mk, causal=causal, window_size=window,
+                                                   softcap=softcap, alibi_slopes=slopes, return_attn_probs=True,
+                                                   block_table=bt.cuda(), **extra)
+        o_ref, lse_ref = oracle.varlen_fwd(f64(q), f64(k), f64(v), cu_q.cpu().numpy(), cu_k.cpu().numpy(), mq, mk,
+                                           D ** -0.5, block_table=bt.numpy(), **kw)
+    else:
+        k = rand16((Tk, Hk, D), dt, s + 2).requires_grad_(bwd)
+        v = rand16((Tk, Hk, D), dt, s + 3).requires_grad_(bwd)
+        out, lse, _ = _fa().flash_attn_varlen_func(q, k, v, cu_q, cu_k, mq, mk, causal=causal, window_size=window,
+                                                   softcap=softcap, alibi_slopes=slopes, return_attn_probs=True, **extra)
+        o_ref, lse_ref = oracle.varlen_fwd(f64(q), f64(k), f64(v), cu_q.cpu().numpy(), cu_k.cpu().numpy(), mq, mk,
+                                           D ** -0.5, **kw)
+    _check(f64(out), o_ref, dt, "out", 1.0, desc)
+    _check_lse(f64(lse), lse_ref, "lse", desc)
+    if bwd:
+        dq, dk, dv = torch.autograd.grad(out, (q, k, v), do)
+        g = oracle.varlen_bwd(f64(do), f64(q), f64(k), f64(v), o_ref, lse_ref.astype(np.float64),
+                              cu_q.cpu().numpy(), cu_k.cpu().numpy(), mq, mk, D ** -0.5, **kw)
+        _check(f64(dq), g[0], dt, "dq", 2.0, desc)
+        _check(f64(dk), g[1], dt, "dk", 2.0, desc)
+        _check(f64(dv), g[2], dt, "dv", 2.0, desc)
+    return desc
+
+
+# ------------------------------------------------------------------------------------------------ kvcache
+def _rotary(seqlen_ro, rd, dt):
+    pos = torch.arange(seqlen_ro, dtype=torch.float32)[:, None]
+    inv = 1.0 / (10000 ** (torch.arange(0, rd, 2, dtype=torch.float32) / rd))[None, :]
+    ang = pos * inv
+    return torch.cos(ang).to(DT[dt]).cuda(), torch.sin(ang).to(DT[dt]).cuda()
+
+
+def kvcache_case(rng, idx):
+    B = int(rng.integers(1, 5))
+    Hk = int(rng.choice([1, 2, 4, 8]))
+    Hq = Hk * int(rng.choice([1, 2, 4, 8]))
+    D = int(rng.choice([16, 32, 64, 64, 128, 128, 128, 256]))
+    dt = str(rng.choice(["fp16", "bf16"]))
+    Tq = int(rng.choice([1, 1, 1, 2, 5, 33, 70, 130]))
+    Tn = Tq if rng.random() < 0.7 else 0
+    paged = rng.random() < 0.4
+    page = int(rng.choice([64, 128, 256]))
+    Smax = int(rng.choice([256, 512, 768, 1024]))
+    if Smax < Tn + 64:
+        Smax = 512
+    rd = 0
+    if Tn and rng.random() < 0.5:
+        rd = int(rng.choice([r for r in (16, 32, 64, 128) if r <= D]))
+    inter = bool(rng.random() < 0.5)
+    use_bidx = (not paged) and rng.random() < 0.25
+    use_lp = (not paged) and rng.random() < 0.25
+    causal, window = _mask(rng, Tq, Smax)
+    slopes = None
+    if rng.random() < 0.15:
+        slopes = torch.tensor([0.05 * (i + 1) for i in range(Hq)], dtype=torch.float32, device="cuda")
+    splits = int(rng.choice([0, 0, 1, 2, 3, 5]))
+    group = Hq // Hk
+    fp8 = slopes is None and Tq * group <= 32 and D in (64, 128) and rng.random() < 0.3
+    kd, vd = (0.05, 0.04) if fp8 else (None, None)
+    g = torch.Generator().manual_seed(7000 + idx)
+    lp = torch.randint(0, 17, (B,), generator=g, dtype=torch.int32) if use_lp else None
+    seqlens = torch.randint(1, Smax - Tn - 20, (B,), generator=g, dtype=torch.int32)
+    if rng.random() < 0.3:
+        seqlens[0] = int(rng.choice([1, 63, 64, 65, 255, 256])) if Smax - Tn - 20 > 256 else 1
+    desc = f"kvcache#{idx} B{B} Tq{Tq} Hq{Hq} Hk{Hk} D{D} Smax{Smax} Tn{Tn} {dt} causal={causal} window={window} rd={rd} " \
+           f"inter={inter} bidx={use_bidx} leftpad={use_lp} alibi={slopes is not None} paged={page if paged else 0} " \
+           f"splits={splits} fp8={fp8} seqlens={seqlens.tolist()}"
+    s = 9000 + 10 * idx
+    q = rand16((B, Tq, Hq, D), dt, s + 1)
+    bt = None
+    if paged:
+        pps = Smax // page
+        nblk = B * pps + 3
+        kc = rand16((nblk, page, Hk, D), dt, s + 2)
+        vc = rand16((nblk, page, Hk, D), dt, s + 3)
+        bt = torch.randperm(nblk, generator=g)[: B * pps].reshape(B, pps).to(torch.int32)
+        bidx = None
+    else:
+        Bc = B + 2 if use_bidx else B
+        kc = rand16((Bc, Smax, Hk, D), dt, s + 2)
+        vc = rand16((Bc, Smax, Hk, D), dt, s + 3)
+        bidx = torch.tensor([Bc - 1 - i for i in range(B)], dtype=torch.int32) if use_bidx else None
+    knew = rand16((B, Tn, Hk, D), dt, s + 4) if Tn else None
+    vnew = rand16((B, Tn, Hk, D), dt, s + 5) if Tn else None
+    cos, sin = _rotary(Smax + 8, rd, dt) if rd else (None, None)
+    if fp8:
+        kc = (kc.float() * 1.5 / kd).to(torch.float8_e4m3fn)
+        vc = (vc.float() * 1.5 / vd).to(torch.float8_e4m3fn)
+        kc_ref, vc_ref = kc.float().double().cpu().numpy().copy(), vc.float().double().cpu().numpy().copy()
+    else:
+        kc_ref, vc_ref = f64(kc).copy(), f64(vc).copy()
+    out, lse = _fa().flash_attn_with_kvcache(
+        q, kc, vc, k=knew, v=vnew, rotary_cos=cos, rotary_sin=sin, cache_seqlens=seqlens.cuda(),
+        cache_batch_idx=None if bidx is None else bidx.cuda(), cache_leftpad=None if lp is None else lp.cuda(),
+        block_table=None if bt is None else bt.cuda(), causal=causal, window_size=window,
+        rotary_interleaved=inter, alibi_slopes=slopes, num_splits=splits, return_softmax_lse=True,
+        k_descale=kd, v_descale=vd)
+    o_ref, lse_ref = oracle.kvcache_fwd(
+        f64(q), kc_ref, vc_ref, k=None if knew is None else f64(knew), v=None if vnew is None else f64(vnew),
+        rotary_cos=None if cos is None else f64(cos), rotary_sin=None if sin is None else f64(sin),
+        cache_seqlens=seqlens.numpy(), cache_batch_idx=None if bidx is None else bidx.numpy(),
+        cache_leftpad=None if lp is None else lp.numpy(), block_table=None if bt is None else bt.numpy(),
+        causal=causal, window=window, rotary_interleaved=inter,
+        alibi_slopes=None if slopes is None else f64(slopes), io_dtype=dt, k_descale=kd, v_descale=vd)
+    if fp8:
+        # appended rows are stored as fp8 codes: the oracle's cache holds the same codes' values (ties may round apart)
+        kg, vg = kc.float().double().cpu().numpy(), vc.float().double().cpu().numpy()
+        assert (np.abs(kg - kc_ref) <= 0.13 * np.abs(kc_ref) + 2e-3).all(), f"k cache (fp8) differs  [{desc}]"
+        assert (np.abs(vg - vc_ref) <= 0.13 * np.abs(vc_ref) + 2e-3).all(), f"v cache (fp8) differs  [{desc}]"
+        assert (kg != kc_ref).mean() < 2e-3 and (vg != vc_ref).mean() < 2e-3, f"fp8 cache codes differ  [{desc}]"
+        _check(f64(out), o_ref, dt, "out", 1.5, desc)
+        _check_lse(f64(lse), lse_ref, "lse", desc, atol=3e-2)
+        return desc
+    tol = 2.0 ** (-7 if dt == "bf16" else -10)
+    assert np.abs(f64(kc) - kc_ref).max() <= tol * max(1.0, np.abs(kc_ref).max()), f"k cache differs  [{desc}]"
+    assert np.array_equal(f64(vc), vc_ref), f"v cache differs  [{desc}]"
+    _check(f64(out), o_ref, dt, "out", 2.0 if rd else 1.0, desc)
+    _check_lse(f64(lse), lse_ref, "lse", desc, atol=2e-2 if rd else 2e-3)
+    return desc
+
+
+KINDS = {"dense": dense_case, "varlen": varlen_case, "kvcache": kvcache_case,
+         "dense_long": lambda rng, i: dense_case(rng, i, long=True),
+         "varlen_long": lambda rng, i: varlen_case(rng, i, long=True)}
+
+
+KIND_ID = {"dense": 0, "kvcache": 1, "varlen": 2, "dense_long": 3, "varlen_long": 4}
+
+
+def run(kind, seed, n, verbose=False, keep_going=False):
+    rng = np.random.default_rng([seed, KIND_ID[kind]])
+    failures = []
+    for i in range(n):
+        sub = np.random.default_rng(rng.integers(0, 2 ** 31))      # one stream per case: cases reproduce by (seed, i)
+        torch.manual_seed(seed * 100003 + i)
+        try:
+            desc = KINDS[kind](sub, i)
+            if verbose:
+                print("ok  ", desc, flush=True)
+        except Exception as e:                                     # noqa: BLE001 - an API error on a drawn case is a finding too
+            if not keep_going:
+                raise
+            failures.append(f"{kind}#{i}: {type(e).__name__}: {e}")
+            print("FAIL", failures[-1], flush=True)
+    return failures
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--n", type=int, default=100)
+    ap.add_argument("--kinds", default="dense,varlen,kvcache")
+    ap.add_argument("-v", action="store_true")
+    a = ap.parse_args()
+    bad = 0
+    for kind in a.kinds.split(","):
+        t0 = time.time()
+        f = run(kind, a.seed, a.n, verbose=a.v, keep_going=True)
+        bad += len(f)
+        print(f"{kind}: {a.n - len(f)} / {a.n} cases agree with the oracle ({time.time() - t0:.0f} s)", flush=True)
+    sys.exit(1 if bad else 0)
