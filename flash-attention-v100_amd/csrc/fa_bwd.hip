@@ -102,10 +102,13 @@ constexpr int DKV_BN = 128;     // keys per workgroup (32 per wave)
 constexpr int DKV_BQ = FA_DKV_BQ;      // query rows per LDS stage
 
 template <int D> struct DkvSmem {
-    static constexpr int TILE = DKV_BQ * D * 2;         // one Q (or dO) tile
-    static constexpr int STATS = DKV_BQ * 4 * 2;        // lse2 + D, fp32
+    // D = 256: 32-row stages leave 64 KiB in which the waves park their K fragments (see kpark in the kernel)
+    static constexpr int BQ = D > 128 ? 32 : DKV_BQ;
+    static constexpr int TILE = BQ * D * 2;             // one Q (or dO) tile
+    static constexpr int STATS = BQ * 4 * 2;            // lse2 + D, fp32
     static constexpr int STAGE = 2 * TILE + STATS;
-    static constexpr int TOTAL = 2 * STAGE;
+    static constexpr int KPARK = D > 128 ? DKV_BN * D * 2 : 0;
+    static constexpr int TOTAL = 2 * STAGE + KPARK;
 };
 
 // BIAS: 0 none, 1 general (ALiBi / softcap per element), 2 causal ALiBi through the matrix pipe (fa_common.h)
@@ -120,7 +123,8 @@ __global__ void __launch_bounds__(BWD_THREADS, 1) fa_bwd_dkdv_kernel(const KArgs
     constexpr int NDH = D > 128 ? 2 : 1;
     constexpr int ADB = DBLKS / NDH;                     // accumulated 32-column blocks per sweep
     constexpr int CPR = D / 8;
-    constexpr int CHUNKS = DKV_BQ * CPR / BWD_THREADS;
+    constexpr int BQ = DkvSmem<D>::BQ;
+    constexpr int CHUNKS = BQ * CPR / BWD_THREADS;
     constexpr int TILE = DkvSmem<D>::TILE;
     constexpr int STAGE = DkvSmem<D>::STAGE;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -238,13 +242,19 @@ __global__ void __launch_bounds__(BWD_THREADS, 1) fa_bwd_dkdv_kernel(const KArgs
         if (wr >= 0) { const int t = n0 - off - wr; m_lo = t > 0 ? t : 0; }
         if (wl >= 0) { const int t = n_last - off + wl + 1; m_hi = t < m_hi ? t : m_hi; }
     }
-    const int mt0 = m_lo / DKV_BQ;
-    const int mt1 = m_hi > m_lo ? (m_hi + DKV_BQ - 1) / DKV_BQ : mt0;
+    const int mt0 = m_lo / BQ;
+    const int mt1 = m_hi > m_lo ? (m_hi + BQ - 1) / BQ : mt0;
     const int n_tiles = mt1 - mt0;
     const int n_iter = n_tiles * group;
 
     // ---- K, V fragments of my 32 keys: B operands, lane holds X[my_key][16ks + 8g .. +7] ----
-    u32x4 kf[KSTEPS], vf[KSTEPS];
+    // D = 256: 128 K + V fragment registers beside 128 accumulators spilled ~80 registers to scratch.  The K fragments
+    // are parked in LDS instead, in exactly the register image (instruction ks = one contiguous 1-KiB line, lane l at
+    // 16 l: conflict-free, no swizzle); only the owning wave touches its 16 KiB, so no barrier is involved.
+    constexpr bool KPARK = DkvSmem<D>::KPARK > 0;
+    u32x4 kf[KPARK ? 1 : KSTEPS], vf[KSTEPS];
+    char* kpark = smem + 2 * STAGE + wave * (32 * D * 2) + lane * 16;
+    (void)kpark;
     {
         const int64_t kb_off = p.cu_seqlens_k ? 0 : (int64_t)b * p.k_batch_stride;
         const int64_t vb_off = p.cu_seqlens_k ? 0 : (int64_t)b * p.v_batch_stride;
@@ -257,7 +267,9 @@ __global__ void __launch_bounds__(BWD_THREADS, 1) fa_bwd_dkdv_kernel(const KArgs
         for (int ks = 0; ks < KSTEPS; ++ks) {
             u32x4 z = {0, 0, 0, 0};
             const bool okc = ok && 16 * ks + 8 * g < dv;
-            kf[ks] = okc ? *reinterpret_cast<const u32x4*>(kr + 16 * ks) : z;
+            const u32x4 kx = okc ? *reinterpret_cast<const u32x4*>(kr + 16 * ks) : z;
+            if constexpr (KPARK) lds_write_b128(kpark + ks * 1024, kx);
+            else kf[ks] = kx;
             vf[ks] = okc ? *reinterpret_cast<const u32x4*>(vr + 16 * ks) : z;
         }
     }
@@ -272,7 +284,7 @@ __global__ void __launch_bounds__(BWD_THREADS, 1) fa_bwd_dkdv_kernel(const KArgs
     auto load_tile = [&](int it, auto stage_c) {
         constexpr int stage = decltype(stage_c)::value;
         const int gq = it / n_tiles;
-        const int m0 = (mt0 + it - gq * n_tiles) * DKV_BQ;
+        const int m0 = (mt0 + it - gq * n_tiles) * BQ;
         const int h = hk * group + gq;
         const __amdgpu_buffer_rsrc_t q_rsrc = make_rsrc(q_base + (int64_t)h * p.q_head_stride, p.q_row_stride, sg.seqlen_q, dv);
         const __amdgpu_buffer_rsrc_t do_rsrc = make_rsrc(do_base + (int64_t)h * p.do_head_stride, p.do_row_stride, sg.seqlen_q, dv);
@@ -290,12 +302,12 @@ __global__ void __launch_bounds__(BWD_THREADS, 1) fa_bwd_dkdv_kernel(const KArgs
 #pragma unroll
             for (int i = 0; i < CHUNKS; ++i) doreg[i] = buf_load_b128(do_rsrc, do_voff[i], do_soff);
         }
-        if (tid < 2 * DKV_BQ) {
-            const int r = tid & (DKV_BQ - 1);
+        if (tid < 2 * BQ) {
+            const int r = tid & (BQ - 1);
             const int qi = m0 + r;
             statreg = 0.f;
             if (qi < sg.seqlen_q) {
-                if (tid < DKV_BQ) statreg = lse_base[(int64_t)h * p.lse_head_stride + qi] * kLog2e;
+                if (tid < BQ) statreg = lse_base[(int64_t)h * p.lse_head_stride + qi] * kLog2e;
                 else statreg = dsum_base[(int64_t)h * p.lse_head_stride + qi];
             }
         }
@@ -312,7 +324,7 @@ __global__ void __launch_bounds__(BWD_THREADS, 1) fa_bwd_dkdv_kernel(const KArgs
                 lds_write_b128(dos + t_lds[i], doreg[i]);
             }
         }
-        if (tid < 2 * DKV_BQ) st[tid] = statreg;          // [0,64): lse2, [64,128): D
+        if (tid < 2 * BQ) st[tid] = statreg;          // [0,64): lse2, [64,128): D
     };
 
     f32x16 dk_acc[ADB], dv_acc[ADB];
@@ -357,7 +369,10 @@ __global__ void __launch_bounds__(BWD_THREADS, 1) fa_bwd_dkdv_kernel(const KArgs
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks) {
             const u32x4 qa = lds_read_b128(qs + a_rd[ks] + sub * 32 * D * 2);
-            s_acc = E::mfma(qa, kf[ks], s_acc);
+            u32x4 kb;
+            if constexpr (KPARK) kb = lds_read_b128(kpark + ks * 1024);
+            else kb = kf[ks];
+            s_acc = E::mfma(qa, kb, s_acc);
         }
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks) {
@@ -398,7 +413,7 @@ __global__ void __launch_bounds__(BWD_THREADS, 1) fa_bwd_dkdv_kernel(const KArgs
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             lse2[i] = *reinterpret_cast<const f32x4*>(st + sub * 32 + 8 * i + 4 * g);
-            dsum[i] = *reinterpret_cast<const f32x4*>(st + DKV_BQ + sub * 32 + 8 * i + 4 * g);
+            dsum[i] = *reinterpret_cast<const f32x4*>(st + BQ + sub * 32 + 8 * i + 4 * g);
         }
     };
     // sm: P = exp2(S c - lse2), dS = P (dP - D), rounded to 16 bit as the B operands of phase bk
@@ -555,12 +570,12 @@ __global__ void __launch_bounds__(BWD_THREADS, 1) fa_bwd_dkdv_kernel(const KArgs
     };
 
     // dS tiles produced in this step, stored after the step's LDS writes (see compute)
-    u32x4 ds_chunk[DKV_BQ / 32][2];
-    char* ds_tile[DKV_BQ / 32];
+    u32x4 ds_chunk[BQ / 32][2];
+    char* ds_tile[BQ / 32];
     uint32_t ds_pending = 0;
     auto flush_ds = [&]() {
 #pragma unroll
-        for (int sub = 0; sub < DKV_BQ / 32; ++sub)
+        for (int sub = 0; sub < BQ / 32; ++sub)
             if (ds_pending & (1u << sub)) {
                 *reinterpret_cast<u32x4*>(ds_tile[sub]) = ds_chunk[sub][0];
                 *reinterpret_cast<u32x4*>(ds_tile[sub] + 1024) = ds_chunk[sub][1];
@@ -569,9 +584,9 @@ __global__ void __launch_bounds__(BWD_THREADS, 1) fa_bwd_dkdv_kernel(const KArgs
     };
     auto compute = [&](auto stage_c, int it) {
         constexpr int stage = decltype(stage_c)::value;
-        constexpr int NSUB = DKV_BQ / 32;
+        constexpr int NSUB = BQ / 32;
         const int gq = it / n_tiles;
-        const int m0 = (mt0 + it - gq * n_tiles) * DKV_BQ;
+        const int m0 = (mt0 + it - gq * n_tiles) * BQ;
         if (BIAS && p.alibi_slopes) slope = p.alibi_slopes[b * p.alibi_batch_stride + hk * group + gq];
         const char* qs = smem + stage * STAGE;
         const char* dos = qs + TILE;
@@ -606,7 +621,7 @@ __global__ void __launch_bounds__(BWD_THREADS, 1) fa_bwd_dkdv_kernel(const KArgs
                 for (int i = 0; i < 4; ++i) {
                     f32x4 l4[4], d4[4];
                     l4[i] = *reinterpret_cast<const f32x4*>(st + sub * 32 + 8 * i + 4 * g);
-                    d4[i] = *reinterpret_cast<const f32x4*>(st + DKV_BQ + sub * 32 + 8 * i + 4 * g);
+                    d4[i] = *reinterpret_cast<const f32x4*>(st + BQ + sub * 32 + 8 * i + 4 * g);
                     sm_rows(i, q0, nm, l4[i], d4[i], s_acc, dp_acc, pf, dsf);
                     __builtin_amdgcn_sched_barrier(0);
                 }

@@ -1,10 +1,14 @@
-"""fwd / fwd+bwd TFLOP/s across head dims (bf16 causal, 16K tokens per batch x heads fixed)."""
+"""fwd / fwd+bwd TFLOP/s across head dims (bf16 causal, 16K tokens per batch x heads fixed).
+  python tools/bench_headdims.py [D ...]      (default: all)"""
 import os, sys
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, os.path.join(ROOT, "flash-attention-v100_amd")); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import torch, flash_attn
 from bench_configs import timeit
+ONLY = [int(x) for x in sys.argv[1:]]
 for D, H in ((64, 32), (96, 16), (128, 16), (192, 8), (256, 8)):
+    if ONLY and D not in ONLY:
+        continue
     B, S = 8, 4096
     q, k, v = (torch.randn(B, S, H, D, device="cuda", dtype=torch.bfloat16, requires_grad=True) for _ in range(3))
     do = torch.randn(B, S, H, D, device="cuda", dtype=torch.bfloat16)
