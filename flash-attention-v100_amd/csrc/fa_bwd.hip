@@ -120,7 +120,10 @@ __global__ void __launch_bounds__(BWD_THREADS, 1) fa_bwd_dkdv_kernel(const KArgs
     // D = 256: dK / dV are produced in two 128-column halves (two sweeps over the query tiles, S and dP
     // recomputed) - 256 accumulator registers + 128 K/V fragment registers do not fit beside the rest
     // (the one-sweep build spilled 400-900 registers: 10 ms -> see DESIGN.md)
-    constexpr int NDH = D > 128 ? 2 : 1;
+#ifndef FA_DKV_NDH256
+#define FA_DKV_NDH256 2
+#endif
+    constexpr int NDH = D > 128 ? FA_DKV_NDH256 : 1;
     constexpr int ADB = DBLKS / NDH;                     // accumulated 32-column blocks per sweep
     constexpr int CPR = D / 8;
     constexpr int BQ = DkvSmem<D>::BQ;
@@ -169,7 +172,10 @@ __global__ void __launch_bounds__(BWD_THREADS, 1) fa_bwd_dkdv_kernel(const KArgs
     // Q / dO tiles staged through registers (buffer_load -> ds_write after the MFMAs): measured
     // 13 % faster than LDS-DMA for this one-wave-per-SIMD kernel (1.54 vs 1.74 ms), while
     // LDS-DMA wins in the two-wave kernels (fwd, dQ).  D = 256 has no registers to stage through.
-    constexpr bool DMA = D > 128;
+#ifndef FA_DKV_DMA256
+#define FA_DKV_DMA256 1
+#endif
+    constexpr bool DMA = D > 128 && FA_DKV_DMA256;
 #else
     // Q / dO tiles by LDS-DMA (see fa_fwd.hip): instruction `inst` = wave*CHUNKS + i covers
     // ROWS_PI rows, lane -> (row, physical slot); the source offset carries the swizzle.
@@ -283,7 +289,7 @@ __global__ void __launch_bounds__(BWD_THREADS, 1) fa_bwd_dkdv_kernel(const KArgs
     //  one burst at the top of the step.)
     auto load_tile = [&](int it, auto stage_c) {
         constexpr int stage = decltype(stage_c)::value;
-        const int gq = it / n_tiles;
+        const int gq = group == 1 ? 0 : it / n_tiles;     // (a scalar division costs ~150 cycles per step)
         const int m0 = (mt0 + it - gq * n_tiles) * BQ;
         const int h = hk * group + gq;
         const __amdgpu_buffer_rsrc_t q_rsrc = make_rsrc(q_base + (int64_t)h * p.q_head_stride, p.q_row_stride, sg.seqlen_q, dv);
@@ -307,8 +313,9 @@ __global__ void __launch_bounds__(BWD_THREADS, 1) fa_bwd_dkdv_kernel(const KArgs
             const int qi = m0 + r;
             statreg = 0.f;
             if (qi < sg.seqlen_q) {
-                if (tid < BQ) statreg = lse_base[(int64_t)h * p.lse_head_stride + qi] * kLog2e;
-                else statreg = dsum_base[(int64_t)h * p.lse_head_stride + qi];
+                // (no arithmetic on the loaded value here: a use would put an s_waitcnt vmcnt(0) - the full latency of the
+                //  tile loads issued just above - at the top of the step; the log2(e) factor is applied in store_tile)
+                statreg = (tid < BQ ? lse_base : dsum_base)[(int64_t)h * p.lse_head_stride + qi];
             }
         }
     };
@@ -324,7 +331,7 @@ __global__ void __launch_bounds__(BWD_THREADS, 1) fa_bwd_dkdv_kernel(const KArgs
                 lds_write_b128(dos + t_lds[i], doreg[i]);
             }
         }
-        if (tid < 2 * BQ) st[tid] = statreg;          // [0,64): lse2, [64,128): D
+        if (tid < 2 * BQ) st[tid] = tid < BQ ? statreg * kLog2e : statreg;     // [0,BQ): lse2, [BQ,2BQ): D
     };
 
     f32x16 dk_acc[ADB], dv_acc[ADB];
@@ -366,18 +373,36 @@ __global__ void __launch_bounds__(BWD_THREADS, 1) fa_bwd_dkdv_kernel(const KArgs
         } else
 #endif
         {
+        // D = 256: the compiler otherwise reuses one register quad per operand and waits for every LDS read in front of its
+        // MFMA (read, lgkmcnt(0), MFMA: ~70 cycles per MFMA).  A ring of PF operand pairs keeps PF reads in flight.
+#ifndef FA_DKV_PF256
+#define FA_DKV_PF256 4
+#endif
+        constexpr int PF = FA_DKV_PF256, NJ = 2 * KSTEPS;
+        u32x4 ra[PF], rb[PF];
+        auto fetch = [&](int j, u32x4& a_, u32x4& b_) {          // j < KSTEPS: S = Q K^T steps, then dP = dO V^T steps
+            const int ks = j % KSTEPS;
+            a_ = lds_read_b128((j < KSTEPS ? qs : dos) + a_rd[ks] + sub * 32 * D * 2);
+            if (j < KSTEPS) {
+                if constexpr (KPARK) b_ = lds_read_b128(kpark + ks * 1024);
+                else b_ = kf[ks];
+            }
+        };
 #pragma unroll
-        for (int ks = 0; ks < KSTEPS; ++ks) {
-            const u32x4 qa = lds_read_b128(qs + a_rd[ks] + sub * 32 * D * 2);
-            u32x4 kb;
-            if constexpr (KPARK) kb = lds_read_b128(kpark + ks * 1024);
-            else kb = kf[ks];
-            s_acc = E::mfma(qa, kb, s_acc);
+        for (int j = 0; j < PF; ++j) fetch(j, ra[j], rb[j]);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            if (j < KSTEPS) s_acc = E::mfma(ra[j % PF], rb[j % PF], s_acc);
+            else dp_acc = E::mfma(ra[j % PF], vf[j - KSTEPS], dp_acc);
+            if (j + PF < NJ) fetch(j + PF, ra[j % PF], rb[j % PF]);
         }
+        if (KPARK) __builtin_amdgcn_sched_group_barrier(0x100, 2 * PF, 0);
+        else __builtin_amdgcn_sched_group_barrier(0x100, PF, 0);
 #pragma unroll
-        for (int ks = 0; ks < KSTEPS; ++ks) {
-            const u32x4 da = lds_read_b128(dos + a_rd[ks] + sub * 32 * D * 2);
-            dp_acc = E::mfma(da, vf[ks], dp_acc);
+        for (int j = 0; j < NJ; ++j) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (KPARK && j + PF < KSTEPS) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            else if (j + PF < NJ) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
         }
     };
@@ -526,8 +551,11 @@ __global__ void __launch_bounds__(BWD_THREADS, 1) fa_bwd_dkdv_kernel(const KArgs
         for (int t = 0; t < 2; ++t) {
             // rows sub*32 + 16 t + 8 hf + 4 g + rr ; cols 32 d + 16 ((lane>>4)&1) + 4 (lane&3)
             const int row_a = sub * 32 + 16 * t + 4 * g + rr;
+#ifndef FA_DKV_BKPF256
+#define FA_DKV_BKPF256 1
+#endif
 #ifndef FA_DKV_NO_PREFETCH
-            if constexpr (D <= 128) {
+            if constexpr (D <= 128 || FA_DKV_BKPF256) {
             u32x4 af[ADB], bfr[ADB];
 #pragma unroll
             for (int d = 0; d < ADB; ++d) {
@@ -585,7 +613,7 @@ __global__ void __launch_bounds__(BWD_THREADS, 1) fa_bwd_dkdv_kernel(const KArgs
     auto compute = [&](auto stage_c, int it) {
         constexpr int stage = decltype(stage_c)::value;
         constexpr int NSUB = BQ / 32;
-        const int gq = it / n_tiles;
+        const int gq = group == 1 ? 0 : it / n_tiles;     // (a scalar division costs ~150 cycles per step)
         const int m0 = (mt0 + it - gq * n_tiles) * BQ;
         if (BIAS && p.alibi_slopes) slope = p.alibi_slopes[b * p.alibi_batch_stride + hk * group + gq];
         const char* qs = smem + stage * STAGE;
@@ -610,7 +638,10 @@ __global__ void __launch_bounds__(BWD_THREADS, 1) fa_bwd_dkdv_kernel(const KArgs
             asm volatile("s_nop 0" :: "v"(s_acc[0]), "v"(dp_acc[0]));
 #endif
             TMR_ADD(0, t0);
-            if constexpr (D <= 128) {
+#ifndef FA_DKV_SMROWS256
+#define FA_DKV_SMROWS256 0      // the register-lean row-group form (sched_barrier between groups): 1223 vs 641 cycles per step
+#endif
+            if constexpr (D <= 128 || !FA_DKV_SMROWS256) {
                 sm_stats(st, sub, lse2, dsum);
                 sm(q0, needs_mask(q0), lse2, dsum, s_acc, dp_acc, pf, dsf);
             } else {
