@@ -967,9 +967,11 @@ __global__ void __launch_bounds__(BWD_THREADS, D <= 64 ? FA_DKV2_OCC64 : 2) fa_b
         }
         const int qi = q0 + l31;
         const int qc = qi < sg.seqlen_q ? qi : (sg.seqlen_q > 0 ? sg.seqlen_q - 1 : 0);
-        const float x = (g ? dsum_base : lse_base)[(int64_t)h * p.lse_head_stride + qc];
-        stat_out = qi < sg.seqlen_q ? (g ? x : x * kLog2e) : 0.f;
+        // the raw value: any arithmetic on it here would put an s_waitcnt vmcnt(0) - the latency of the tile loads issued
+        // just above - at the top of the stage; stat_fix() is applied where the value is consumed, a stage later
+        stat_out = (g ? dsum_base : lse_base)[(int64_t)h * p.lse_head_stride + qc];
     };
+    auto stat_fix = [&](float x, int q0) { return q0 + l31 < sg.seqlen_q ? (g ? x : x * kLog2e) : 0.f; };
     float statv = 0.f, stat_next = 0.f;
     (void)statv;
     int gq = 0, mt = mt0;                                 // stage it = (q-head gq of the group, 32-row tile mt)
@@ -977,7 +979,7 @@ __global__ void __launch_bounds__(BWD_THREADS, D <= 64 ? FA_DKV2_OCC64 : 2) fa_b
     auto advance = [&](int& gq_x, int& mt_x) { if (++mt_x == mt1) { mt_x = mt0; ++gq_x; } };
     if (NSTG == 2 && n_iter > 0) {
         issue_stage(0, gq_n, mt_n * DKV2_BQ, stat_next);
-        if (wave == 0) reinterpret_cast<float*>(stg_base + 2 * QT)[lane] = stat_next;     // stage 0's statistics
+        if (wave == 0) reinterpret_cast<float*>(stg_base + 2 * QT)[lane] = stat_fix(stat_next, mt_n * DKV2_BQ);     // stage 0's statistics
     }
 #pragma unroll 1
     for (int it = 0; it < n_iter; ++it, advance(gq, mt)) {
@@ -987,6 +989,7 @@ __global__ void __launch_bounds__(BWD_THREADS, D <= 64 ? FA_DKV2_OCC64 : 2) fa_b
             if (it > 0) __syncthreads();                     // everyone is done reading the previous stage
             issue_stage(it, gq, q0, statv);
             __syncthreads();                                 // (hipcc waits for the DMA in front of the barrier)
+            statv = stat_fix(statv, q0);
         } else {
             __syncthreads();                                 // stage it landed (vmcnt(0) before the barrier) and
             advance(gq_n, mt_n);                             // everyone left stage it-1: its buffer is re-filled
@@ -998,7 +1001,7 @@ __global__ void __launch_bounds__(BWD_THREADS, D <= 64 ? FA_DKV2_OCC64 : 2) fa_b
         const bool active = wave_has_keys && (q0 <= w_qhi_max) && (q0 + 31 >= w_qlo_min);
         auto publish_stats = [&]() {      // next stage's statistics -> LDS (loaded a whole stage ago: no wait)
             if (NSTG == 2 && wave == 0 && it + 1 < n_iter)
-                reinterpret_cast<float*>(stg_base + ((it + 1) % NSTG) * STG + 2 * QT)[lane] = stat_next;
+                reinterpret_cast<float*>(stg_base + ((it + 1) % NSTG) * STG + 2 * QT)[lane] = stat_fix(stat_next, mt_n * DKV2_BQ);
         };
         if (!active) { publish_stats(); continue; }
         // ---- S = Q K^T, dP = dO V^T ----
