@@ -1375,8 +1375,10 @@ __global__ void __launch_bounds__(BWD_THREADS, OCC) fa_bwd_dq_kernel(const KArgs
                     const int64_t plane = p.cu_seqlens_q ? (int64_t)p.nheads_q * p.total_q : (int64_t)p.batch * p.nheads_q * p.seqlen_q;
                     const int64_t at = p.cu_seqlens_q ? (int64_t)w.h * p.total_q + sg.q_row0 + my_row
                                                       : ((int64_t)w.b * p.nheads_q + w.h) * p.seqlen_q + my_row;
-                    a.stats_ws[at] = lse == -INFINITY ? INFINITY : lse2;
-                    a.stats_ws[plane + at] = -acc;
+                    if (a.stats_ws) {                         // the asm dK/dV kernel's statistics planes
+                        a.stats_ws[at] = lse == -INFINITY ? INFINITY : lse2;
+                        a.stats_ws[plane + at] = -acc;
+                    }
                 }
             }
         } else if (ok) {
@@ -1791,8 +1793,8 @@ template <typename T, int D>
 static int launch_bwd_td(const KArgs& a, hipStream_t stream) {
     const fa_params& p = a.p;
     const int g_bwd_phase_mask = p.bwd_phases ? p.bwd_phases : 7;      // per call (fa_params::bwd_phases)
-    // asm path (dense, D = 128, statistics workspace): no preprocess launch - the dQ kernel computes D in its prologue,
-    // runs first and leaves softmax_d + the statistics for the dK/dV kernel (saves one pass over dO and a launch)
+    // no preprocess launch when the dQ kernel recomputes S / dP (every path but the dS hand-off): it computes D in its
+    // prologue, runs first and leaves softmax_d (+ the asm dK/dV kernel's statistics planes) behind
     const bool fused_pre = a.fuse_pre != 0;
     // 1. preprocess
     if ((g_bwd_phase_mask & 1) && !fused_pre) {
@@ -1912,8 +1914,11 @@ int launch_bwd(const KArgs& a_in, hipStream_t stream) {
         a.ds_ws = a.p.workspace;
         a.ds_nqb = (a.p.seqlen_q + 31) / 32;
         a.ds_nkb = (a.p.seqlen_k + 31) / 32;
-    } else if (bwd_asm_applicable(a) && a.p.workspace && a.p.workspace_bytes >= bwd_asm_workspace_bytes(a.p)) {
-        a.stats_ws = reinterpret_cast<float*>(a.p.workspace);     // (without a workspace the hipcc kernels run)
+    } else {
+        if (bwd_asm_applicable(a) && a.p.workspace && a.p.workspace_bytes >= bwd_asm_workspace_bytes(a.p))
+            a.stats_ws = reinterpret_cast<float*>(a.p.workspace);     // (without a workspace the hipcc kernels run)
+        // every path whose dQ kernel recomputes S / dP: D = rowsum(dO o O) comes out of that kernel's prologue, it runs
+        // first, and there is no preprocess launch (one pass over dO and O less: 0.10 of 1.97 ms at config 3)
 #ifndef FA_NO_FUSE_PRE
         a.fuse_pre = 1;
 #else
