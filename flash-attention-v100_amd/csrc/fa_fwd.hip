@@ -565,7 +565,9 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : FA_FWD_OCC)) fa_fw
     auto tile_step = [&](auto stage_c, int nb) {
         constexpr int stage = decltype(stage_c)::value;
         const bool has_next = nb + 1 < n_max;
+#ifndef FA_FWD_KO_DMA            // timing knock-out (tools/define_variant.py): no tile loads in the loop - results are garbage
         if (has_next) load_tile(nb + 1, std::integral_constant<int, stage ^ 1>{});
+#endif
         const int n0 = nb * FWD_BN;
         // wave-uniform: does this wave see anything in this tile?
         const bool wave_active = (n0 <= w_hi_max) && (n0 + FWD_BN - 1 >= w_lo_min);
