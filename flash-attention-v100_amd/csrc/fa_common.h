@@ -127,6 +127,12 @@ __device__ __forceinline__ int vtile_off(int row, int col) {
     return (((row >> 2) * (D / 32) + (col >> 5)) << 8) + ((row & 3) << 6) + ((col & 31) << 1);
 }
 
+// (x & m) | (other & ~m) in one v_bitop3_b32 (truth table 0xE2 with a = 0xF0, b = 0xCC, c = 0xAA): the masks' select
+// without a compare, VCC or the wait states between v_cmp and v_cndmask.  m is all ones (keep x) or zero per element.
+__device__ __forceinline__ float select_bits(float x, uint32_t m, uint32_t other) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_bitop3_b32(__builtin_bit_cast(uint32_t, x), m, other, 0xE2));
+}
+
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ float fast_log2(float x) { return __builtin_amdgcn_logf(x); }
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }

@@ -437,19 +437,30 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : FA_FWD_OCC)) fa_fw
         }
         const bool need_mask = (n0 + FWD_BN - 1 > w_hi_min) || (n0 < w_lo_max);
         if (need_mask) {
-            // the key of register (kb, r) is n0 + 4 g + c with c a compile-time constant: one unsigned
-            // compare of (c - lo_t) against the band width instead of rebuilding j per element
-            // (an empty row, hi < lo, is folded into the operands: width 0 against a position that never matches -
-            // a separate `empty ||` cost one scalar OR per element)
-            const bool empty = hi < lo;
-            const int lo_t = empty ? 0x3fffffff : lo - n0 - 4 * g;
-            const uint32_t width = empty ? 0u : (uint32_t)(hi - lo);
+            // the key of register (kb, r) is n0 + 4 g + c with c a compile-time constant: the lane builds the visibility
+            // bits of its row for this tile once (bit c set <=> lo <= n0 + 4 g + c <= hi; one 32-bit word per 32-key
+            // block), and every element costs a sign-extending bit extract and a three-input bit op (v_bfe_i32,
+            // v_bitop3_b32) - no compare, no VCC, none of the wait states hipcc puts between v_cmp and v_cndmask
+            // (4 issue slots per element before, 2 now)
+            const int lc = lo - n0 - 4 * g;                                   // visible positions [lc, hc)
+            const int hc = hi < lo ? lc : hi - n0 - 4 * g + 1;
+            uint32_t visw[FWD_NKB];
+#pragma unroll
+            for (int kb = 0; kb < FWD_NKB; ++kb) {
+                int l = lc - 32 * kb, h = hc - 32 * kb;
+                l = l < 0 ? 0 : (l > 32 ? 32 : l);
+                h = h < 0 ? 0 : (h > 32 ? 32 : h);
+                const uint32_t below_h = h >= 32 ? ~0u : ((1u << h) - 1u);
+                const uint32_t below_l = l >= 32 ? ~0u : ((1u << l) - 1u);
+                visw[kb] = below_h & ~below_l;
+            }
 #pragma unroll
             for (int kb = 0; kb < FWD_NKB; ++kb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int cpos = kb * 32 + (r & 3) + 8 * (r >> 2);
-                    if ((uint32_t)(cpos - lo_t) > width) sacc[kb][r] = -INFINITY;
+                    const int cpos = (r & 3) + 8 * (r >> 2);
+                    const uint32_t m = (uint32_t)((int32_t)(visw[kb] << (31 - cpos)) >> 31);
+                    sacc[kb][r] = select_bits(sacc[kb][r], m, 0xff800000u);
                 }
         }
         // ---- online softmax (log2 domain) with deferred rescale ----
@@ -461,6 +472,9 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : FA_FWD_OCC)) fa_fw
 #pragma unroll
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[kb][r]);
         mx = xhalf_max(mx) * c;
+#ifdef FA_FWD_KO_MAX             // timing knock-out: no row maximum (the compiler drops the max tree)
+        mx = m_run == -INFINITY ? 0.f : m_run;
+#endif
         if (BIAS) mx += shift;
         // keep the old max unless some row of the wave would exceed it by > 2^THR
         // (NaN-safe: -inf - -inf compares false -> takes the rescale path)
@@ -482,7 +496,11 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : FA_FWD_OCC)) fa_fw
         for (int kb = 0; kb < FWD_NKB; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
+#ifdef FA_FWD_KO_EXP             // timing knock-out: no exp2
+                const float e = fmaf(sacc[kb][r], c, -ms);
+#else
                 const float e = fast_exp2(fmaf(sacc[kb][r], c, -ms));
+#endif
                 sacc[kb][r] = e;
                 psum += e;
             }
@@ -571,7 +589,9 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : FA_FWD_OCC)) fa_fw
         const int n0 = nb * FWD_BN;
         // wave-uniform: does this wave see anything in this tile?
         const bool wave_active = (n0 <= w_hi_max) && (n0 + FWD_BN - 1 >= w_lo_min);
+#ifndef FA_FWD_KO_COMPUTE        // timing knock-out: loads and barriers only
         if (wave_active) compute_tile(stage_c, nb);
+#endif
         if (has_next) store_tile(std::integral_constant<int, stage ^ 1>{});
         __syncthreads();
     };
