@@ -137,7 +137,10 @@ def dense_case(rng, idx, long=False):
     _check_lse(f64(lse), lse_ref, "lse", desc)
     if bwd:
         dq, dk, dv = torch.autograd.grad(out, (q, k, v), do)
-        g = oracle.attn_bwd(t(do), t(q), t(k), t(v), o_ref, lse_ref.astype(np.float64), D ** -0.5, **kw)
+        # the backward's inputs are the SAVED 16-bit O and the fp32 LSE of the forward (D = rowsum(dO o O) "from the saved
+        # 16-bit O", oracle.attn_bwd): with the unrounded o_ref a two-key sequence, whose dQ is a small difference, shows
+        # the rounding of O as a few per cent of |dQ|
+        g = oracle.attn_bwd(t(do), t(q), t(k), t(v), t(out), lse_ref.astype(np.float64), D ** -0.5, **kw)
         m = 3.0 if pdrop else 2.0
         _check(t(dq), g[0], dt, "dq", m, desc)
         _check(t(dk), g[1], dt, "dk", m, desc)
@@ -216,7 +219,7 @@ def varlen_case(rng, idx, long=False):
     _check_lse(f64(lse), lse_ref, "lse", desc)
     if bwd:
         dq, dk, dv = torch.autograd.grad(out, (q, k, v), do)
-        g = oracle.varlen_bwd(f64(do), f64(q), f64(k), f64(v), o_ref, lse_ref.astype(np.float64),
+        g = oracle.varlen_bwd(f64(do), f64(q), f64(k), f64(v), f64(out), lse_ref.astype(np.float64),
                               cu_q.cpu().numpy(), cu_k.cpu().numpy(), mq, mk, D ** -0.5, **kw)
         _check(f64(dq), g[0], dt, "dq", 2.0, desc)
         _check(f64(dk), g[1], dt, "dk", 2.0, desc)
