@@ -18,7 +18,9 @@ Besides the contract fields the JSON line carries
                     that duration vs the 2.5 PFLOP/s dense bf16 MFMA peak; durations measured here with HIP events on
                     the stream the kernels run on (torch's current stream).  `traffic` is NOT measured in this run: it
                     is the HBM byte count of the committed rocprofv3 PMC passes (`traffic_source` names the file);
-  kernels         - the same for every kernel of the step (fwd, bwd dK/dV, bwd dQ, preprocess);
+  kernels         - the same for every kernel of the step (fwd, bwd dK/dV, bwd dQ): median and min over individually
+                    evented launches, taken right behind the timed steps; `timing.sum_over_step` compares their sum
+                    with ms_per_step (tests/test_bench_contract.py fails a recorded line where they differ by > 3 %);
   other_configs   - BASELINE configs 3, 4 (fp8 and fp16 KV) and the config-5 shard, measured in the same run (rank 0);
   strong_scaling_config5 - BASELINE configs[4]: dense fwd bf16 causal + ALiBi, B64 H32 S8192 D128 with the 32 heads
                     sharded over the N ranks (flash_attn_mi355.sharding.shard_units / shard_alibi): total TFLOP/s at
@@ -50,19 +52,31 @@ def fwd_flops(c):
     return f * (0.5 if c["causal"] else 1.0)
 
 
-def event_time_ms(fn, iters, warm=1):
-    """Average duration of `fn` (kernel launches only) over `iters` back-to-back calls."""
-    s = torch.cuda.Event(enable_timing=True)
-    e = torch.cuda.Event(enable_timing=True)
+def event_times_ms(fn, iters, warm=1):
+    """GPU-side durations of `iters` individually-evented calls of `fn` (HIP events on torch's current stream = the
+    stream the kernels are launched on; no host synchronisation between the calls, so the GPU stays busy)."""
     for _ in range(warm):
         fn()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
     torch.cuda.synchronize()
-    s.record()
-    for _ in range(iters):
+    for s, e in evs:
+        s.record()
         fn()
-    e.record()
+        e.record()
     torch.cuda.synchronize()
-    return s.elapsed_time(e) / iters
+    return sorted(s.elapsed_time(e) for s, e in evs)
+
+
+def med_min(ts):
+    """(median, min) of a sorted list - the reference's protocol reports the median (test.py:87-100)."""
+    n = len(ts)
+    med = ts[n // 2] if n % 2 else 0.5 * (ts[n // 2 - 1] + ts[n // 2])
+    return med, ts[0]
+
+
+def event_time_ms(fn, iters, warm=1):
+    """Median duration of `fn` over `iters` individually-evented calls."""
+    return med_min(event_times_ms(fn, iters, warm))[0]
 
 
 # ------------------------------------------------------------------------------------------------ CPU baseline
@@ -305,6 +319,26 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = world * step_flops / (elapsed / args.steps) / 1e12
 
+    # ---- per-kernel durations (rank 0; HIP events on the launch stream), right behind the timed steps and BEFORE the
+    #      28 ms config-5 launches, so that they are taken in the power / clock state the steps ran in ------------------
+    kern, kmin = {}, {}
+    if rank == 0:
+        it = 30
+        with torch.no_grad():
+            kern["fwd"], kmin["fwd"] = med_min(event_times_ms(lambda: flash_attn.flash_attn_func(q, k, v, causal=c["causal"]), it, warm=3))
+        o = flash_attn.flash_attn_func(q, k, v, causal=c["causal"])
+        # which backward kernels run follows from the gradients asked for (needs_input_grad -> fa_bwd with dq == NULL or
+        # dk == dv == NULL): (q,) = the dQ kernel alone, (k, v) = preprocess + dK/dV kernel, (q, k, v) = dQ + dK/dV kernels
+        for name, ins in (("bwd_all", (q, k, v)), ("bwd_dq", (q,)), ("bwd_dkdv_pre", (k, v))):
+            kern[name], kmin[name] = med_min(event_times_ms(lambda: torch.autograd.grad(o, ins, do, retain_graph=True), it, warm=3))
+
+        def fb():
+            oo = flash_attn.flash_attn_func(q, k, v, causal=c["causal"])
+            oo.backward(do)
+            q.grad = k.grad = v.grad = None
+        kern["step"], kmin["step"] = med_min(event_times_ms(fb, it, warm=3))
+        del o
+
     # ---- strong scaling, BASELINE configs[4]: every rank takes 32 / N heads of all 64 batches ----------------------
     strong = None
     if not args.no_other_configs:
@@ -321,24 +355,13 @@ def main():
                   "n_gpus": world, "batch_per_gpu": Bs, "heads_per_gpu": Hs, "ms": round(ms5max, 4),
                   "tflops_total": round(total5 / ms5max / 1e9, 1),
                   "frac_of_mfma_peak": round(total5 / ms5max / 1e9 / (world * PEAK_BF16_TFLOPS), 4), "scaling": "strong"}
-        q, k, v, do = mk(H), mk(Hk), mk(Hk), mk(H)
-        q.requires_grad_(True); k.requires_grad_(True); v.requires_grad_(True)
 
     out = None
     if rank == 0:
-        # ---- per-kernel durations (HIP events on the launch stream) --------------------
-        it = 20
-        with torch.no_grad():
-            t_fwd = event_time_ms(lambda: flash_attn.flash_attn_func(q, k, v, causal=c["causal"]), it)
-        o = flash_attn.flash_attn_func(q, k, v, causal=c["causal"])
-
-        def bwd_only():
-            torch.autograd.grad(o, (q, k, v), do, retain_graph=True)
-
-        kern = {}
-        for name, mask in (("bwd_preprocess", 1), ("bwd_dkdv", 2), ("bwd_dq", 4), ("bwd_all", 7)):
-            with fi.bwd_phases(mask):               # per call, through fa_params::bwd_phases
-                kern[name] = event_time_ms(bwd_only, it)
+        # the dK/dV kernel's own duration: the full backward launches exactly two kernels (dQ, then dK/dV)
+        kern["bwd_dkdv"] = kern["bwd_all"] - kern["bwd_dq"]
+        kmin["bwd_dkdv"] = kmin["bwd_all"] - kmin["bwd_dq"]
+        t_fwd = kern["fwd"]
         pairs_flops = ff / 2.0            # one GEMM over the visible pairs = 2*D*pairs
         # algorithmic FLOPs: fwd 2 GEMMs; bwd 5 GEMMs split as dK/dV kernel 4 (S, dP, dV, dK)
         # and dQ kernel 1 (its S/dP recomputation is overhead, not algorithmic work).
@@ -347,15 +370,24 @@ def main():
         kernels = {}
         for name in ("fwd", "bwd_dkdv", "bwd_dq"):
             ach = alg[name] / (dur[name] * 1e-3) / 1e12
-            kernels[name] = {"ms": round(dur[name], 4), "algorithmic_tflop": round(alg[name] / 1e12, 5),
+            kernels[name] = {"ms": round(dur[name], 4), "ms_min": round(kmin[name], 4), "algorithmic_tflop": round(alg[name] / 1e12, 5),
                              "achieved": round(ach, 1), "frac": round(ach / PEAK_BF16_TFLOPS, 4)}
-        kernels["bwd_preprocess"] = {"ms": round(kern["bwd_preprocess"], 4),
-                                     "note": "no separate launch on the asm path (FA_BWD_ASM != 0): D = rowsum(dO o O) is computed in "
-                                             "the dQ kernel's prologue; this figure is the host cost of an empty call"}
-        kernels["bwd_all"] = {"ms": round(kern["bwd_all"], 4),
+        kernels["bwd_dkdv"]["note"] = "median(bwd, dq + dk + dv) - median(bwd, dq only): the full backward is these two launches"
+        kernels["bwd_dkdv_plus_preprocess"] = {
+            "ms": round(kern["bwd_dkdv_pre"], 4), "ms_min": round(kmin["bwd_dkdv_pre"], 4),
+            "note": "backward asked for dk, dv only: the dQ kernel (and its fused row-dot) does not run, so this is the "
+                    "preprocess kernel + the dK/dV kernel"}
+        kernels["bwd_all"] = {"ms": round(kern["bwd_all"], 4), "ms_min": round(kmin["bwd_all"], 4),
                               "achieved": round(2.5 * ff / (kern["bwd_all"] * 1e-3) / 1e12, 1)}
+        kernels["step_evented"] = {"ms": round(kern["step"], 4), "ms_min": round(kmin["step"], 4),
+                                   "achieved": round(step_flops / (kern["step"] * 1e-3) / 1e12, 1),
+                                   "note": "one fwd + bwd through autograd, individually evented (median / min of 30)"}
+        sum_k = kern["fwd"] + kern["bwd_all"]
+        kernels["timing"] = {"statistic": "median (ms) and min (ms_min) over 30 individually-evented launches, HIP events on the launch stream",
+                             "sum_of_kernels_ms": round(sum_k, 4), "ms_per_step": round(ms_per_step, 4),
+                             "sum_over_step": round(sum_k / ms_per_step, 4)}
         dom = max(("fwd", "bwd_dkdv", "bwd_dq"), key=lambda n: dur[n])
-        fwd_kernel = "fa_fwd_ws_kernel" if os.environ.get("FA_FWD_WS") == "1" else "fa_fwd_asm_kernel"
+        fwd_kernel = "fa_fwd_kernel" if os.environ.get("FA_FWD_ASM") == "0" else "fa_fwd_asm_kernel"
         dkdv_kernel = "fa_bwd_dkdv2_kernel" if os.environ.get("FA_BWD_ASM") == "0" else "fa_bwd_dkdv_asm_kernel"
         roofline = {"bound": "mfma", "kernel": {"fwd": fwd_kernel, "bwd_dkdv": dkdv_kernel,
                                                   "bwd_dq": "fa_bwd_dq_kernel"}[dom],
@@ -381,7 +413,6 @@ def main():
         if strong is not None:
             out["strong_scaling_config5"] = strong
         if not args.no_other_configs:
-            del q, k, v, do, o
             torch.cuda.empty_cache()
             oc = {"config3": config3(flash_attn, dev)}
             torch.cuda.empty_cache()

@@ -64,6 +64,7 @@ static int check_common(const fa_params& p, bool need_out) {
     FA_CHECK(p.q && (no_keys || (p.k && p.v)), "q, k, v must not be NULL");
     FA_CHECK(!need_out || (p.o && p.lse), "o and lse must not be NULL");
     FA_CHECK(p.dtype == FA_FP16 || p.dtype == FA_BF16, "q must be fp16 or bf16");
+    FA_CHECK(p.reserved0 == 0, "fa_params::reserved0 must be 0 (zero-initialise the struct)");
     FA_CHECK(p.batch > 0, "batch size must be positive");
     FA_CHECK(p.head_dim <= 256, "head dimension must be <= 256");
     FA_CHECK(p.head_dim % 8 == 0, "head dimension must be multiple of 8");
@@ -206,7 +207,7 @@ int fa_fwd_kvcache(const fa_params* pp, void* stream) {
     if (p.rotary_dim > 0) {
         FA_CHECK(p.k_new, "If rotary cos/sin are provided, new key / value to be appended to KV cache must also be provided");
         FA_CHECK(p.rotary_cos && p.rotary_sin, "rotary_cos and rotary_sin must both be given");
-        FA_CHECK(p.rotary_dim <= p.head_dim, "rotary_dim must be <= head_dim");
+        FA_CHECK(p.rotary_dim <= (p.head_dim_v > 0 ? p.head_dim_v : p.head_dim), "rotary_dim must be <= headdim");
         FA_CHECK(p.rotary_dim % 16 == 0, "rotary_dim must be divisible by 16");
         // every position the kernels can touch is < the cache capacity (append and rotation are range-guarded)
         FA_CHECK(p.seqlen_ro >= p.seqlen_k, "rotary_cos / rotary_sin must cover the cache capacity (seqlen_ro >= seqlen_k)");
@@ -240,7 +241,8 @@ int fa_bwd(const fa_params* pp, void* stream) {
     p.block_table = nullptr;
     int rc = check_common(p, true);
     if (rc) return rc;
-    FA_CHECK(p.dout && p.dq && p.dk && p.dv && p.softmax_d, "dout, dq, dk, dv, softmax_d must not be NULL");
+    FA_CHECK(p.dout && p.softmax_d, "dout and softmax_d must not be NULL");
+    FA_CHECK((p.dk == nullptr) == (p.dv == nullptr), "dk and dv must be given (or left NULL) together");
     FA_CHECK(p.kv_dtype == p.dtype, "k/v must have the same dtype as q");
     if (p.seqlen_q == 0 && p.seqlen_k == 0) return FA_OK;
     normalize(p, false);
@@ -257,7 +259,8 @@ int fa_varlen_bwd(const fa_params* pp, void* stream) {
     p.block_table = nullptr;
     int rc = check_common(p, true);
     if (rc) return rc;
-    FA_CHECK(p.dout && p.dq && p.dk && p.dv && p.softmax_d, "dout, dq, dk, dv, softmax_d must not be NULL");
+    FA_CHECK(p.dout && p.softmax_d, "dout and softmax_d must not be NULL");
+    FA_CHECK((p.dk == nullptr) == (p.dv == nullptr), "dk and dv must be given (or left NULL) together");
     FA_CHECK(p.cu_seqlens_q && p.cu_seqlens_k, "cu_seqlens_q and cu_seqlens_k are required");
     FA_CHECK(p.kv_dtype == p.dtype, "k/v must have the same dtype as q");
     if (p.total_q == 0) {
@@ -265,7 +268,7 @@ int fa_varlen_bwd(const fa_params* pp, void* stream) {
         const int64_t rows = p.total_k;
         const size_t width = (size_t)(p.head_dim_v > 0 ? p.head_dim_v : p.head_dim) * 2;
         hipStream_t s = static_cast<hipStream_t>(stream);
-        for (int h = 0; h < p.nheads_k && rows > 0; ++h) {
+        for (int h = 0; h < p.nheads_k && rows > 0 && p.dk; ++h) {
             if (hipMemset2DAsync(reinterpret_cast<uint16_t*>(p.dk) + (int64_t)h * p.dk_head_stride, (size_t)p.dk_row_stride * 2, 0, width, (size_t)rows, s) != hipSuccess ||
                 hipMemset2DAsync(reinterpret_cast<uint16_t*>(p.dv) + (int64_t)h * p.dv_head_stride, (size_t)p.dv_row_stride * 2, 0, width, (size_t)rows, s) != hipSuccess)
                 return fail(FA_ERR_LAUNCH, "hipMemset2DAsync(dk / dv) failed");

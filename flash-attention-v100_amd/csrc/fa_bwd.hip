@@ -1350,7 +1350,7 @@ __global__ void __launch_bounds__(BWD_THREADS, OCC) fa_bwd_dq_kernel(const KArgs
         if (a.fuse_pre) {
             // D = rowsum(dO o O) here instead of in a preprocess launch (dense asm path: this kernel runs FIRST and
             // leaves softmax_d and the dK/dV kernel's statistics behind): the lane holds half of its row's dO already
-            const int64_t ob_off = (int64_t)w.b * p.o_batch_stride;
+            const int64_t ob_off = p.cu_seqlens_q ? 0 : (int64_t)w.b * p.o_batch_stride;
             const uint16_t* orow = reinterpret_cast<const uint16_t*>(p.o) + ob_off + (sg.q_row0 + my_row) * p.o_row_stride +
                                    (int64_t)w.h * p.o_head_stride + 8 * g;
             float acc = 0.f;
@@ -1792,7 +1792,8 @@ extern "C" int fa_debug_read_timers(unsigned long long* out, int n) {
 template <typename T, int D>
 static int launch_bwd_td(const KArgs& a, hipStream_t stream) {
     const fa_params& p = a.p;
-    const int g_bwd_phase_mask = p.bwd_phases ? p.bwd_phases : 7;      // per call (fa_params::bwd_phases)
+    // outputs the caller did not ask for are not computed (include/fa_mi355.h: dq == NULL, dk == dv == NULL)
+    const int g_bwd_phase_mask = 1 | (p.dk ? 2 : 0) | (p.dq ? 4 : 0);
     // no preprocess launch when the dQ kernel recomputes S / dP (every path but the dS hand-off): it computes D in its
     // prologue, runs first and leaves softmax_d (+ the asm dK/dV kernel's statistics planes) behind
     const bool fused_pre = a.fuse_pre != 0;
@@ -1910,7 +1911,7 @@ int launch_bwd(const KArgs& a_in, hipStream_t stream) {
     a.stats_ws = nullptr;
     a.fuse_pre = 0;
     const size_t need = bwd_ds_workspace_bytes(a.p);
-    if (need > 0 && a.p.workspace && a.p.workspace_bytes >= need) {
+    if (need > 0 && a.p.dq && a.p.dk && a.p.workspace && a.p.workspace_bytes >= need) {
         a.ds_ws = a.p.workspace;
         a.ds_nqb = (a.p.seqlen_q + 31) / 32;
         a.ds_nkb = (a.p.seqlen_k + 31) / 32;
@@ -1924,6 +1925,12 @@ int launch_bwd(const KArgs& a_in, hipStream_t stream) {
 #else
         if (a.p.cu_seqlens_q) a.stats_ws = nullptr;      // (A/B build: the preprocess kernel only knows the dense statistics layout)
 #endif
+        if (!a.p.dq) {
+            // dQ not requested: its kernel - and with it the fused row-dot - does not run, so the preprocess kernel
+            // provides softmax_d and the statistics planes (dense layout only; packed sequences take the hipcc dK/dV kernel)
+            a.fuse_pre = 0;
+            if (a.p.cu_seqlens_q) a.stats_ws = nullptr;
+        }
     }
     const bool bf = a.p.dtype == FA_BF16;
     switch (a.p.head_dim) {

@@ -10,6 +10,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include "fa_mi355.h"
 
 namespace fa {
@@ -301,15 +302,22 @@ static inline int work_grid(int batch, int nheads_q, int nheads_k, int n_qblocks
     return 8 * upx * (nheads_q / nheads_k) * n_qblocks;
 }
 
-// Raise a kernel's dynamic-LDS limit ONCE per instantiation (the static lives in the expansion site, which sits in a
-// per-instantiation template function), not on every launch.
-#define FA_SET_LDS_ONCE(kern, bytes)                                                                              \
-    do {                                                                                                          \
-        static bool fa_attr_done_ = false;                                                                        \
-        if (!fa_attr_done_) {                                                                                     \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)); \
-            fa_attr_done_ = true;                                                                                 \
-        }                                                                                                         \
+// Raise a kernel's dynamic-LDS limit once per instantiation AND DEVICE: the attribute belongs to the device's copy of
+// the function, and one process may drive several GPUs (the Python layer wraps every call in torch.cuda.device(q.device)).
+// `done` is a per-instantiation bit mask over device ordinals (devices >= 64 set the attribute on every launch); a failed
+// hipFuncSetAttribute leaves the bit clear and is reported by the hipGetLastError() check behind the launch (fa_api.hip).
+static inline void fa_set_max_lds(std::atomic<uint64_t>& done, const void* kern, int bytes) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return;
+    const uint64_t bit = dev < 64 ? (1ull << dev) : 0;
+    if (bit && (done.load(std::memory_order_acquire) & bit)) return;
+    if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess && bit)
+        done.fetch_or(bit, std::memory_order_release);
+}
+#define FA_SET_LDS_ONCE(kern, bytes)                                                     \
+    do {                                                                                 \
+        static std::atomic<uint64_t> fa_attr_done_{0};   /* one per expansion site */     \
+        fa_set_max_lds(fa_attr_done_, reinterpret_cast<const void*>(kern), (int)(bytes)); \
     } while (0)
 
 // Host-side launch args: the ABI struct plus derived values.

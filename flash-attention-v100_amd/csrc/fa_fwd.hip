@@ -640,12 +640,7 @@ static int launch_fwd_td(const KArgs& a, bool paged, hipStream_t stream) {
 #define FA_LAUNCH(BIAS, PAGED, DROP)                                                            \
     do {                                                                                        \
         auto kern = fa_fwd_kernel<T, D, BIAS, PAGED, DROP>;                                     \
-        static bool attr_done = false;             /* once per instantiation */                \
-        if (!attr_done) {                                                                       \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                      \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);   \
-            attr_done = true;                                                                   \
-        }                                                                                       \
+        FA_SET_LDS_ONCE(kern, smem);               /* once per instantiation and device */    \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(FWD_THREADS), smem, stream, a);               \
     } while (0)
     const bool drop = a.p.p_dropout > 0.f;
@@ -664,7 +659,6 @@ static int launch_fwd_td(const KArgs& a, bool paged, hipStream_t stream) {
 
 bool fwd_asm_applicable(const KArgs& a);
 int launch_fwd_asm(const KArgs& a, hipStream_t stream);
-int launch_fwd_ws(const KArgs& a, hipStream_t stream);
 
 // FA_FWD_ASM=0 (read once, at the first call) keeps every shape on fa_fwd_kernel: the A/B switch for the
 // hand-scheduled D = 128 path of fa_fwd_asm.hip.
@@ -673,15 +667,8 @@ static bool fwd_asm_enabled() {
     return on;
 }
 
-// FA_FWD_WS=1: take the warp-specialised kernel (fa_fwd_ws.hip; same applicability, currently slower - see DESIGN.md)
-// instead of the one-wave-per-SIMD asm kernel.
-static bool fwd_ws_enabled() {
-    static const bool on = [] { const char* e = getenv("FA_FWD_WS"); return e && e[0] == '1'; }();
-    return on;
-}
-
 int launch_fwd(const KArgs& a, hipStream_t stream) {
-    if (fwd_asm_enabled() && fwd_asm_applicable(a)) return fwd_ws_enabled() ? launch_fwd_ws(a, stream) : launch_fwd_asm(a, stream);
+    if (fwd_asm_enabled() && fwd_asm_applicable(a)) return launch_fwd_asm(a, stream);
     const bool paged = a.p.block_table != nullptr;
     const bool bf = a.p.dtype == FA_BF16;
     switch (a.p.head_dim) {

@@ -25,28 +25,6 @@ from ._lib import FaParams
 
 _DTYPES = {torch.float16: _lib.FA_FP16, torch.bfloat16: _lib.FA_BF16}
 
-import contextlib
-
-
-class _Measure:
-    bwd_phases = 0          # process-wide on the PYTHON side only (autograd runs backward on its own thread);
-                            # the library itself takes the mask per call (fa_params::bwd_phases)
-
-
-_TLS = _Measure
-
-
-@contextlib.contextmanager
-def bwd_phases(mask: int):
-    """Measurement aid (bench.py, tools/): inside the block the backward ops launch only the selected kernels
-    (bit 0 preprocess, bit 1 dK/dV, bit 2 dQ)."""
-    old = _Measure.bwd_phases
-    _Measure.bwd_phases = int(mask)
-    try:
-        yield
-    finally:
-        _Measure.bwd_phases = old
-
 
 def maybe_contiguous(x):
     return x.contiguous() if x is not None and not x.is_contiguous() else x
@@ -187,7 +165,6 @@ def _base_params(q, dtype, scale, causal, window_size, softcap):
     p.is_causal = int(bool(causal))
     p.window_left, p.window_right = int(window_size[0]), int(window_size[1])
     p.k_descale = p.v_descale = 1.0
-    p.bwd_phases = getattr(_TLS, "bwd_phases", 0)
     return p
 
 
@@ -242,20 +219,25 @@ def _dense_forward(q, k, v, dropout_p, softmax_scale, causal, window_size, softc
 
 def _dense_backward(dout, q_, k_, v_, out_, lse, alibi_slopes, dropout_p, softmax_scale, causal,
                     window_size, softcap, rng, dq_, dk_, dv_):
-    """One fa_bwd call; dq_/dk_/dv_ are caller-allocated [B, S, H, dpad] views (written in place)."""
+    """One fa_bwd call; dq_/dk_/dv_ are caller-allocated [B, S, H, dpad] views (written in place).  dq_ = None, or
+    dk_ = dv_ = None, skips that gradient's kernel (autograd's needs_input_grad)."""
     B, M, H_Q, dpad = q_.shape
     N, H_K = k_.shape[1], k_.shape[2]
     dout_ = _prep(dout, dpad)
     softmax_d = torch.empty((B, H_Q, M), dtype=torch.float32, device=q_.device)
+    if (dk_ is None) != (dv_ is None):
+        raise RuntimeError("dk and dv are computed together: pass both or neither")
     if q_.numel() == 0:                                  # no queries: nothing flows into K / V
-        dk_.zero_(); dv_.zero_()
+        if dk_ is not None:
+            dk_.zero_(); dv_.zero_()
         return softmax_d
     p = _base_params(q_, q_.dtype, softmax_scale, causal, window_size, softcap)
     p.q, p.k, p.v, p.o, p.lse = _ptr(q_), _ptr(k_), _ptr(v_), _ptr(out_), _ptr(lse)
     p.dout, p.dq, p.dk, p.dv, p.softmax_d = _ptr(dout_), _ptr(dq_), _ptr(dk_), _ptr(dv_), _ptr(softmax_d)
     for name, t in (("q", q_), ("k", k_), ("v", v_), ("o", out_), ("do", dout_),
                     ("dq", dq_), ("dk", dk_), ("dv", dv_)):
-        _set3(p, name, t, "bshd")
+        if t is not None:                               # a gradient nobody needs: NULL -> its kernel does not run
+            _set3(p, name, t, "bshd")
     p.lse_batch_stride, p.lse_head_stride = lse.stride(0), lse.stride(1)
     p.batch, p.nheads_q, p.nheads_k = B, H_Q, H_K
     p.seqlen_q, p.seqlen_k = M, N
@@ -302,11 +284,14 @@ class FlashAttnFunc(torch.autograd.Function):
     def backward(ctx, dout, *args):
         q_, k_, v_, out_, lse, alibi_slopes = ctx.saved_tensors
         d = ctx.head_size_og
-        dq_, dk_, dv_ = torch.empty_like(q_), torch.empty_like(k_), torch.empty_like(v_)
-        dq_, dk_, dv_ = (_prep(t, q_.shape[-1]) for t in (dq_, dk_, dv_))
+        need_q, need_kv = ctx.needs_input_grad[0], ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        new = lambda t: _prep(torch.empty_like(t), q_.shape[-1])
+        dq_ = new(q_) if need_q else None
+        dk_, dv_ = (new(k_), new(v_)) if need_kv else (None, None)
         _dense_backward(dout, q_, k_, v_, out_, lse, alibi_slopes, ctx.dropout_p, ctx.softmax_scale,
                         ctx.causal, ctx.window_size, ctx.softcap, ctx.rng, dq_, dk_, dv_)
-        return (dq_[..., :d], dk_[..., :d], dv_[..., :d]) + (None,) * 10
+        cut = lambda t, need: t[..., :d] if (t is not None and need) else None
+        return (cut(dq_, need_q), cut(dk_, ctx.needs_input_grad[1]), cut(dv_, ctx.needs_input_grad[2])) + (None,) * 10
 
 
 class FlashAttnQKVPackedFunc(torch.autograd.Function):
@@ -498,15 +483,19 @@ def _varlen_backward(dout, q_, k_, v_, out_, lse, cu_seqlens_q, cu_seqlens_k, al
     B = cu_seqlens_q.numel() - 1
     dout_ = _prep(dout, dpad)
     softmax_d = torch.empty((H_Q, T_Q), dtype=torch.float32, device=q_.device)
+    if (dk_ is None) != (dv_ is None):
+        raise RuntimeError("dk and dv are computed together: pass both or neither")
     if q_.numel() == 0:
-        dk_.zero_(); dv_.zero_()
+        if dk_ is not None:
+            dk_.zero_(); dv_.zero_()
         return softmax_d
     p = _base_params(q_, q_.dtype, softmax_scale, causal, window_size, softcap)
     p.q, p.k, p.v, p.o, p.lse = _ptr(q_), _ptr(k_), _ptr(v_), _ptr(out_), _ptr(lse)
     p.dout, p.dq, p.dk, p.dv, p.softmax_d = _ptr(dout_), _ptr(dq_), _ptr(dk_), _ptr(dv_), _ptr(softmax_d)
     for name, t in (("q", q_), ("k", k_), ("v", v_), ("o", out_), ("do", dout_),
                     ("dq", dq_), ("dk", dk_), ("dv", dv_)):
-        _set3(p, name, t, "thd")
+        if t is not None:                               # a gradient nobody needs: NULL -> its kernel does not run
+            _set3(p, name, t, "thd")
     p.lse_batch_stride, p.lse_head_stride = 0, lse.stride(0)
     p.batch, p.nheads_q, p.nheads_k = B, H_Q, H_K
     p.seqlen_q, p.seqlen_k = int(max_seqlen_q), int(max_seqlen_k)
@@ -555,12 +544,15 @@ class FlashAttnVarlenFunc(torch.autograd.Function):
     def backward(ctx, dout, *args):
         q_, k_, v_, out_, cu_seqlens_q, cu_seqlens_k, lse, alibi_slopes = ctx.saved_tensors
         d = ctx.head_size_og
-        dq_, dk_, dv_ = torch.empty_like(q_), torch.empty_like(k_), torch.empty_like(v_)
-        dq_, dk_, dv_ = (_prep(t, q_.shape[-1]) for t in (dq_, dk_, dv_))
+        need_q, need_kv = ctx.needs_input_grad[0], ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        new = lambda t: _prep(torch.empty_like(t), q_.shape[-1])
+        dq_ = new(q_) if need_q else None
+        dk_, dv_ = (new(k_), new(v_)) if need_kv else (None, None)
         _varlen_backward(dout, q_, k_, v_, out_, lse, cu_seqlens_q, cu_seqlens_k, alibi_slopes,
                          ctx.max_seqlen_q, ctx.max_seqlen_k, ctx.dropout_p, ctx.softmax_scale,
                          ctx.causal, ctx.window_size, ctx.softcap, ctx.rng, dq_, dk_, dv_)
-        return (dq_[..., :d], dk_[..., :d], dv_[..., :d]) + (None,) * 14
+        cut = lambda t, need: t[..., :d] if (t is not None and need) else None
+        return (cut(dq_, need_q), cut(dk_, ctx.needs_input_grad[1]), cut(dv_, ctx.needs_input_grad[2])) + (None,) * 14
 
 
 def flash_attn_varlen_func(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q: int,
@@ -700,6 +692,8 @@ def flash_attn_with_kvcache(q, k_cache, v_cache, k=None, v=None, rotary_cos=None
             raise RuntimeError("rotary_cos/rotary_sin must be contiguous 2D tensors")
         p.rotary_cos, p.rotary_sin = _ptr(rotary_cos), _ptr(rotary_sin)
         p.rotary_dim = rotary_cos.shape[1] * 2
+        if p.rotary_dim > q.shape[-1]:
+            raise RuntimeError("rotary_dim must be <= headdim")
         p.seqlen_ro = rotary_cos.shape[0]
         p.rotary_interleaved = int(bool(rotary_interleaved))
     _alibi(p, alibi_slopes, B, H_Q, q.device)

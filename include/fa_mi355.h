@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define FA_ABI_VERSION 1
+#define FA_ABI_VERSION 2   /* 2: fa_params::reserved0 (was bwd_phases); fa_bwd / fa_varlen_bwd skip outputs passed as NULL */
 
 typedef enum fa_dtype {
     FA_FP16 = 0,      /* IEEE half */
@@ -141,9 +141,7 @@ typedef struct fa_params {
 
     /* ---- split-KV (decode) ---- */
     int32_t num_splits;             /* 0 = heuristic, 1 = no split */
-    int32_t bwd_phases;             /* fa_bwd / fa_varlen_bwd: 0 = all; else bit 0 preprocess, bit 1 dK/dV, bit 2 dQ
-                                       (per call, for per-kernel timing by bench.py; partial masks leave the
-                                       skipped outputs untouched) */
+    int32_t reserved0;              /* must be 0 (ABI 1 had a measurement switch here; ABI 2 rejects non-zero values) */
     void*   workspace;              /* >= fa_*_workspace_bytes(params) bytes, or NULL if 0 */
     size_t  workspace_bytes;
 } fa_params;
@@ -172,6 +170,9 @@ int fa_fwd(const fa_params* p, void* stream);
  *   reference: include/mha.h:67-87, kernel/fused_mha_backward.cu:577-721
  *   reads dout, q, k, v, o, lse; writes dq, dk, dv, softmax_d.  Deterministic
  *   (no atomics).  GQA: dk/dv are summed over the q-heads of each kv-head in-kernel.
+ *   Gradients the caller does not need are skipped: dq == NULL -> the dQ kernel does not run;
+ *   dk == dv == NULL -> the dK/dV kernel does not run (autograd's needs_input_grad; softmax_d is
+ *   always written).  The same holds for fa_varlen_bwd.
  */
 int fa_bwd(const fa_params* p, void* stream);
 

@@ -36,14 +36,14 @@ def test_flop_convention_matches_baseline_md():
 
 @pytest.mark.gpu
 def test_bench_json_line_contract():
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1",
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "5",
                           "--no-cpu-baseline"], capture_output=True, text=True, cwd=ROOT, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     d = json.loads(out.stdout.strip().splitlines()[-1])
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
                 "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
         assert key in d, key
-    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True
+    assert d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 5 and d["higher_is_better"] is True
     assert d["scaling"] == "weak" and d["dtype"] == "bf16" and d["data"] == "synthetic" and d["vs_baseline"] is None
     assert "workload" in d["config"] and "model" not in d["config"]
     r = d["roofline"]
@@ -57,3 +57,9 @@ def test_bench_json_line_contract():
     assert sc["scaling"] == "strong" and sc["n_gpus"] == 1 and sc["heads_per_gpu"] == 32
     # value is consistent with ms_per_step and the algorithmic FLOPs of config 2
     assert abs(d["value"] - 1924.16e9 / (d["ms_per_step"] * 1e-3) / 1e12) / d["value"] < 1e-2
+    # the per-kernel medians (individually evented launches) compose the step they were taken next to
+    t = d["kernels"]["timing"]
+    assert abs(t["sum_of_kernels_ms"] - (d["kernels"]["fwd"]["ms"] + d["kernels"]["bwd_all"]["ms"])) < 1e-3
+    assert 0.97 <= t["sum_over_step"] <= 1.03, t
+    for name in ("fwd", "bwd_dq", "bwd_all"):
+        assert d["kernels"][name]["ms_min"] <= d["kernels"][name]["ms"]

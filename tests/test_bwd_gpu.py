@@ -167,3 +167,51 @@ def test_odd_head_dims_without_padded_copies(D, dt):
     for name, got, ref in (("dq", dq, g_ref[0]), ("dk", dk, g_ref[1]), ("dv", dv, g_ref[2])):
         assert got.shape[-1] == D
         assert_close(tr(got), ref, dt, name, mult=1.5)
+
+
+@pytest.mark.parametrize("S,D,H,Hk,causal,dt", [(1024, 128, 4, 2, True, "bf16"), (777, 128, 2, 2, False, "fp16"),
+                                                (500, 64, 4, 4, True, "fp16"), (384, 256, 2, 1, True, "bf16")])
+def test_unneeded_gradients_are_skipped_not_changed(S, D, H, Hk, causal, dt):
+    """autograd's needs_input_grad reaches the C ABI as dq == NULL / dk == dv == NULL: the kernels that do run give the
+    same bits as in the full backward (dQ alone; dK/dV alone then takes D = rowsum(dO o O) from the preprocess kernel
+    instead of the dQ kernel's prologue - the same fp32 sum order is not promised there, so that pair is compared to
+    tolerance), and a K/V-only or Q-only caller gets no gradient for the rest."""
+    import flash_attn
+    q = rand16((2, S, H, D), dt, 1).requires_grad_(True)
+    k = rand16((2, S, Hk, D), dt, 2).requires_grad_(True)
+    v = rand16((2, S, Hk, D), dt, 3).requires_grad_(True)
+    do = rand16((2, S, H, D), dt, 4)
+    o = flash_attn.flash_attn_func(q, k, v, causal=causal)
+    dq, dk, dv = torch.autograd.grad(o, (q, k, v), do, retain_graph=True)
+    (dq1,) = torch.autograd.grad(o, (q,), do, retain_graph=True)
+    dk1, dv1 = torch.autograd.grad(o, (k, v), do, retain_graph=True)
+    (dv2,) = torch.autograd.grad(o, (v,), do, retain_graph=True)
+    assert torch.equal(dq, dq1)
+    assert_close(f64(dk1), f64(dk), dt, "dk (dk, dv only)", mult=0.25)
+    assert_close(f64(dv1), f64(dv), dt, "dv (dk, dv only)", mult=0.25)
+    assert torch.equal(dv1, dv2)
+    # frozen K / V: only q requires grad
+    q2 = q.detach().clone().requires_grad_(True)
+    o2 = flash_attn.flash_attn_func(q2, k.detach(), v.detach(), causal=causal)
+    o2.backward(do)
+    assert torch.equal(q2.grad, dq)
+
+
+def test_large_lds_kernels_on_every_visible_device():
+    """The > 64 KiB dynamic-LDS attribute is per device (fa_common.h: FA_SET_LDS_ONCE keeps a per-device flag): a D = 128
+    forward + backward must launch on every GPU of one process.  Needs >= 2 visible devices."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one visible device")
+    import flash_attn
+    ref = None
+    for dev in range(torch.cuda.device_count()):
+        q, k, v, do = (rand16((1, 512, 2, 128), "bf16", 10 + i, device=f"cuda:{dev}") for i in range(4))
+        q.requires_grad_(True); k.requires_grad_(True); v.requires_grad_(True)
+        o = flash_attn.flash_attn_func(q, k, v, causal=True)
+        g = torch.autograd.grad(o, (q, k, v), do)
+        torch.cuda.synchronize(dev)
+        got = [t.cpu() for t in (o.detach(),) + g]
+        if ref is None:
+            ref = got
+        else:
+            assert all(torch.equal(a, b) for a, b in zip(ref, got)), f"device {dev} differs from device 0"

@@ -112,6 +112,38 @@ def test_config3_shape_properties():
         assert_close(f64(o1[s0:s1, hs]).transpose(1, 0, 2)[None], o_ref, "fp16", f"seq {b}")
 
 
+def test_config3_backward_full_size_vs_oracle():
+    """BASELINE config 3 at FULL size, backward: three sequences (first, the 2048-row one, last) x two heads of
+    dQ / dK / dV against the fp64 oracle (the oracle gets its own forward output rounded to the io type)."""
+    g = torch.Generator().manual_seed(421)
+    lens = torch.randint(64, 2049, (64,), generator=g).tolist()
+    lens[7] = 2048
+    H, D, dt = 32, 64, "fp16"
+    T = sum(lens)
+    q = rand16((T, H, D), dt, 1).requires_grad_(True)
+    k = rand16((T, H, D), dt, 2).requires_grad_(True)
+    v = rand16((T, H, D), dt, 3).requires_grad_(True)
+    do = rand16((T, H, D), dt, 4)
+    cu = _cu(lens)
+    out = _fa().flash_attn_varlen_func(q, k, v, cu, cu, 2048, 2048, window_size=(512, 0))
+    dq, dk, dv = torch.autograd.grad(out, (q, k, v), do)
+    for t in (dq, dk, dv):
+        assert torch.isfinite(t.float()).all()
+    cun = cu.cpu().numpy()
+    tr = lambda x, s0, s1, hs: f64(x[s0:s1, hs]).transpose(1, 0, 2)[None]
+    for b in (0, 7, 63):
+        s0, s1 = int(cun[b]), int(cun[b + 1])
+        hs = slice(3, 5)
+        o_ref, lse_ref, _ = oracle.attn_fwd(tr(q, s0, s1, hs), tr(k, s0, s1, hs), tr(v, s0, s1, hs), D ** -0.5,
+                                            window=(512, 0))
+        gr = oracle.attn_bwd(tr(do, s0, s1, hs), tr(q, s0, s1, hs), tr(k, s0, s1, hs), tr(v, s0, s1, hs),
+                             oracle.round_to(o_ref, dt), lse_ref.astype(np.float64), D ** -0.5, window=(512, 0))
+        assert_close(tr(out, s0, s1, hs), o_ref, dt, f"out seq {b}")
+        assert_close(tr(dq, s0, s1, hs), gr[0], dt, f"dq seq {b}", mult=2.0)
+        assert_close(tr(dk, s0, s1, hs), gr[1], dt, f"dk seq {b}", mult=2.0)
+        assert_close(tr(dv, s0, s1, hs), gr[2], dt, f"dv seq {b}", mult=2.0)
+
+
 def test_varlen_with_empty_sequences():
     """cu_seqlens with zero-length entries (query-side, key-side and both): no crash, rows of the other
     sequences unaffected, empty-key rows give O = 0 / LSE = -inf, gradients finite."""

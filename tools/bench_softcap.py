@@ -3,7 +3,7 @@ import os, sys
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, os.path.join(ROOT, "flash-attention-v100_amd")); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import torch, flash_attn
-from flash_attn_mi355 import _lib
+from _bwdsel import bwd_call
 from bench_configs import timeit
 B, S, H, D = 8, 4096, 16, 128
 q, k, v = (torch.randn(B, S, H, D, device="cuda", dtype=torch.bfloat16, requires_grad=True) for _ in range(3))
@@ -13,8 +13,6 @@ for cap in (0.0, 0.0, 50.0):
         tf = timeit(lambda: flash_attn.flash_attn_func(q, k, v, causal=True, softcap=cap))
     o = flash_attn.flash_attn_func(q, k, v, causal=True, softcap=cap)
     res = {}
-    for nm, mask in (("dkdv", 2), ("dq", 4), ("all", 7)):
-        setattr(_fi._TLS, "bwd_phases", mask)
-        res[nm] = timeit(lambda: torch.autograd.grad(o, (q, k, v), do, retain_graph=True), iters=5)
-    setattr(_fi._TLS, "bwd_phases", 7)
+    for nm in ("dkdv", "dq", "all"):
+        res[nm] = timeit(bwd_call(o, q, k, v, do, nm), iters=5)
     print(f"softcap={cap}: fwd {tf:.3f} | dkdv {res['dkdv']:.3f} dq {res['dq']:.3f} bwd {res['all']:.3f} ms", flush=True)

@@ -3,7 +3,7 @@ import os, sys
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, os.path.join(ROOT, "flash-attention-v100_amd")); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import torch, flash_attn
-from flash_attn_mi355 import _lib
+from _bwdsel import bwd_call
 from bench_configs import timeit
 B, S, H, D = (int(x) for x in sys.argv[1:5])
 q, k, v = (torch.randn(B, S, H, D, device="cuda", dtype=torch.bfloat16, requires_grad=True) for _ in range(3))
@@ -13,7 +13,6 @@ with torch.no_grad():
     tf = timeit(lambda: flash_attn.flash_attn_func(q, k, v, causal=True))
 o = flash_attn.flash_attn_func(q, k, v, causal=True)
 res = {}
-for nm, mask in (("pre", 1), ("dkdv", 2), ("dq", 4), ("all", 7)):
-    setattr(_fi._TLS, "bwd_phases", mask)
-    res[nm] = timeit(lambda: torch.autograd.grad(o, (q, k, v), do, retain_graph=True), iters=5)
-print(f"B{B} S{S} H{H} D{D}: fwd {tf:.3f} ms ({fl/tf/1e9:.0f} TF) | pre {res['pre']:.3f} dkdv {res['dkdv']:.3f} ({2*fl/res['dkdv']/1e9:.0f} TF) dq {res['dq']:.3f} ({0.5*fl/res['dq']/1e9:.0f} TF alg) all {res['all']:.3f}")
+for nm in ("dkdv", "dq", "all"):
+    res[nm] = timeit(bwd_call(o, q, k, v, do, nm), iters=5)
+print(f"B{B} S{S} H{H} D{D}: fwd {tf:.3f} ms ({fl/tf/1e9:.0f} TF) | dkdv(+pre) {res['dkdv']:.3f} ({2*fl/res['dkdv']/1e9:.0f} TF) dq {res['dq']:.3f} ({0.5*fl/res['dq']/1e9:.0f} TF alg) all {res['all']:.3f}")
