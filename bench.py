@@ -326,18 +326,22 @@ def main():
         it = 30
         with torch.no_grad():
             kern["fwd"], kmin["fwd"] = med_min(event_times_ms(lambda: flash_attn.flash_attn_func(q, k, v, causal=c["causal"]), it, warm=3))
-        o = flash_attn.flash_attn_func(q, k, v, causal=c["causal"])
-        # which backward kernels run follows from the gradients asked for (needs_input_grad -> fa_bwd with dq == NULL or
-        # dk == dv == NULL): (q,) = the dQ kernel alone, (k, v) = preprocess + dK/dV kernel, (q, k, v) = dQ + dK/dV kernels
-        for name, ins in (("bwd_all", (q, k, v)), ("bwd_dq", (q,)), ("bwd_dkdv_pre", (k, v))):
+        # which backward kernels run follows from the gradients the op has to produce (autograd's needs_input_grad ->
+        # fa_bwd with dq == NULL or dk == dv == NULL): q alone = the dQ kernel, k and v = preprocess + dK/dV kernel,
+        # all three = dQ kernel + dK/dV kernel (the step's backward)
+        qd, kd, vd = q.detach(), k.detach(), v.detach()
+        graphs = {"bwd_all": (flash_attn.flash_attn_func(q, k, v, causal=c["causal"]), (q, k, v)),
+                  "bwd_dq": (flash_attn.flash_attn_func(q, kd, vd, causal=c["causal"]), (q,)),
+                  "bwd_dkdv_pre": (flash_attn.flash_attn_func(qd, k, v, causal=c["causal"]), (k, v))}
+        for name, (o, ins) in graphs.items():
             kern[name], kmin[name] = med_min(event_times_ms(lambda: torch.autograd.grad(o, ins, do, retain_graph=True), it, warm=3))
+        del graphs, o
 
         def fb():
             oo = flash_attn.flash_attn_func(q, k, v, causal=c["causal"])
             oo.backward(do)
             q.grad = k.grad = v.grad = None
         kern["step"], kmin["step"] = med_min(event_times_ms(fb, it, warm=3))
-        del o
 
     # ---- strong scaling, BASELINE configs[4]: every rank takes 32 / N heads of all 64 batches ----------------------
     strong = None

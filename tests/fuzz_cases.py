@@ -70,12 +70,16 @@ def _gen_state():
     return g.initial_seed(), g.get_offset()
 
 
-def _check(got, ref, dt, name, mult, desc, absfloor=2e-3):
+def _check(got, ref, dt, name, mult, desc, absfloor=2e-3, slack=None):
     # (a reference that cancels to ~0 still sees the 16-bit rounding of O in D = dO . O: bound by the element tolerance)
+    # `slack` (>= 0): an allowance taken off the difference first - the oracle's own measure of how far the saved 16-bit
+    # O's LAST-BIT rounding moves this gradient (see _o_rounding_slack)
     got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
     assert got.shape == ref.shape, (name, got.shape, ref.shape, desc)
     assert np.isfinite(got).all(), f"{name}: non-finite values  [{desc}]"
     d = np.abs(got - ref)
+    if slack is not None:
+        d = np.maximum(d - slack, 0.0)
     if d.size == 0:
         return
     rmax, rfro = np.abs(ref).max(), np.sqrt((ref ** 2).sum())
@@ -94,6 +98,18 @@ def _check_lse(got, ref, name, desc, atol=2e-3):
     assert (np.isneginf(got) == inf_ref).all(), f"{name}: -inf pattern differs  [{desc}]"
     d = np.abs(got[~inf_ref] - ref[~inf_ref])
     assert d.size == 0 or d.max() <= atol, f"{name}: max abs diff {d.max():.3e}  [{desc}]"
+
+
+def _o_rounding_slack(g_rounded, g_exact, k=2.0):
+    """The backward takes D = rowsum(dO o O) from the SAVED 16-bit O (reference include/product.h:72-94).  The kernel's O
+    (fp32 accumulation) and the oracle's (fp64) can round to neighbouring 16-bit values, and where P (dP - D) is a small
+    difference of large terms (two-key sequences: dS = P0 P1 (dP0 - dP1)) that last bit is a few per cent of dQ.  The
+    oracle measures this sensitivity itself - gradients from round_to(o_ref) vs from the unrounded o_ref differ by what
+    HALF-ulp changes of O do - and the check allows k x the largest such change on top of the usual tolerance (for long
+    rows it is ~2^-9 of the gradient, i.e. nothing; for two-key rows it is the dominant term).  No kernel output enters
+    the oracle.  Returns one allowance (a scalar) per gradient."""
+    return [k * float(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).max(initial=0.0))
+            for a, b in zip(g_rounded, g_exact)]
 
 
 # ------------------------------------------------------------------------------------------------ dense fwd + bwd
@@ -142,9 +158,11 @@ def dense_case(rng, idx, long=False):
         # never the kernel's `out`, so a forward error cannot hide in the backward check.  (With the unrounded o_ref a
         # two-key sequence, whose dQ is a small difference, shows the rounding of O as a few per cent of |dQ|.)
         g = oracle.attn_bwd(t(do), t(q), t(k), t(v), oracle.round_to(o_ref, dt), lse_ref.astype(np.float64), D ** -0.5, **kw)
+        gx = oracle.attn_bwd(t(do), t(q), t(k), t(v), o_ref, lse_ref.astype(np.float64), D ** -0.5, **kw)
+        sl = _o_rounding_slack(g, gx)
         m = 3.0 if pdrop else 2.0
-        _check(t(dq), g[0], dt, "dq", m, desc)
-        _check(t(dk), g[1], dt, "dk", m, desc)
+        _check(t(dq), g[0], dt, "dq", m, desc, slack=sl[0])
+        _check(t(dk), g[1], dt, "dk", m, desc, slack=sl[1])
         _check(t(dv), g[2], dt, "dv", m, desc)
     return desc
 
@@ -222,8 +240,11 @@ def varlen_case(rng, idx, long=False):
         dq, dk, dv = torch.autograd.grad(out, (q, k, v), do)
         g = oracle.varlen_bwd(f64(do), f64(q), f64(k), f64(v), oracle.round_to(o_ref, dt), lse_ref.astype(np.float64),
                               cu_q.cpu().numpy(), cu_k.cpu().numpy(), mq, mk, D ** -0.5, **kw)
-        _check(f64(dq), g[0], dt, "dq", 2.0, desc)
-        _check(f64(dk), g[1], dt, "dk", 2.0, desc)
+        gx = oracle.varlen_bwd(f64(do), f64(q), f64(k), f64(v), o_ref, lse_ref.astype(np.float64),
+                               cu_q.cpu().numpy(), cu_k.cpu().numpy(), mq, mk, D ** -0.5, **kw)
+        sl = _o_rounding_slack(g, gx)
+        _check(f64(dq), g[0], dt, "dq", 2.0, desc, slack=sl[0])
+        _check(f64(dk), g[1], dt, "dk", 2.0, desc, slack=sl[1])
         _check(f64(dv), g[2], dt, "dv", 2.0, desc)
     return desc
 

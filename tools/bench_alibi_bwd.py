@@ -15,5 +15,5 @@ for name, sl in (("no bias", None), ("alibi", slopes)):
     o = flash_attn.flash_attn_func(q, k, v, causal=True, alibi_slopes=sl)
     res = {}
     for nm in ("dkdv", "dq", "all"):
-        res[nm] = timeit(bwd_call(o, q, k, v, do, nm), iters=5)
+        res[nm] = timeit(bwd_call(lambda a, b, c: flash_attn.flash_attn_func(a, b, c, causal=True, alibi_slopes=sl), q, k, v, do, nm), iters=5)
     print(f"{name:8s}: fwd {tf:.3f} | dkdv {res['dkdv']:.3f} dq {res['dq']:.3f} bwd {res['all']:.3f} ms", flush=True)

@@ -14,5 +14,5 @@ for cap in (0.0, 0.0, 50.0):
     o = flash_attn.flash_attn_func(q, k, v, causal=True, softcap=cap)
     res = {}
     for nm in ("dkdv", "dq", "all"):
-        res[nm] = timeit(bwd_call(o, q, k, v, do, nm), iters=5)
+        res[nm] = timeit(bwd_call(lambda a, b, c: flash_attn.flash_attn_func(a, b, c, causal=True, softcap=cap), q, k, v, do, nm), iters=5)
     print(f"softcap={cap}: fwd {tf:.3f} | dkdv {res['dkdv']:.3f} dq {res['dq']:.3f} bwd {res['all']:.3f} ms", flush=True)

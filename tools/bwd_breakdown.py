@@ -14,5 +14,5 @@ with torch.no_grad():
 o = flash_attn.flash_attn_func(q, k, v, causal=True)
 res = {}
 for nm in ("dkdv", "dq", "all"):
-    res[nm] = timeit(bwd_call(o, q, k, v, do, nm), iters=5)
+    res[nm] = timeit(bwd_call(lambda a, b, c: flash_attn.flash_attn_func(a, b, c, causal=True), q, k, v, do, nm), iters=5)
 print(f"B{B} S{S} H{H} D{D}: fwd {tf:.3f} ms ({fl/tf/1e9:.0f} TF) | dkdv(+pre) {res['dkdv']:.3f} ({2*fl/res['dkdv']/1e9:.0f} TF) dq {res['dq']:.3f} ({0.5*fl/res['dq']/1e9:.0f} TF alg) all {res['all']:.3f}")

@@ -13,7 +13,7 @@ for (B, S, H, Hk, causal) in ((8, 4096, 16, 16, True), (8, 4096, 16, 16, False),
     o = flash_attn.flash_attn_func(q, k, v, causal=causal)
     res = {}
     for name in ("dkdv", "dq", "all"):
-        fn = bwd_call(o, q, k, v, do, name)
+        fn = bwd_call(lambda a, b, c: flash_attn.flash_attn_func(a, b, c, causal=causal), q, k, v, do, name)
         for _ in range(3):
             fn()
         torch.cuda.synchronize()
