@@ -59,39 +59,88 @@ def merge_attention_shards(outs, lses):
     return out.to(outs[0].dtype), tot
 
 
-def context_parallel_attention(q, k_shard, v_shard, group=None, causal=False, softmax_scale=None, attn_fn=None):
+def _local_fwd(q, k, v, window, scale):
+    from .flash_attn_interface import flash_attn_func
+    o, lse, _ = flash_attn_func(q, k, v, softmax_scale=scale, causal=False, window_size=window, return_attn_probs=True)
+    return o, lse
+
+
+def _local_bwd(dout, q, k, v, out, lse, window, scale):
+    """fa_bwd of the LOCAL problem (q over this rank's key shard) with the GLOBAL out / lse: P = exp(s - LSE_global) and
+    D = rowsum(dO o O_global) are then the true probabilities / row-dots of the full problem, so dk, dv of the shard are
+    complete and dq is this shard's share of the sum over keys."""
+    import torch
+    from . import flash_attn_interface as fi
+    d = q.shape[-1]
+    dpad = (d + 7) // 8 * 8
+    q_, k_, v_, o_ = (fi._prep(t, dpad) for t in (q, k, v, out))
+    dq_, dk_, dv_ = (fi._prep(torch.empty_like(t), dpad) for t in (q_, k_, v_))
+    fi._dense_backward(dout, q_, k_, v_, o_, lse.contiguous(), None, 0.0, d ** -0.5 if scale is None else scale, False,
+                       window, 0.0, None, dq_, dk_, dv_)
+    return dq_[..., :d], dk_[..., :d], dv_[..., :d]
+
+
+def _cp_function():
+    import torch
+    import torch.distributed as dist
+
+    class ContextParallelAttnFunc(torch.autograd.Function):
+        """forward: local attention, all-gather of (out, lse), LSE merge.  backward: the local backward kernels with the
+        merged out / lse (dk, dv of the shard complete; no exchange), then ONE all-reduce (sum, fp32) of the partial dq."""
+
+        @staticmethod
+        def forward(ctx, q, k_shard, v_shard, group, window, scale, attn_fn, bwd_fn):
+            world = dist.get_world_size(group) if dist.is_initialized() else 1
+            out, lse = attn_fn(q, k_shard, v_shard, window, scale)
+            if world > 1:
+                outs = [torch.empty_like(out) for _ in range(world)]
+                lses = [torch.empty_like(lse) for _ in range(world)]
+                dist.all_gather(outs, out.contiguous(), group=group)
+                dist.all_gather(lses, lse.contiguous(), group=group)
+                out, lse = merge_attention_shards(outs, lses)
+            ctx.save_for_backward(q, k_shard, v_shard, out, lse)
+            ctx.group, ctx.window, ctx.scale, ctx.bwd_fn, ctx.world = group, window, scale, bwd_fn, world
+            ctx.mark_non_differentiable(lse)
+            return out, lse
+
+        @staticmethod
+        def backward(ctx, dout, dlse):
+            q, k, v, out, lse = ctx.saved_tensors
+            dq, dk, dv = ctx.bwd_fn(dout.contiguous(), q, k, v, out, lse, ctx.window, ctx.scale)
+            if ctx.world > 1:
+                dq32 = dq.float().contiguous()                          # partial sums over key shards: add in fp32
+                dist.all_reduce(dq32, op=dist.ReduceOp.SUM, group=ctx.group)
+                dq = dq32.to(q.dtype)
+            return dq, dk, dv, None, None, None, None, None
+
+    return ContextParallelAttnFunc
+
+
+def context_parallel_attention(q, k_shard, v_shard, group=None, causal=False, softmax_scale=None, attn_fn=None,
+                               bwd_fn=None):
     """Attention over keys / values that are SHARDED along the sequence across the ranks of `group`
-    (context parallelism; the consumers SURVEY.md section 8(f) row 4 cites: flash_attn_interface.py:129-131,
-    utils/benchmarks/benchmark_unsloth.py:19-39).
+    (context parallelism; the consumers SURVEY.md section 8(f) row 4 cites: flash_attn_interface.py:17-112 - an
+    autograd Function, i.e. it trains -, utils/benchmarks/benchmark_unsloth.py:19-39).
 
     Every rank holds all queries `q` (B, Sq, H, D) and one contiguous, equally sized shard of the keys / values
-    `k_shard`, `v_shard` (B, Sk / N, Hk, D), rank r owning keys [r Sk/N, (r+1) Sk/N).  Each rank runs ONE local
-    attention call, the partial (out, lse) pairs are all-gathered (the only collective; RCCL over xGMI under the
-    "nccl" backend) and merged with merge_attention_shards.  causal=True is the bottom-right aligned causal mask of
-    the GLOBAL problem: in rank r's local coordinates that is a right window of (N - 1 - r) Sk/N keys, which the
-    kernels take as window_size=(-1, wr) - no mask tensor is ever built.
+    `k_shard`, `v_shard` (B, Sk / N, Hk, D), rank r owning keys [r Sk/N, (r+1) Sk/N).  Forward: each rank runs ONE local
+    attention call, the partial (out, lse) pairs are all-gathered (RCCL over xGMI under the "nccl" backend) and merged
+    with merge_attention_shards.  causal=True is the bottom-right aligned causal mask of the GLOBAL problem: in rank r's
+    local coordinates that is a right window of (N - 1 - r) Sk/N keys, which the kernels take as window_size=(-1, wr) -
+    no mask tensor is ever built.
 
-    attn_fn(q, k, v, window_size, softmax_scale) -> (out, lse) replaces the local attention call (tests on CPU);
-    the default is flash_attn_func(..., return_attn_probs=True).  Returns (out, lse) of the full problem on every rank.
-    Forward only (inference / evaluation use; a training-time ring would interleave the exchange with the backward)."""
-    import torch
+    Backward (autograd): each rank runs the local backward kernels over its shard with the MERGED out / lse - dk_shard
+    and dv_shard are then complete without any exchange - and the partial dq (sum over this rank's keys) is all-reduced
+    once in fp32.  `dout` is the gradient of the replicated output (every rank passes the same values, as every rank
+    holds the same q and out).
+
+    attn_fn(q, k, v, window_size, softmax_scale) -> (out, lse) and bwd_fn(dout, q, k, v, out, lse, window_size,
+    softmax_scale) -> (dq, dk, dv) replace the local kernels (tests on CPU); the defaults are the HIP path.
+    Returns (out, lse) of the full problem on every rank."""
     import torch.distributed as dist
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     skl = k_shard.shape[1]
     window = (-1, (world - 1 - rank) * skl) if causal else (-1, -1)
-    if attn_fn is None:
-        from .flash_attn_interface import flash_attn_func
-
-        def attn_fn(q_, k_, v_, window_size, scale):
-            o, lse, _ = flash_attn_func(q_, k_, v_, softmax_scale=scale, causal=False, window_size=window_size,
-                                        return_attn_probs=True)
-            return o, lse
-    out, lse = attn_fn(q, k_shard, v_shard, window, softmax_scale)
-    if world == 1:
-        return out, lse
-    outs = [torch.empty_like(out) for _ in range(world)]
-    lses = [torch.empty_like(lse) for _ in range(world)]
-    dist.all_gather(outs, out.contiguous(), group=group)
-    dist.all_gather(lses, lse.contiguous(), group=group)
-    return merge_attention_shards(outs, lses)
+    return _cp_function().apply(q, k_shard, v_shard, group, window, softmax_scale, attn_fn or _local_fwd,
+                                bwd_fn or _local_bwd)

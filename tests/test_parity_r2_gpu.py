@@ -499,6 +499,39 @@ def test_context_parallel_two_shards_on_one_gpu(causal):
     assert_lse_close(f64(lse), lse_ref, "lse", atol=1e-4)
 
 
+@pytest.mark.parametrize("causal", [False, True])
+def test_context_parallel_backward_two_shards_on_one_gpu(causal):
+    """the per-rank backward of context_parallel_attention on the HIP path, both shards on one GPU: fa_bwd over each key
+    shard with the MERGED out / lse gives that shard's dk / dv complete, and the two partial dq add up to the full dq
+    (oracle: the unsharded problem)."""
+    from flash_attn_mi355 import sharding
+    dt = "bf16"
+    B, Sq, Sk, H, Hk, D, N = 2, 512, 1024, 4, 2, 128, 2
+    q = rand16((B, Sq, H, D), dt, 1); k = rand16((B, Sk, Hk, D), dt, 2); v = rand16((B, Sk, Hk, D), dt, 3)
+    do = rand16((B, Sq, H, D), dt, 4)
+    skl = Sk // N
+    shards = [(k[:, r * skl:(r + 1) * skl], v[:, r * skl:(r + 1) * skl],
+               (-1, (N - 1 - r) * skl) if causal else (-1, -1)) for r in range(N)]
+    parts = [sharding._local_fwd(q, ks, vs, w, None) for ks, vs, w in shards]
+    out, lse = sharding.merge_attention_shards([p[0] for p in parts], [p[1] for p in parts])
+    grads = [sharding._local_bwd(do, q, ks, vs, out, lse, w, None) for ks, vs, w in shards]
+    dq = sum(g[0].float() for g in grads)
+    dk = torch.cat([g[1] for g in grads], 1); dv = torch.cat([g[2] for g in grads], 1)
+    t = lambda x: f64(x).transpose(0, 2, 1, 3)
+    o_ref, lse_ref, _ = oracle.attn_fwd(t(q), t(k), t(v), D ** -0.5, causal=causal)
+    g_ref = oracle.attn_bwd(t(do), t(q), t(k), t(v), oracle.round_to(o_ref, dt), lse_ref.astype(np.float64), D ** -0.5,
+                            causal=causal)
+    assert_close(t(dq), g_ref[0], dt, "dq", mult=2.0)
+    assert_close(t(dk), g_ref[1], dt, "dk", mult=2.0)
+    assert_close(t(dv), g_ref[2], dt, "dv", mult=2.0)
+    # and through autograd in a single-rank "group" (no process group: world = 1)
+    q1, k1, v1 = (x.clone().requires_grad_(True) for x in (q, k, v))
+    o1, _ = sharding.context_parallel_attention(q1, k1, v1, causal=causal)
+    o1.backward(do)
+    assert_close(t(q1.grad), g_ref[0], dt, "dq (autograd)", mult=2.0)
+    assert_close(t(k1.grad), g_ref[1], dt, "dk (autograd)", mult=2.0)
+
+
 # ------------------------------------------------------------------------------------------------ fp8 matrix-vector decode
 @pytest.mark.parametrize("H,Hk", [(4, 4), (32, 32), (64, 64), (32, 8), (16, 8), (64, 16)])
 @pytest.mark.parametrize("paged,window,interleaved,use_lp,splits", [

@@ -142,3 +142,70 @@ def test_context_parallel_attention_two_ranks(tmp_path, causal):
     t = lambda x: x.double().numpy().transpose(0, 2, 1, 3)
     o2, lse2, _ = oracle.attn_fwd(t(q), t(k), t(v), D ** -0.5, causal=causal)
     assert np.abs(res["out"].double().numpy().transpose(0, 2, 1, 3) - o2).max() < 2e-6
+
+
+def _torch_attn_bwd(dout, q, k, v, out, lse, window, scale):
+    """test-local stand-in for the backward kernels, written the way they work: P from the GIVEN lse, D from the GIVEN out
+    (fp64) - with the merged lse / out of a context-parallel forward these are the global probabilities."""
+    B, Sq, H, D = q.shape
+    Sk, Hk = k.shape[1], k.shape[2]
+    G = H // Hk
+    scale = D ** -0.5 if scale is None else scale
+    qf, dof, of = (t.double().permute(0, 2, 1, 3) for t in (q, dout, out))
+    kf = k.double().permute(0, 2, 1, 3).repeat_interleave(G, 1)
+    vf = v.double().permute(0, 2, 1, 3).repeat_interleave(G, 1)
+    s = qf @ kf.transpose(-1, -2) * scale
+    if window[1] >= 0:
+        i = torch.arange(Sq)[:, None]; j = torch.arange(Sk)[None, :]
+        s = s.masked_fill(j > i + (Sk - Sq) + window[1], float("-inf"))
+    p = torch.nan_to_num(torch.exp(s - lse.double()[..., None]), nan=0.0)
+    dp = dof @ vf.transpose(-1, -2)
+    dd = (dof * of).sum(-1, keepdim=True)
+    ds = p * (dp - dd) * scale
+    dq = (ds @ kf).permute(0, 2, 1, 3)
+    dk = (ds.transpose(-1, -2) @ qf).reshape(B, Hk, G, Sk, D).sum(2).permute(0, 2, 1, 3)
+    dv = (p.transpose(-1, -2) @ dof).reshape(B, Hk, G, Sk, D).sum(2).permute(0, 2, 1, 3)
+    return dq.to(q.dtype).contiguous(), dk.to(k.dtype).contiguous(), dv.to(v.dtype).contiguous()
+
+
+def _cp_bwd_worker(rank, world, port, q, k, v, dout, causal, out_dir):
+    from flash_attn_mi355.sharding import context_parallel_attention
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    skl = k.shape[1] // world
+    q = q.clone().requires_grad_(True)
+    ks = k[:, rank * skl:(rank + 1) * skl].clone().requires_grad_(True)
+    vs = v[:, rank * skl:(rank + 1) * skl].clone().requires_grad_(True)
+    out, lse = context_parallel_attention(q, ks, vs, causal=causal, attn_fn=_torch_attn, bwd_fn=_torch_attn_bwd)
+    out.backward(dout)
+    torch.save({"dq": q.grad, "dk": ks.grad, "dv": vs.grad, "out": out.detach()}, os.path.join(out_dir, f"r{rank}.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("causal", [False, True])
+def test_context_parallel_backward_two_ranks(tmp_path, causal):
+    """autograd through context_parallel_attention on two gloo ranks: dk / dv of each shard come out of the local
+    backward with the merged out / lse, dq after one all-reduce - all equal the gradients of the unsharded problem
+    (torch autograd in fp64 and the oracle)."""
+    torch.manual_seed(2)
+    B, Sq, Sk, H, Hk, D, world = 2, 40, 96, 4, 2, 16, 2
+    q = torch.randn(B, Sq, H, D, dtype=torch.float64); k = torch.randn(B, Sk, Hk, D, dtype=torch.float64)
+    v = torch.randn(B, Sk, Hk, D, dtype=torch.float64); dout = torch.randn(B, Sq, H, D, dtype=torch.float64)
+    mp.spawn(_cp_bwd_worker, args=(world, _free_port(), q, k, v, dout, causal, str(tmp_path)), nprocs=world, join=True)
+    res = [torch.load(str(tmp_path / f"r{r}.pt")) for r in range(world)]
+    qr, kr, vr = (t.clone().requires_grad_(True) for t in (q, k, v))
+    o_ref, _ = _torch_attn(qr, kr, vr, (-1, 0) if causal else (-1, -1), None)
+    o_ref.backward(dout)
+    skl = Sk // world
+    for r in range(world):
+        assert (res[r]["out"] - o_ref.detach()).abs().max() < 2e-6       # (the merge runs in fp32)
+        assert (res[r]["dq"] - qr.grad).abs().max() < 5e-6, r
+        assert (res[r]["dk"] - kr.grad[:, r * skl:(r + 1) * skl]).abs().max() < 5e-6, r
+        assert (res[r]["dv"] - vr.grad[:, r * skl:(r + 1) * skl]).abs().max() < 5e-6, r
+    t = lambda x: x.double().numpy().transpose(0, 2, 1, 3)
+    o2, lse2, _ = oracle.attn_fwd(t(q), t(k), t(v), D ** -0.5, causal=causal)
+    g = oracle.attn_bwd(t(dout), t(q), t(k), t(v), o2, lse2, D ** -0.5, causal=causal)
+    assert np.abs(t(res[0]["dq"]) - g[0]).max() < 5e-6
+    assert np.abs(np.concatenate([t(res[0]["dk"]), t(res[1]["dk"])], 2) - g[1]).max() < 5e-6
+    assert np.abs(np.concatenate([t(res[0]["dv"]), t(res[1]["dv"])], 2) - g[2]).max() < 5e-6
