@@ -32,7 +32,7 @@ template <int D> struct DecSmem {
 struct DecArgs {
     KArgs a;
     int n_splits;
-    int rows;                  // T_q * G (<= 32)
+    int rows;                  // T_q * G; a workgroup takes 32 of them (blockIdx.z = row block: fp8 caches with more than 32)
     int group;                 // G
     int local;                 // RoPE position advances with the query row (causal / window)
     int page_shift;            // log2(page_block_size) or -1
@@ -100,8 +100,10 @@ __global__ void __launch_bounds__(DEC_THREADS, 1) fa_decode_kernel(const DecArgs
     const int wl = p.window_left;
     const int wr = p.is_causal ? 0 : p.window_right;
 
-    // ---- my packed query row: r = t * G + gq ----
-    const int r = l31;
+    // ---- my packed query row: r = t * G + gq; blockIdx.z picks the 32-row block (multi-token queries over an fp8 cache:
+    //      every row block streams the kv-head's cache again, dequantised into the same LDS tiles) ----
+    const int rbase = 32 * (int)blockIdx.z;
+    const int r = rbase + l31;
     const int t_row = r / G, gq = r - t_row * G;
     const int h = hk * G + gq;
     const bool row_ok = r < R;
@@ -140,9 +142,11 @@ __global__ void __launch_bounds__(DEC_THREADS, 1) fa_decode_kernel(const DecArgs
 
     // ---- key-tile range of this split / this wave ----
     int tile_lo = 0;
-    if (wl >= 0) { const int kmin = off - wl; if (kmin > 0) tile_lo = kmin / DEC_BN; }
+    const int t_first = rbase / G;                                       // query positions of this row block
+    const int t_last = (rbase + 31) / G < Tq - 1 ? (rbase + 31) / G : Tq - 1;
+    if (wl >= 0) { const int kmin = t_first + off - wl; if (kmin > 0) tile_lo = kmin / DEC_BN; }
     int tile_hi = (seqlen_k + DEC_BN - 1) / DEC_BN;
-    if (wr >= 0) { const int kmax = (Tq - 1) + off + wr; const int t2 = kmax < 0 ? 0 : kmax / DEC_BN + 1; tile_hi = t2 < tile_hi ? t2 : tile_hi; }
+    if (wr >= 0) { const int kmax = t_last + off + wr; const int t2 = kmax < 0 ? 0 : kmax / DEC_BN + 1; tile_hi = t2 < tile_hi ? t2 : tile_hi; }
     const int n_all = tile_hi > tile_lo ? tile_hi - tile_lo : 0;
     const int per_split = ((n_all + da.n_splits - 1) / da.n_splits + 3) & ~3;     // multiple of 4 waves
     const int s_lo = tile_lo + split * per_split;
@@ -380,8 +384,8 @@ __global__ void __launch_bounds__(DEC_THREADS, 1) fa_decode_kernel(const DecArgs
     {
         const int row = tid >> 3;                           // 0..31
         const int cs = (tid & 7) * (D / 8);                 // D/8 columns per thread
-        const int t3 = row / G, gq3 = row - t3 * G;
-        if (row < R) {
+        const int t3 = (rbase + row) / G, gq3 = (rbase + row) - t3 * G;
+        if (rbase + row < R) {
             float mw[4], lw[4];
             float m_all = -INFINITY;
 #pragma unroll
@@ -976,7 +980,10 @@ __global__ void __launch_bounds__(GEMV_THREADS) fa_decode_gemv_tm_kernel(const D
 bool decode_applicable(const fa_params& p) {
     if (p.alibi_slopes || p.softcap > 0.f) return false;
     const int G = p.nheads_q / p.nheads_k;
-    return p.seqlen_q * G <= 32 && (p.head_dim == 64 || p.head_dim == 128) && p.head_dim_v == 0;
+    if (!((p.head_dim == 64 || p.head_dim == 128) && p.head_dim_v == 0)) return false;
+    // 16-bit caches: up to 32 packed rows (longer query blocks run fa_fwd_kernel on the cache); fp8 caches: any number of
+    // rows, 32 per workgroup - this kernel is the one that dequantises (chunked prefill / speculative decode over fp8 KV)
+    return p.kv_dtype == FA_FP8_E4M3 || p.seqlen_q * G <= 32;
 }
 
 static int device_cu_count() {
@@ -990,7 +997,7 @@ static int device_cu_count() {
 
 int decode_num_splits(const fa_params& p) {
     if (p.num_splits >= 1) return p.num_splits > 64 ? 64 : p.num_splits;
-    const int units = p.batch * p.nheads_k;
+    const int units = p.batch * p.nheads_k * ((p.seqlen_q * (p.nheads_q / p.nheads_k) + 31) / 32);   // x row blocks
     const int max_tiles = (p.seqlen_k + DEC_BN - 1) / DEC_BN;
     int s = 1;
     while (units * s < 512 && s < 32 && max_tiles / (s * 2) >= 8) s *= 2;       // >= 8 tiles (256 keys) per split
@@ -1044,7 +1051,7 @@ static int launch_decode_td(DecArgs& da, hipStream_t stream) {
     const fa_params& p = da.a.p;
     const bool kv8 = p.kv_dtype == FA_FP8_E4M3;
     const bool paged = p.block_table != nullptr;
-    dim3 grid(p.batch * p.nheads_k, da.n_splits);
+    dim3 grid(p.batch * p.nheads_k, da.n_splits, (da.rows + 31) / 32);
     const size_t smem = DecSmem<D>::TOTAL;
     if constexpr (D == 128) {
         // one query position, heads adjacent in the cache rows: the token-major streaming kernel (fp8 and 16-bit caches, GQA)

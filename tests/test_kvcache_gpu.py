@@ -174,6 +174,51 @@ def test_decode_fp8_kv_cache(Hk):
     assert_lse_close(f64(lse), lse_ref, "lse", atol=3e-2)
 
 
+@pytest.mark.parametrize("Tq,Hq,Hk,D,paged,causal,window,rot", [
+    (33, 4, 4, 128, True, True, (-1, -1), True),        # one row past a row block
+    (64, 8, 2, 128, False, True, (-1, -1), False),      # G = 4: 256 packed rows = 8 row blocks
+    (130, 2, 2, 64, True, False, (-1, -1), False),      # non-causal chunk, D = 64
+    (96, 4, 1, 128, True, False, (200, 0), True),       # MQA, sliding window
+    (40, 6, 2, 128, False, False, (50, 10), False),     # G = 3: rows of one query position straddle row blocks
+])
+def test_fp8_cache_multi_token_queries(Tq, Hq, Hk, D, paged, causal, window, rot):
+    """Chunked prefill / speculative decode over an fp8-e4m3 cache: T_q * H_q/H_k > 32 packed rows run as 32-row blocks
+    of the dequantising decode kernel (reference semantics: fused_mha_forward_kvcache.cu:344 takes any T_Q).
+    Tolerance: the fp8 cases' (out 1.5 x the io tolerance, LSE 3e-2) - the oracle reads the same fp8 codes."""
+    B, page, dt = 3, 128, "bf16"
+    kd, vd = 0.05, 0.04
+    Smax = 1024
+    seqlens = torch.tensor([Smax - Tq - 7, 1, 300], dtype=torch.int32)
+    q = rand16((B, Tq, Hq, D), dt, 1)
+    knew = rand16((B, Tq, Hk, D), dt, 4); vnew = rand16((B, Tq, Hk, D), dt, 5)
+    bt = None
+    if paged:
+        pps = Smax // page
+        nblk = B * pps
+        kc16 = rand16((nblk, page, Hk, D), dt, 2, scale=1.5); vc16 = rand16((nblk, page, Hk, D), dt, 3, scale=1.5)
+        bt = torch.randperm(nblk, generator=torch.Generator().manual_seed(3)).reshape(B, pps).to(torch.int32)
+    else:
+        kc16 = rand16((B, Smax, Hk, D), dt, 2, scale=1.5); vc16 = rand16((B, Smax, Hk, D), dt, 3, scale=1.5)
+    kc = (kc16.float() / kd).to(torch.float8_e4m3fn); vc = (vc16.float() / vd).to(torch.float8_e4m3fn)
+    cos, sin = _rotary(Smax + 8, D, dt) if rot else (None, None)
+    kc_ref = kc.float().double().cpu().numpy().copy(); vc_ref = vc.float().double().cpu().numpy().copy()
+    out, lse = _fa().flash_attn_with_kvcache(q, kc, vc, k=knew, v=vnew, rotary_cos=cos, rotary_sin=sin,
+                                             cache_seqlens=seqlens.cuda(), block_table=None if bt is None else bt.cuda(),
+                                             causal=causal, window_size=window, rotary_interleaved=False,
+                                             return_softmax_lse=True, k_descale=kd, v_descale=vd)
+    o_ref, lse_ref = oracle.kvcache_fwd(f64(q), kc_ref, vc_ref, k=f64(knew), v=f64(vnew),
+                                        rotary_cos=None if cos is None else f64(cos), rotary_sin=None if sin is None else f64(sin),
+                                        cache_seqlens=seqlens.numpy(), block_table=None if bt is None else bt.numpy(),
+                                        causal=causal, window=window, rotary_interleaved=False, io_dtype=dt,
+                                        k_descale=kd, v_descale=vd)
+    assert_close(f64(out), o_ref, dt, "out", mult=1.5)
+    assert_lse_close(f64(lse), lse_ref, "lse", atol=3e-2)
+    # and the explicit split-KV path gives the same rows
+    out2 = _fa().flash_attn_with_kvcache(q, kc, vc, cache_seqlens=(seqlens + Tq).cuda(), block_table=None if bt is None else bt.cuda(),
+                                         causal=causal, window_size=window, num_splits=3, k_descale=kd, v_descale=vd)
+    assert_close(f64(out2), o_ref, dt, "out (3 splits, no append)", mult=1.5)
+
+
 def test_full_size_config4_decode_paged_rotary_fp8():
     """BASELINE config 4 at full size (B128, 32 heads, D128, cache_seqlen 8192, paged KV with a random
     block table, NeoX rotary, fp8-e4m3 KV), checked through size-independent properties:
