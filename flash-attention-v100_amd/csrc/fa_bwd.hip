@@ -1789,6 +1789,9 @@ extern "C" int fa_debug_read_timers(unsigned long long* out, int n) {
 #endif
 
 
+bool bwd_dq_asm_applicable(const KArgs& a);
+int launch_bwd_dq_asm(const KArgs& a, hipStream_t stream);
+
 template <typename T, int D>
 static int launch_bwd_td(const KArgs& a, hipStream_t stream) {
     const fa_params& p = a.p;
@@ -1877,6 +1880,8 @@ static int launch_bwd_td(const KArgs& a, hipStream_t stream) {
             FA_SET_LDS_ONCE(kern, smem);
             if (grid > 0) hipLaunchKernelGGL(kern, dim3(grid), dim3(BWD_THREADS), smem, stream, a);
         }
+    } else if ((g_bwd_phase_mask & 4) && D == 128 && bwd_dq_asm_applicable(a)) {
+        launch_bwd_dq_asm(a, stream);                     // hand-scheduled body (fa_bwd_dq_asm.hip)
     } else if (g_bwd_phase_mask & 4) {
         const int grid = a.flat_blocks ? a.flat_blocks * p.nheads_q : work_grid(p.batch, p.nheads_q, p.nheads_k, a.n_qblocks);
         const size_t smem = DqSmem<D>::TOTAL;
