@@ -15,8 +15,8 @@ Orientation (the forward's): everything transposed, so that a lane owns ONE quer
     dQ^T += K^T dS^T    A = K^T      (ds_read_b64_tr_b16 from the SAME K image), B = packed dS^T in the C layout
 Structure (one wave per SIMD, 512 registers, 4 waves x 64 query rows = 256-row workgroup):
   * a wave owns two 32-row q-blocks that run HALF AN ITERATION OUT OF PHASE over 32-key stages:
-        phase A of iteration j : MFMA  dQ1(j), S1(j+1), dP1(j+1)      VALU  grad0(j+1)      (24 MFMAs)
-        phase B of iteration j : MFMA  dQ0(j+1), S0(j+2), dP0(j+2)    VALU  grad1(j+1)
+        phase A of iteration j : MFMA  S1(j+1), dP1(j+1), dQ1(j)      VALU  grad0(j+1)      (24 MFMAs)
+        phase B of iteration j : MFMA  S0(j+2), dP0(j+2), dQ0(j+1)    VALU  grad1(j+1)
     so the VALU stream of a phase never depends on the MFMAs issued beside it, and S / dP need no double buffering;
   * dQ^T accumulators a[0:127], Q fragments a[128:191], dO fragments a[192:255]; the stage's K-row, V-row and K^T
     fragments (3 x 32 VGPRs) are reloaded right behind their use by q-block 1 (phase A) and are consumed by q-block 0
@@ -206,8 +206,9 @@ class DQ(Gen):
         A(f"s_cmp_lt_i32 s{t}, s{S_NMAX}")
         A(f"s_cselect_b32 s{t + 3}, s{S_KSO}, s{S_OOB}")
         A(f"s_cselect_b32 s{t + 4}, s{S_VSO}, s{S_OOB}")
-        mfA = self.dq_mfmas(1) + self.sdp_mfmas(1)
-        mfB = self.dq_mfmas(0) + self.sdp_mfmas(0)
+        # S / dP first: the VALU stream of the NEXT phase starts on them; dQ (operands ready since the previous phase) last
+        mfA = self.sdp_mfmas(1) + self.dq_mfmas(1)
+        mfB = self.sdp_mfmas(0) + self.dq_mfmas(0)
         nA = len(mfA)
         lds = []
         for k, (tag, mf) in enumerate(mfA):
