@@ -17,10 +17,10 @@ def build(specs):
     b.build()
     os.makedirs(OUT, exist_ok=True)
     bdir = os.path.join(CSRC, "build")
-    which = os.environ.get("VARIANT_KERNEL", "ws")           # ws: fa_fwd_ws.hip / gen_fwd_ws.py ; asm: fa_fwd_asm.hip / gen_fwd_asm.py
-    src, gen, macro = {"ws": ("fa_fwd_ws.hip", "gen_fwd_ws.py", "FA_FWD_WS_GEN_H"),
-                       "asm": ("fa_fwd_asm.hip", "gen_fwd_asm.py", "FA_FWD_ASM_GEN_H"),
-                       "bwd": ("fa_bwd_asm.hip", "gen_bwd_dkdv_asm.py", "FA_BWD_ASM_GEN_H")}[which]
+    which = os.environ.get("VARIANT_KERNEL", "asm")          # asm: forward ; bwd: dK/dV ; dq: dQ
+    src, gen, macro = {"asm": ("fa_fwd_asm.hip", "gen_fwd_asm.py", "FA_FWD_ASM_GEN_H"),
+                       "bwd": ("fa_bwd_asm.hip", "gen_bwd_dkdv_asm.py", "FA_BWD_ASM_GEN_H"),
+                       "dq": ("fa_bwd_dq_asm.hip", "gen_bwd_dq_asm.py", "FA_BWD_DQ_ASM_GEN_H")}[which]
     others = [os.path.join(bdir, s.replace(".hip", ".o")) for s in b.SOURCES if s != src]
     procs = []
     for spec in specs:
@@ -87,6 +87,30 @@ def one_bwd():
     print(json.dumps(res))
 
 
+def one_dq():
+    """dQ kernel alone (K / V frozen: only dq is asked for)"""
+    import torch
+    import flash_attn
+    torch.manual_seed(421)
+    res = {}
+    for (tag, B, S, H, Hk, causal) in (("causal4k", 8, 4096, 16, 16, True), ("full4k", 8, 4096, 16, 16, False), ("causal8k", 4, 8192, 16, 16, True)):
+        q = torch.randn(B, S, H, 128, device="cuda", dtype=torch.bfloat16, requires_grad=True)
+        k, v = (torch.randn(B, S, Hk, 128, device="cuda", dtype=torch.bfloat16) for _ in range(2))
+        do = torch.randn(B, S, H, 128, device="cuda", dtype=torch.bfloat16)
+        o = flash_attn.flash_attn_func(q, k, v, causal=causal)
+        for _ in range(3):
+            torch.autograd.grad(o, (q,), do, retain_graph=True)
+        torch.cuda.synchronize()
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
+        for s, e in evs:
+            s.record(); torch.autograd.grad(o, (q,), do, retain_graph=True); e.record()
+        torch.cuda.synchronize()
+        ts = sorted(s.elapsed_time(e) for s, e in evs)
+        fl = 6.0 * B * H * S * S * 128 * (0.5 if causal else 1.0)          # executed: 3 GEMMs
+        res[tag] = (ts[len(ts) // 2], fl / ts[len(ts) // 2] / 1e9)
+    print(json.dumps(res))
+
+
 def time_all(names):
     if not names:
         names = sorted(f[6:-3] for f in os.listdir(OUT) if f.startswith("libfa_") and f.endswith(".so"))
@@ -96,7 +120,7 @@ def time_all(names):
             env = dict(os.environ)
             if n != "default":
                 env["FA_MI355_LIB"] = os.path.join(OUT, f"libfa_{n}.so")
-            mode = "one_bwd" if os.environ.get("VARIANT_KERNEL") == "bwd" else "one"
+            mode = {"bwd": "one_bwd", "dq": "one_dq"}.get(os.environ.get("VARIANT_KERNEL"), "one")
             r = subprocess.run([sys.executable, os.path.abspath(__file__), mode], env=env, capture_output=True, text=True)
             line = [l for l in r.stdout.splitlines() if l.startswith("{")]
             if not line:
@@ -113,30 +137,8 @@ if __name__ == "__main__":
         one()
     elif sys.argv[1] == "one_bwd":
         one_bwd()
-    elif sys.argv[1] == "timers":
-        pass
+    elif sys.argv[1] == "one_dq":
+        one_dq()
     else:
         time_all(sys.argv[2:])
 
-
-def timers():
-    """WS measurement build (cfg timers=1): per-phase cycle sums land in the LSE rows 0..5 (S wave) / 8..13 (O wave)
-    of every 64-row chunk."""
-    import torch
-    import flash_attn
-    torch.manual_seed(421)
-    B, S, H = 2, 4096, 4
-    for causal in (False, True):
-        q, k, v = (torch.randn(B, S, H, 128, device="cuda", dtype=torch.bfloat16) for _ in range(3))
-        o, lse, _ = flash_attn.flash_attn_func(q, k, v, causal=causal, return_attn_probs=True)
-        torch.cuda.synchronize()
-        t = lse[0, 0].view(S // 64, 64).double()
-        nt = 64 if not causal else None
-        for chunk in (0, 1, 2, 3, 32, 63):
-            srow, orow = t[chunk, 0:6].tolist(), t[chunk, 8:14].tolist()
-            print(f"causal={causal} chunk {chunk:2d}: S wave [wait/disp, QK, softmax, tail] = {[int(x) for x in srow[:4]]}  "
-                  f"O wave [start, loads, PV, tail] = {[int(x) for x in orow[:4]]}")
-
-
-if __name__ == "__main__" and sys.argv[1] == "timers":
-    timers()
