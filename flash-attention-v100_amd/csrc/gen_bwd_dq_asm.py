@@ -11,7 +11,9 @@ Orientation (the forward's): everything transposed, so that a lane owns ONE quer
 (LSE log2e, D = rowsum(dO o O)) are one register per lane:
     S^T  = K Q^T        A = K rows   (ds_read_b128 from the stage's K image),  B = Q fragments  (pinned, AGPR)
     dP^T = V dO^T       A = V rows   (ds_read_b128 from the stage's V image),  B = dO fragments (pinned, AGPR)
-    P^T  = exp2(S^T c - lse2),  dS^T = P^T o (dP^T - D)     VALU, 4.5 instructions per element, rounded to 16 bit
+    P^T  = exp2(S^T c - lse2),  dS^T = P^T o (dP^T - D)     VALU, 3.5 instructions per element, rounded to 16 bit
+                        (the "- D" costs no VALU work: the dP chain starts with ONE rank-1 MFMA, A = ones in three contraction
+                         slots, B = -D split exactly into three 16-bit terms, that leaves -D[q] in every row of the column)
     dQ^T += K^T dS^T    A = K^T      (ds_read_b64_tr_b16 from the SAME K image), B = packed dS^T in the C layout
 Structure (one wave per SIMD, 512 registers, 4 waves x 64 query rows = 256-row workgroup):
   * a wave owns two 32-row q-blocks that run HALF AN ITERATION OUT OF PHASE over 32-key stages:
@@ -48,8 +50,9 @@ S_C, S_SCALE = 52, 53           # softmax_scale * log2e, softmax_scale
 S_JIN, S_NMAX, S_NMIN = 54, 55, 56   # first iteration (n_min - 2), stage range [n_min, n_max)
 S_KSTG, S_VSTG = 57, 58         # bytes of one 32-key stage of K / V
 S_W1024 = 59
-S_HIMIN = (60, 62)              # in: min over the q-block's rows of the last visible key
-S_LOMAX = (61, 63)              # in: max over the q-block's rows of the first visible key
+S_MLO = (60, 62)                # in: a stage starting at key n0 is free of masks for the q-block iff (n0 - MLO) <=u MRANGE
+S_MRANGE = (61, 63)             #     (MLO = max over the rows of the first visible key, MRANGE = min last visible key - 31 - MLO;
+                                #      MLO = 0x40000000, MRANGE = 0: every stage is masked)
 S_PLANE = 64                    # in: bytes of one statistics plane (0 when there is no statistics workspace)
 S_WHI = 65                      # in: this wave has no visible key in stages >= S_WHI ...
 S_WLO = 66                      # ... nor in stages < S_WLO: iterations outside [WLO - 2, WHI) only move data
@@ -79,14 +82,17 @@ V_K16, V_V16 = 48, 49           # in (uniform): 16 rows of K / V in bytes
 V_DMAK2, V_DMAV2 = 50, 51
 V_LSE2 = (52, 54)               # lse * log2e (+inf for rows without keys)
 V_D = (53, 55)                  # rowsum(dO o O)
-V_T = 56                        # temps v56..v71
+V_T = 56                        # temps v56..v63
+V_ND = (64, 68)                 # B operand of the rank-1 MFMA that starts the dP chain at -D: -D split into three 16-bit
+                                # terms in the contraction slots 0..2 (lanes 0..31; zeros elsewhere), 4 regs per q-block
+V_ONE = 252                     # its A operand: ones in the contraction slots 0..2 (4 regs)
 V_S = (72, 88)                  # S^T accumulators (16 each)
 V_DP = (104, 120)               # dP^T accumulators
 V_DS = (136, 144)               # packed dS^T (8 each)
 V_KR = 152                      # K-row fragments [ks] x 4
 V_VR = 184                      # V-row fragments [ks] x 4
 V_KT = 216                      # K^T fragments [t][d] x 4           (.. v247)
-V_TM = 248                      # measurement build: time stamps
+V_TM = 248                      # measurement build: time stamps (v248..v251)
 A_DQ = (0, 64)
 A_Q = (128, 160)
 A_DO = (192, 224)
@@ -113,14 +119,16 @@ class DQ(Gen):
 
     def sdp_mfmas(self, qb):
         """S^T (+)= K[ks] Q[ks]^T and dP^T (+)= V[ks] dO[ks]^T, interleaved (two accumulator chains)"""
-        out = []
+        out = [(("nd", 0), self.mfma("v", V_DP[qb], "v", V_ONE, "v", V_ND[qb], True))]       # dP := -D (rank-1)
         for ks in range(8):
             out.append((("kr", ks), self.mfma("v", V_S[qb], "v", V_KR + 4 * ks, "a", A_Q[qb] + 4 * ks, ks == 0)))
-            out.append((("vr", ks), self.mfma("v", V_DP[qb], "v", V_VR + 4 * ks, "a", A_DO[qb] + 4 * ks, ks == 0)))
+            out.append((("vr", ks), self.mfma("v", V_DP[qb], "v", V_VR + 4 * ks, "a", A_DO[qb] + 4 * ks, False)))
         return out
 
     # ---- LDS reads (slot offsets are immediates) ----
     def frag_reads(self, which, idx, slot):
+        if which == "nd":
+            return []
         if which == "kr":
             b = V_KR + 4 * idx
             return [Ins(f"ds_read_b128 {vr(b, 4)}, v{V_ROW + idx} offset:{slot * STG}", "lds", [f"v{V_ROW + idx}"], rl("v", b, 4))]
@@ -135,12 +143,11 @@ class DQ(Gen):
     # ---- VALU stream: P = exp2(S c - lse2), dS = P (dP - D), pack ----
     def grad(self, qb):
         S, DP, DS = V_S[qb], V_DP[qb], V_DS[qb]
-        l2, dd = f"v{V_LSE2[qb]}", f"v{V_D[qb]}"
+        l2 = f"v{V_LSE2[qb]}"
         out = []
         for r in range(16 + 3):
             if r < 16:
                 out.append(Ins(f"v_fma_f32 v{S + r}, v{S + r}, s{S_C}, -{l2}", "valu", [f"v{S + r}", l2], [f"v{S + r}"]))
-                out.append(Ins(f"v_sub_f32 v{DP + r}, v{DP + r}, {dd}", "valu", [f"v{DP + r}", dd], [f"v{DP + r}"]))
             if 0 <= r - 1 < 16:
                 q = r - 1
                 out.append(Ins(f"v_exp_f32 v{S + q}, v{S + q}", "trans", [f"v{S + q}"], [f"v{S + q}"], w=1.6))
@@ -163,18 +170,13 @@ class DQ(Gen):
                            Ins(f"buffer_load_dwordx4 v{vo}, {sr(rs, 4)}, s{so} offen lds", "dma", ["m0", f"v{vo}", f"s{so}"], [], w=4.0)], "dma"))
         return g
 
-    def mask_check(self, qb, stage_expr):
-        """SALU: does stage `S_J + stage_expr` need masking for this q-block?  -> call the mask routine."""
+    def mask_check(self, qb):
+        """SALU: does stage j + 1 (first key S_N0) need masking for this q-block?  -> call the mask routine."""
         t = S_T
         u = self.uid()
-        return [f"s_add_u32 s{t}, s{S_J}, {stage_expr}",
-                f"s_lshl_b32 s{S_N0}, s{t}, 5",
-                f"s_add_u32 s{t}, s{S_N0}, 31",
-                f"s_cmp_gt_i32 s{t}, s{S_HIMIN[qb]}",
-                f"s_cbranch_scc1 L_domask_{u}_%=",
-                f"s_cmp_lt_i32 s{S_N0}, s{S_LOMAX[qb]}",
-                f"s_cbranch_scc0 L_nomask_{u}_%=",
-                f"L_domask_{u}_%=:",
+        return [f"s_sub_u32 s{t}, s{S_N0}, s{S_MLO[qb]}",
+                f"s_cmp_le_u32 s{t}, s{S_MRANGE[qb]}",
+                f"s_cbranch_scc1 L_nomask_{u}_%=",
                 f"s_swappc_b64 {sr(S_RET, 2)}, {sr(S_MASKFN[qb], 2)}",
                 f"L_nomask_{u}_%=:"]
 
@@ -218,11 +220,11 @@ class DQ(Gen):
         lds.sort(key=lambda x: (x[1], x[0]))
         misc = self.dma_groups(slot_dma)
         # ---- phase A: q-block 1 on the matrix pipe, q-block 0's gradient arithmetic (stage j + 1) on the VALU
-        for l in self.mask_check(0, 1):
+        for l in self.mask_check(0):
             A(l)
         self._phase([m for _, m in mfA], self.grad(0), lds, 0, cfg, phase=1, misc=misc, extra=[])
         # ---- phase B
-        for l in self.mask_check(1, 1):
+        for l in self.mask_check(1):
             A(l)
         self._phase([m for _, m in mfB], self.grad(1), lds, nA, cfg, phase=2, misc=misc, extra=[])
         assert not lds, "unissued LDS reads"
@@ -267,6 +269,8 @@ class DQ(Gen):
             A(f"s_addc_u32 s{reg + 1}, s{S_SUB + 1}, 0")
         A(f"s_mov_b32 s{S_OOB}, 0x80000000")
         A(f"s_mov_b32 s{S_J}, s{S_JIN}")
+        A(f"s_add_u32 s{S_N0}, s{S_J}, 1")
+        A(f"s_lshl_b32 s{S_N0}, s{S_N0}, 5")                      # first key of stage j + 1
         A("s_barrier")                                            # previous pass is done with LDS
         # ---- Q -> AGPRs; dO, O -> registers (q-block 0: K-row / V-row fragment registers, q-block 1: K^T fragments and
         # the S / dP accumulators - all dead until the loop); LSE
@@ -303,11 +307,19 @@ class DQ(Gen):
             A(f"s_add_u32 s{S_KSO}, s{S_KSO}, s{S_KSTG}")
             A(f"s_add_u32 s{S_VSO}, s{S_VSO}, s{S_VSTG}")
         # (S_KSO / S_VSO now point at stage j + 4: the first iteration's DMA)
+        # ---- (while the loads are in flight) accumulators 0, virtual gradients 0
+        for i in range(128):
+            A(f"v_accvgpr_write_b32 a{i}, 0")
+        for qb in range(2):
+            for r in range(16):
+                A(f"v_mov_b32 v{V_DP[qb] + r}, 0")
+            for r in range(8):
+                A(f"v_mov_b32 v{V_DS[qb] + r}, 0")
         # ---- D = rowsum(dO o O), lse2, statistics; dO -> AGPRs
         T = V_T
         for qb in range(2):
             A(f"s_waitcnt vmcnt({12 + (1 - qb) * 25})")            # everything of this q-block has landed (12 stage pieces + the other q-block's loads stay in flight)
-            acc, acc2 = f"v{V_D[qb]}", f"v{T + 8}"
+            acc, acc2 = f"v{V_D[qb]}", f"v{T + 4}"
             A(f"v_mov_b32 {acc}, 0")
             A(f"v_mov_b32 {acc2}, 0")
             for i in range(32):
@@ -336,17 +348,49 @@ class DQ(Gen):
             A(f"buffer_store_dword {acc}, v{V_LSEOFF[qb]}, {sr(S_SDRS, 4)}, 0 offen")          # softmax_d
             A(f"buffer_store_dword {l2}, v{V_LSEOFF[qb]}, {sr(S_STRS, 4)}, 0 offen")           # statistics plane 0
             A(f"buffer_store_dword v{T + 2}, v{V_LSEOFF[qb]}, {sr(S_STRS, 4)}, s{S_PLANE} offen")   # plane 1: -D
+            # -D = hi + mid + lo exactly, three 16-bit terms (truncating splits of the fp32 remainder for bf16, rounding ones
+            # for fp16: every remainder is exact in fp32); lanes 32..63 hold the contraction slots 8..15: zeros
+            nd, h, m, lo_, r = f"v{T + 2}", f"v{T + 3}", f"v{T + 4}", f"v{T + 5}", f"v{T + 6}"
+            b0, b1 = f"v{V_ND[qb]}", f"v{V_ND[qb] + 1}"
+            if self.dtype == "bf16":
+                A(f"v_and_b32 {h}, 0xffff0000, {nd}")
+                A(f"v_sub_f32 {r}, {nd}, {h}")
+                A(f"v_and_b32 {m}, 0xffff0000, {r}")
+                A(f"v_sub_f32 {r}, {r}, {m}")
+                A(f"v_lshrrev_b32 {h}, 16, {h}")
+                A(f"v_or_b32 {b0}, {h}, {m}")
+                A(f"v_lshrrev_b32 {b1}, 16, {r}")
+            else:
+                A(f"v_cvt_f16_f32 {h}, {nd}")
+                A(f"v_cvt_f32_f16 {lo_}, {h}")
+                A(f"v_sub_f32 {r}, {nd}, {lo_}")
+                A(f"v_cvt_f16_f32 {m}, {r}")
+                A(f"v_cvt_f32_f16 {lo_}, {m}")
+                A(f"v_sub_f32 {r}, {r}, {lo_}")
+                A(f"v_cvt_f16_f32 {lo_}, {r}")
+                A(f"v_pack_b32_f16 {b0}, {h}, {m}")
+                A(f"v_and_b32 {b1}, 0xffff, {lo_}")
+            A(f"v_mbcnt_lo_u32_b32 {h}, -1, 0")
+            A(f"v_mbcnt_hi_u32_b32 {h}, -1, {h}")
+            A(f"v_cmp_gt_u32 vcc, 32, {h}")
+            A(f"v_cndmask_b32 {b0}, 0, {b0}, vcc")
+            A(f"v_cndmask_b32 {b1}, 0, {b1}, vcc")
+            A(f"v_mov_b32 v{V_ND[qb] + 2}, 0")
+            A(f"v_mov_b32 v{V_ND[qb] + 3}, 0")
+            if qb == 0:
+                one = 0x3f80 if self.dtype == "bf16" else 0x3c00
+                A(f"v_mov_b32 {m}, 0x{one | (one << 16):08x}")
+                A(f"v_mov_b32 {lo_}, 0x{one:08x}")
+                A(f"v_cndmask_b32 v{V_ONE}, 0, {m}, vcc")
+                A(f"v_cndmask_b32 v{V_ONE + 1}, 0, {lo_}, vcc")
+                A(f"v_mov_b32 v{V_ONE + 2}, 0")
+                A(f"v_mov_b32 v{V_ONE + 3}, 0")
             for i in range(32):
                 A(f"v_accvgpr_write_b32 a{A_DO[qb] + i}, v{DOT[qb] + i}")
-        # ---- state: accumulators 0, virtual fragments / gradients 0
-        for i in range(128):
-            A(f"v_accvgpr_write_b32 a{i}, 0")
+        # ---- state: virtual fragments / scores 0 (these registers held dO / O)
         for qb in range(2):
             for r in range(16):
                 A(f"v_mov_b32 v{V_S[qb] + r}, 0")
-                A(f"v_mov_b32 v{V_DP[qb] + r}, 0")
-            for r in range(8):
-                A(f"v_mov_b32 v{V_DS[qb] + r}, 0")
         for r in range(96):
             A(f"v_mov_b32 v{V_KR + r}, 0")
         A("s_waitcnt vmcnt(4)")                                    # stages j+1, j+2 have landed (j+3 in flight); the 6 statistics stores are older
@@ -378,6 +422,7 @@ class DQ(Gen):
             if "vmwait" not in self.ko:
                 A("s_waitcnt vmcnt(4)")
             A(f"s_add_u32 s{S_J}, s{S_J}, 1")
+            A(f"s_add_u32 s{S_N0}, s{S_N0}, 32")
             A(f"s_cmp_lt_i32 s{S_J}, s{S_NMAX}")
             if c < NRING - 1:
                 A("s_cbranch_scc0 L_done_%=")
