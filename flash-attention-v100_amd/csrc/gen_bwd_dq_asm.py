@@ -42,7 +42,9 @@ STG = 16384                     # one stage: K tile 8 KiB + V tile 8 KiB
 NRING = 4
 EP_PITCH = 272                  # epilogue: [64 rows][256 B + 16] per wave
 EP_QB = 32 * EP_PITCH
-LDS_TOTAL = max(NRING * STG, 4 * 2 * EP_QB)
+QST = NRING * STG               # prologue: per wave [Q | dO | O] x [32 rows][256 B] of ONE q-block (24 KiB), behind the ring
+QST_WAVE = 3 * 8192
+LDS_TOTAL = max(QST + 4 * QST_WAVE, 4 * 2 * EP_QB)
 
 # ------------------------------------------------------------------ SGPRs (inputs s16..s59, owned s60..)
 S_QRS, S_DORS, S_ORS, S_KRS, S_VRS, S_DQRS, S_LRS, S_SDRS, S_STRS = 16, 20, 24, 28, 32, 36, 40, 44, 48
@@ -67,9 +69,8 @@ S_MASKFN = (82, 84)
 S_LAST = 85
 
 # ------------------------------------------------------------------ VGPRs (v0..v15 are left to the compiler)
-V_QOFF = (16, 17)               # in: Q voffset of the lane's row (q-block 0 / 1): row * row_bytes + 16 g
-V_DOOFF = (18, 19)
-V_OOFF = (20, 21)
+V_CBS = 16                      # in: v16..v19 = swizzled column byte of the lane's 16-byte DMA chunk for rows 4p + (lane >> 4), p = 0..3
+V_QRB, V_DORB = 20, 21          # in (uniform): bytes per Q / dO row
 V_LSEOFF = (22, 23)             # in: row * 4 (LSE load, softmax_d / statistics stores)
 V_ROW = 24                      # in: 8 row-read addresses (swzt image, tile-relative)
 V_TR = 32                       # in: 8 transposed-read addresses [h][d]
@@ -77,9 +78,9 @@ V_DMAK, V_DMAV = 40, 41         # in: LDS-DMA source voffsets (first piece; the 
 V_LOG = (42, 44)                # in: lo - 4g of the lane's row (0x3fffffff: no row)
 V_WID = (43, 45)                # in: hi - lo
 V_DQRB, V_R0 = 46, 47           # in (uniform): bytes per dQ row, first row of the wave's 64
-V_K16, V_V16 = 48, 49           # in (uniform): 16 rows of K / V in bytes
-# owned
-V_DMAK2, V_DMAV2 = 50, 51
+V_DMAK2, V_DMAV2 = 48, 49       # in: the second piece of a stage (16 rows further)
+V_ORB = 50                      # in (uniform): bytes per O row
+# owned (v51 free)
 V_LSE2 = (52, 54)               # lse * log2e (+inf for rows without keys)
 V_D = (53, 55)                  # rowsum(dO o O)
 V_T = 56                        # temps v56..v63
@@ -272,21 +273,8 @@ class DQ(Gen):
         A(f"s_add_u32 s{S_N0}, s{S_J}, 1")
         A(f"s_lshl_b32 s{S_N0}, s{S_N0}, 5")                      # first key of stage j + 1
         A("s_barrier")                                            # previous pass is done with LDS
-        # ---- Q -> AGPRs; dO, O -> registers (q-block 0: K-row / V-row fragment registers, q-block 1: K^T fragments and
-        # the S / dP accumulators - all dead until the loop); LSE
-        DOT = (V_KR, V_KT)
-        OT = (V_VR, V_S[0])
-        for qb in range(2):
-            for ks in range(8):
-                A(f"buffer_load_dwordx4 {ar(A_Q[qb] + 4 * ks, 4)}, v{V_QOFF[qb]}, {sr(S_QRS, 4)}, 0 offen offset:{32 * ks}")
-            for ks in range(8):
-                A(f"buffer_load_dwordx4 {vr(DOT[qb] + 4 * ks, 4)}, v{V_DOOFF[qb]}, {sr(S_DORS, 4)}, 0 offen offset:{32 * ks}")
-            for ks in range(8):
-                A(f"buffer_load_dwordx4 {vr(OT[qb] + 4 * ks, 4)}, v{V_OOFF[qb]}, {sr(S_ORS, 4)}, 0 offen offset:{32 * ks}")
-            A(f"buffer_load_dword v{V_LSE2[qb]}, v{V_LSEOFF[qb]}, {sr(S_LRS, 4)}, 0 offen")
-        # ---- second DMA piece of a tile: 16 rows further
-        A(f"v_add_u32 v{V_DMAK2}, v{V_K16}, v{V_DMAK}")
-        A(f"v_add_u32 v{V_DMAV2}, v{V_V16}, v{V_DMAV}")
+        DOT = (V_KR, V_KT)          # dO / O of q-block 0: K-row / V-row fragment registers, of q-block 1: K^T fragments and
+        OT = (V_VR, V_S[0])         # the S accumulators - all dead until the loop
         # ---- stages j+1, j+2, j+3 -> ring slots 1, 2, 3 (stage j + 1 = n_min - 1 is virtual: zeros)
         A(f"s_add_u32 s{t}, s{S_J}, 1")
         A(f"s_mul_i32 s{S_KSO}, s{t}, s{S_KSTG}")
@@ -307,18 +295,65 @@ class DQ(Gen):
             A(f"s_add_u32 s{S_KSO}, s{S_KSO}, s{S_KSTG}")
             A(f"s_add_u32 s{S_VSO}, s{S_VSO}, s{S_VSTG}")
         # (S_KSO / S_VSO now point at stage j + 4: the first iteration's DMA)
-        # ---- (while the loads are in flight) accumulators 0, virtual gradients 0
+        # ---- Q, dO, O: whole 256-byte rows by LDS-DMA into a wave-private staging area (each wave its own 32 rows of one
+        # q-block: 3 x 8 pieces of 4 rows), read back as MFMA B fragments (Q -> AGPRs, dO / O -> registers).  Straight
+        # buffer loads in the fragment layout fetch 16-byte shreds of 32 rows per instruction: 16-20 k cycles per pass.
+        VO = V_DP[0]                # 12 lane offsets [tensor][p]: (4p + (lane >> 4)) * row_bytes + swizzled column byte
+        AD = V_DP[1]                # 8 fragment read addresses inside the staging area
+        S_P = (t + 2, t + 3, t + 4)  # s: bytes per Q / dO / O row (the stage DMA above is done with these temps)
+        S_ROW0 = S_RET              # s: first row of the wave (the call registers are idle until the loop)
+        SB = S_RET + 1              # s: staging base of the wave
+        A(f"v_mbcnt_lo_u32_b32 v{V_T}, -1, 0")
+        A(f"v_mbcnt_hi_u32_b32 v{V_T}, -1, v{V_T}")
+        A(f"v_lshrrev_b32 v{V_T}, 4, v{V_T}")                     # lane >> 4
+        A(f"v_readfirstlane_b32 s{S_P[0]}, v{V_QRB}")
+        A(f"v_readfirstlane_b32 s{S_P[1]}, v{V_DORB}")
+        A(f"v_readfirstlane_b32 s{S_P[2]}, v{V_ORB}")
+        A(f"v_readfirstlane_b32 s{S_ROW0}, v{V_R0}")
+        A("s_nop 4")
+        for ti in range(3):
+            for pp in range(4):
+                A(f"v_add_u32 v{V_T + 1}, {4 * pp}, v{V_T}")
+                A(f"v_mad_u32_u24 v{VO + 4 * ti + pp}, v{V_T + 1}, s{S_P[ti]}, v{V_CBS + pp}")
+        A(f"s_mul_i32 s{SB}, s{S_W1024}, {QST_WAVE // 1024}")
+        A(f"s_add_u32 s{SB}, s{SB}, {QST}")
+        for ks in range(8):
+            A(f"v_add_u32 v{AD + ks}, s{SB}, v{V_ROW + ks}")
+
+        def stage_rows(qb):
+            """this wave's 32 rows of q-block qb: 24 pieces"""
+            for ti, rs in enumerate((S_QRS, S_DORS, S_ORS)):
+                A(f"s_add_u32 s{t}, s{S_ROW0}, {32 * qb}")
+                A(f"s_mul_i32 s{t}, s{t}, s{S_P[ti]}")                    # byte offset of the q-block's first row
+                A(f"s_lshl_b32 s{t + 1}, s{S_P[ti]}, 4")
+                A(f"s_add_u32 s{t + 1}, s{t + 1}, s{t}")                  # ... and of its 16th
+                for pc in range(8):
+                    A(f"s_add_u32 m0, s{SB}, {ti * 8192 + 1024 * pc}")
+                    A("s_nop 0")
+                    A(f"buffer_load_dwordx4 v{VO + 4 * ti + pc % 4}, {sr(rs, 4)}, s{t + pc // 4} offen lds")
+
+        def read_rows(qb):
+            for ks in range(8):
+                A(f"ds_read_b128 {ar(A_Q[qb] + 4 * ks, 4)}, v{AD + ks}")
+                A(f"ds_read_b128 {vr(DOT[qb] + 4 * ks, 4)}, v{AD + ks} offset:8192")
+                A(f"ds_read_b128 {vr(OT[qb] + 4 * ks, 4)}, v{AD + ks} offset:16384")
+        stage_rows(0)
+        for qb in range(2):
+            A(f"buffer_load_dword v{V_LSE2[qb]}, v{V_LSEOFF[qb]}, {sr(S_LRS, 4)}, 0 offen")
+        # ---- (while the loads are in flight) accumulators 0
         for i in range(128):
             A(f"v_accvgpr_write_b32 a{i}, 0")
-        for qb in range(2):
-            for r in range(16):
-                A(f"v_mov_b32 v{V_DP[qb] + r}, 0")
-            for r in range(8):
-                A(f"v_mov_b32 v{V_DS[qb] + r}, 0")
+        A("s_waitcnt vmcnt(0)")
+        read_rows(0)
+        A("s_waitcnt lgkmcnt(0)")
+        stage_rows(1)                                             # (q-block 0's D is computed while these are in flight)
         # ---- D = rowsum(dO o O), lse2, statistics; dO -> AGPRs
         T = V_T
         for qb in range(2):
-            A(f"s_waitcnt vmcnt({12 + (1 - qb) * 25})")            # everything of this q-block has landed (12 stage pieces + the other q-block's loads stay in flight)
+            if qb == 1:
+                A("s_waitcnt vmcnt(0)")                            # q-block 1's rows have landed (q-block 0's statistics are stored below)
+                read_rows(1)
+                A("s_waitcnt lgkmcnt(0)")
             acc, acc2 = f"v{V_D[qb]}", f"v{T + 4}"
             A(f"v_mov_b32 {acc}, 0")
             A(f"v_mov_b32 {acc2}, 0")
@@ -345,9 +380,15 @@ class DQ(Gen):
             A(f"v_mul_f32 {l2}, 0x3fb8aa3b, {l2}")
             A(f"v_cndmask_b32 {l2}, {l2}, v{T + 1}, vcc")             # rows without keys: P = exp2(S c - inf) = 0
             A(f"v_sub_f32 v{T + 2}, 0, {acc}")
-            A(f"buffer_store_dword {acc}, v{V_LSEOFF[qb]}, {sr(S_SDRS, 4)}, 0 offen")          # softmax_d
-            A(f"buffer_store_dword {l2}, v{V_LSEOFF[qb]}, {sr(S_STRS, 4)}, 0 offen")           # statistics plane 0
-            A(f"buffer_store_dword v{T + 2}, v{V_LSEOFF[qb]}, {sr(S_STRS, 4)}, s{S_PLANE} offen")   # plane 1: -D
+            if qb == 1:       # q-block 0's stores were held back: a store completing out of order must not satisfy the DMA wait above
+                A(f"buffer_store_dword v{V_D[0]}, v{V_LSEOFF[0]}, {sr(S_SDRS, 4)}, 0 offen")
+                A(f"buffer_store_dword v{V_LSE2[0]}, v{V_LSEOFF[0]}, {sr(S_STRS, 4)}, 0 offen")
+                A(f"buffer_store_dword v{T + 7}, v{V_LSEOFF[0]}, {sr(S_STRS, 4)}, s{S_PLANE} offen")
+                A(f"buffer_store_dword {acc}, v{V_LSEOFF[qb]}, {sr(S_SDRS, 4)}, 0 offen")          # softmax_d
+                A(f"buffer_store_dword {l2}, v{V_LSEOFF[qb]}, {sr(S_STRS, 4)}, 0 offen")           # statistics plane 0
+                A(f"buffer_store_dword v{T + 2}, v{V_LSEOFF[qb]}, {sr(S_STRS, 4)}, s{S_PLANE} offen")   # plane 1: -D
+            else:
+                A(f"v_mov_b32 v{T + 7}, v{T + 2}")                 # -D of q-block 0, stored with q-block 1's
             # -D = hi + mid + lo exactly, three 16-bit terms (truncating splits of the fp32 remainder for bf16, rounding ones
             # for fp16: every remainder is exact in fp32); lanes 32..63 hold the contraction slots 8..15: zeros
             nd, h, m, lo_, r = f"v{T + 2}", f"v{T + 3}", f"v{T + 4}", f"v{T + 5}", f"v{T + 6}"
@@ -387,13 +428,16 @@ class DQ(Gen):
                 A(f"v_mov_b32 v{V_ONE + 3}, 0")
             for i in range(32):
                 A(f"v_accvgpr_write_b32 a{A_DO[qb] + i}, v{DOT[qb] + i}")
-        # ---- state: virtual fragments / scores 0 (these registers held dO / O)
+        # ---- state: virtual fragments / scores / gradients 0 (these registers held dO / O and the prologue's addresses)
         for qb in range(2):
             for r in range(16):
                 A(f"v_mov_b32 v{V_S[qb] + r}, 0")
+                A(f"v_mov_b32 v{V_DP[qb] + r}, 0")
+            for r in range(8):
+                A(f"v_mov_b32 v{V_DS[qb] + r}, 0")
         for r in range(96):
             A(f"v_mov_b32 v{V_KR + r}, 0")
-        A("s_waitcnt vmcnt(4)")                                    # stages j+1, j+2 have landed (j+3 in flight); the 6 statistics stores are older
+        A("s_waitcnt vmcnt(0)")
         stamp(1)
         # ---- the loop: four copies (ring slots as immediates)
         report = {}
@@ -507,7 +551,7 @@ DEFAULT_CFG = {
 
 def clobbers():
     c = ["memory", "vcc", "scc", "m0"]
-    c += [f"v{i}" for i in range(V_DMAK2, 256)]
+    c += [f"v{i}" for i in range(V_ORB + 1, 256)]
     c += [f"a{i}" for i in range(256)]
     c += [f"s{i}" for i in range(S_J, S_LAST + 1)]
     return c
