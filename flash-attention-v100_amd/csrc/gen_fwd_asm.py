@@ -26,7 +26,9 @@ import sys
 
 # ----------------------------------------------------------------------------- register map
 # VGPR (v0-v15 are left to the compiler)
-V_QOFF = (16, 17)        # in: Q voffset of qb0 / qb1 (prologue only)
+V_QOFF = (16, 17)        # in, D = 64: Q voffset of qb0 / qb1 (prologue only)
+V_QCB, V_QROW = 16, 17   # in, D = 128: swizzled column byte of the lane's 16-byte chunk for row (lane >> 4) of a 4-row DMA piece
+                         # (rows 4p + (lane >> 4): the byte ^ 64 p), and (lane >> 4) * q_row_bytes
 V_ORB, V_R0 = 18, 19     # in (uniform): bytes per O row, first row of the wave's 64
 V_LSEOFF = (20, 21)      # in: LSE voffset
 V_DMAK, V_DMAV = 22, 23  # in: LDS-DMA source voffsets
@@ -83,6 +85,7 @@ S_KJ = 75                # s75..s77: 1,2,3 x 16 K rows in bytes (fast-loop DMA s
 S_VJ = 78                # s78..s80
 S_LAST = 80
 S_RC, S_FASTLO, S_FASTEND = 81, 82, 83     # in: 1 / c; fast-loop iteration range [lo, end)
+S_QRB = 84               # in (D = 128): bytes per Q row
 
 # ----------------------------------------------------------------------------- head dimension (128 or 64)
 HD = 128
@@ -744,10 +747,34 @@ class Gen:
             A(f"s_mul_i32 s{S_KJ + jj - 1}, s{S_K16}, {jj}")
             A(f"s_mul_i32 s{S_VJ + jj - 1}, s{S_V16}, {jj}")
         A("s_barrier")                                   # previous pass: every wave is done with the LDS ring
-        # ---- Q fragments -> AGPRs
-        for qb in range(2):
-            for ks in range(KS):
-                A(f"buffer_load_dwordx4 {ar(A_Q[qb] + 4 * ks, 4)}, v{V_QOFF[qb]}, {sr(S_QRS, 4)}, 0 offen offset:{32 * ks}")
+        stage_q = HD == 128 and cfg.get("stage_q", True)
+        QST = 6 * LDS_STAGE                              # Q staging area behind the ring: 16 KiB per wave
+        if stage_q:
+            # ---- Q: the wave's 64 rows as whole 256-byte rows by LDS-DMA (16 pieces of 4 rows) into a wave-private staging
+            # area in the K image's layout, read back as B fragments below.  (Straight buffer loads in the fragment layout
+            # fetch 16-byte shreds of 32 rows per instruction: the prologue of a pass took 6-9 k cycles.)
+            sb, so, s16r, s4p = S_N0, S_SUB, S_SUB + 1, S_RET
+            A(f"s_lshl_b32 s{sb}, s{S_W1024}, 4")                   # wave * 16384
+            A(f"s_add_u32 s{sb}, s{sb}, {QST}")
+            A(f"v_readfirstlane_b32 s{so}, v{V_R0}")
+            A(f"s_lshl_b32 s{s16r}, s{S_QRB}, 4")                   # 16 rows
+            A("s_nop 2")
+            A(f"s_mul_i32 s{so}, s{so}, s{S_QRB}")                  # byte offset of the wave's first row
+            for pp in range(4):
+                A(f"s_mul_i32 s{s4p}, s{S_QRB}, {4 * pp}")
+                A(f"v_xor_b32 v{V_T + pp}, {64 * pp}, v{V_QCB}")
+                A(f"v_add3_u32 v{V_T + pp}, v{V_T + pp}, v{V_QROW}, s{s4p}")
+            for pc in range(16):
+                A(f"s_add_u32 m0, s{sb}, {1024 * pc}")
+                A("s_nop 0")
+                A(f"buffer_load_dwordx4 v{V_T + pc % 4}, {sr(S_QRS, 4)}, s{so} offen lds")
+                if pc % 4 == 3:
+                    A(f"s_add_u32 s{so}, s{so}, s{s16r}")
+        else:
+            # ---- Q fragments -> AGPRs
+            for qb in range(2):
+                for ks in range(KS):
+                    A(f"buffer_load_dwordx4 {ar(A_Q[qb] + 4 * ks, 4)}, v{V_QOFF[qb]}, {sr(S_QRS, 4)}, 0 offen offset:{32 * ks}")
         # ---- first tiles: K(n_min) -> R1, V(n_min) -> R1, K(n_min+1) -> R2      (n_min = j_start + 2)
         t = S_TMP
         A(f"s_add_u32 s{t}, s{S_J}, 2")
@@ -773,6 +800,15 @@ class Gen:
                 cr = float((r & 3) + 8 * (r >> 2))
                 A(f"v_mul_f32 v{V_C0 + r}, 0x{struct.unpack('<I', struct.pack('<f', cr))[0]:08x}, v{V_BETA}")
         A(f"s_waitcnt vmcnt({2 * NP})")                  # Q and K(n_min) have landed
+        if stage_q:
+            A(f"s_lshl_b32 s{S_N0}, s{S_W1024}, 4")
+            A(f"s_add_u32 s{S_N0}, s{S_N0}, {QST}")
+            for ks in range(KS):
+                A(f"v_add_u32 v{V_T + ks}, s{S_N0}, v{V_KBASE + ks}")
+            for qb in range(2):
+                for ks in range(KS):
+                    A(f"ds_read_b128 {ar(A_Q[qb] + 4 * ks, 4)}, v{V_T + ks} offset:{8192 * qb}")
+            A("s_waitcnt lgkmcnt(0)")
         stamp(1)
 
         # ---- iteration loop + dispatch
@@ -998,7 +1034,7 @@ def main():
         cfg["dma_gaps"] = {int(k): v for k, v in cfg["dma_gaps"].items()}
     print("// GENERATED by gen_fwd_asm.py - do not edit.  See that script for the schedule and the register map.")
     print("#pragma once")
-    print(f"#define {prefix}_LDS_BYTES {6 * LDS_STAGE}")
+    print(f"#define {prefix}_LDS_BYTES {6 * LDS_STAGE + (65536 if HD == 128 and cfg.get('stage_q', True) else 0)}")
     for alibi in (False, True):
         tag = "ALIBI_" if alibi else ""
         for dt in ("bf16", "f16"):

@@ -60,6 +60,7 @@ def test_bench_json_line_contract():
     # the per-kernel medians (individually evented launches) compose the step they were taken next to
     t = d["kernels"]["timing"]
     assert abs(t["sum_of_kernels_ms"] - (d["kernels"]["fwd"]["ms"] + d["kernels"]["bwd_all"]["ms"])) < 1e-3
-    assert 0.97 <= t["sum_over_step"] <= 1.03, t
+    assert 0.97 <= t["sum_over_step_evented"] <= 1.03, t        # same statistic on both sides: the kernels compose the step
+    assert 0.95 <= t["sum_over_step"] <= 1.03, t                # vs the wall-clock mean of the timed steps (outliers, host tail)
     for name in ("fwd", "bwd_dq", "bwd_all"):
         assert d["kernels"][name]["ms_min"] <= d["kernels"][name]["ms"]
