@@ -26,7 +26,8 @@ Structure (one wave per SIMD, 512 registers, 4 waves x 64 query rows = 256-row w
   * a stage = 32 keys: K tile + V tile (8 KiB each, the `swzt` image of fa_common.h that serves row and transposed reads)
     arrive by LDS-DMA in a ring of four 16 KiB slots, issued two iterations ahead behind a counted vmcnt; the loop is
     unrolled by four so that every LDS address is an immediate;
-  * the pipeline is filled and drained by VIRTUAL stages (zero-filled through an out-of-range DMA source, fully
+  * q-block 0's S / dP of the first stage are computed in front of the loop and the last iteration ends after phase A;
+    what is left of fill and drain works on VIRTUAL stages (zero-filled through an out-of-range DMA source, fully
     masked): one loop body; masks (causal / window / key tail) set S = -inf in a called routine on edge stages only;
   * prologue: Q -> AGPRs, dO and O -> registers, D = rowsum(dO o O) in fp32 (the fused preprocess: this kernel runs
     first and leaves softmax_d and the statistics planes of the asm dK/dV kernel behind), dO -> AGPRs;
@@ -49,7 +50,7 @@ LDS_TOTAL = max(QST + 4 * QST_WAVE, 4 * 2 * EP_QB)
 # ------------------------------------------------------------------ SGPRs (inputs s16..s59, owned s60..)
 S_QRS, S_DORS, S_ORS, S_KRS, S_VRS, S_DQRS, S_LRS, S_SDRS, S_STRS = 16, 20, 24, 28, 32, 36, 40, 44, 48
 S_C, S_SCALE = 52, 53           # softmax_scale * log2e, softmax_scale
-S_JIN, S_NMAX, S_NMIN = 54, 55, 56   # first iteration (n_min - 2), stage range [n_min, n_max)
+S_JIN, S_NMAX, S_NMIN = 54, 55, 56   # first iteration (n_min - 1), stage range [n_min, n_max)
 S_KSTG, S_VSTG = 57, 58         # bytes of one 32-key stage of K / V
 S_W1024 = 59
 S_MLO = (60, 62)                # in: a stage starting at key n0 is free of masks for the q-block iff (n0 - MLO) <=u MRANGE
@@ -224,6 +225,10 @@ class DQ(Gen):
         for l in self.mask_check(0):
             A(l)
         self._phase([m for _, m in mfA], self.grad(0), lds, 0, cfg, phase=1, misc=misc, extra=[])
+        # ---- the last iteration (j = n_max - 1) ends here: its phase B would touch virtual stages only
+        A(f"s_add_u32 s{t}, s{S_J}, 1")
+        A(f"s_cmp_ge_i32 s{t}, s{S_NMAX}")
+        A("s_cbranch_scc1 L_done_%=")
         # ---- phase B
         for l in self.mask_check(1):
             A(l)
@@ -438,6 +443,19 @@ class DQ(Gen):
         for r in range(96):
             A(f"v_mov_b32 v{V_KR + r}, 0")
         A("s_waitcnt vmcnt(0)")
+        # ---- q-block 0 runs half an iteration ahead: S0 / dP0 of the first stage (ring slot 1) before the loop, so that
+        # the loop starts at j = n_min - 1 (no virtual iteration in front)
+        A("s_barrier")                                            # every wave's pieces of the first stages have landed
+        self.out, self.stats = [], {"nop_states": 0, "lgkm_waits": 0}
+        self.reset_dq(mfma_age=0)
+        for ks in range(8):
+            for which in ("kr", "vr"):
+                for ins in self.frag_reads(which, ks, 1):
+                    self.emit(ins)
+        for _, mf in self.sdp_mfmas(0):
+            self.emit(mf)
+        self.drain_lds()
+        L += self.out
         stamp(1)
         # ---- the loop: four copies (ring slots as immediates)
         report = {}
@@ -526,8 +544,9 @@ class DQ(Gen):
                 A(f"buffer_store_dwordx4 {vr(ST + 4 * j, 4)}, v{goff}, {sr(S_DQRS, 4)}, s{t + 3} offen")
                 A(f"s_add_u32 s{t + 3}, s{t + 3}, s{t + 1}")
             A("s_nop 1")
-        A("s_waitcnt vmcnt(0)")
+        # (no wait for the stores: their data left the registers at issue, and nothing below reads what they write)
         if timers:
+            A("s_waitcnt vmcnt(0)")
             stamp(3)
             A("s_mov_b64 exec, 1")
             for i in range(4):

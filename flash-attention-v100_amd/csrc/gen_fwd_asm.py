@@ -989,8 +989,9 @@ class Gen:
                 A(f"buffer_store_dwordx4 {vr(V_S[0] + 4 * j, 4)}, v{goff}, {sr(S_ORS, 4)}, s{t + 3} offen")
                 A(f"s_add_u32 s{t + 3}, s{t + 3}, s{t + 1}")
             A("s_nop 1")
-        A("s_waitcnt vmcnt(0)")
+        # (no wait for the stores: their data left the registers at issue, and nothing below reads what they write)
         if timers:
+            A("s_waitcnt vmcnt(0)")
             stamp(3)
             A("s_mov_b64 exec, 1")
             for i in range(6):
