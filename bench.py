@@ -411,7 +411,7 @@ def main():
         fwd_kernel = "fa_fwd_kernel" if os.environ.get("FA_FWD_ASM") == "0" else "fa_fwd_asm_kernel"
         dkdv_kernel = "fa_bwd_dkdv2_kernel" if os.environ.get("FA_BWD_ASM") == "0" else "fa_bwd_dkdv_asm_kernel"
         roofline = {"bound": "mfma", "kernel": {"fwd": fwd_kernel, "bwd_dkdv": dkdv_kernel,
-                                                  "bwd_dq": "fa_bwd_dq_kernel"}[dom],
+                                                  "bwd_dq": "fa_bwd_dq_kernel" if os.environ.get("FA_BWD_DQ_ASM") == "0" else "fa_bwd_dq_asm_kernel"}[dom],
                     "achieved": kernels[dom]["achieved"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                     "frac": kernels[dom]["frac"], "traffic": None}
         tr = measured_traffic(roofline["kernel"])
