@@ -320,6 +320,13 @@ static inline void fa_set_max_lds(std::atomic<uint64_t>& done, const void* kern,
         fa_set_max_lds(fa_attr_done_, reinterpret_cast<const void*>(kern), (int)(bytes)); \
     } while (0)
 
+// Mirrored block pairs (causal masks): the low block first in every workgroup.  -DFA_PAIR_FLIP=1 (experiment build)
+// alternates the order with the workgroup index so that the pro / epilogues of the CUs do not line up at launch:
+// measured 1-2 % SLOWER on forward and dQ at config 2 (tools/experiments/README.md)
+#ifndef FA_PAIR_FLIP
+#define FA_PAIR_FLIP 0
+#endif
+
 // Host-side launch args: the ABI struct plus derived values.
 struct KArgs {
     fa_params p;
