@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <atomic>
+#include <stdlib.h>
 #include "fa_mi355.h"
 
 namespace fa {
@@ -326,6 +327,21 @@ static inline void fa_set_max_lds(std::atomic<uint64_t>& done, const void* kern,
 #ifndef FA_PAIR_FLIP
 #define FA_PAIR_FLIP 0
 #endif
+
+// Dense causal-like problems on the 256-row hand-scheduled kernels (forward, dQ): with an ODD number of 256-row blocks the
+// middle block has no mirror and runs alone, and a last block that is half empty idles two of the four waves - measured
+// against the 128-row compiler kernels (tools/seqlen_sweep.py, 8 k / 32 k / 131 k tokens): 3 blocks (S 640, 768) +17 ... +47 %,
+// 5 and 7 blocks -5 ... +22 %, S 384 / 896 (128 valid rows in the last block) +4 ... +8 %, every other length 5 - 13 % faster.
+// `paired`: the launch pairs mirrored blocks (causal-like mask without a left window).  FA_ASM_FORCE=1 (read per call:
+// tests switch it) takes the hand-scheduled kernels wherever they are correct.
+static inline bool asm_256row_blocks_pay(int seqlen_q, bool paired) {
+    const char* e = getenv("FA_ASM_FORCE");
+    if (e && e[0] == '1') return true;
+    const int n = (seqlen_q + 255) / 256, waste = n * 256 - seqlen_q;
+    if (paired && (n < 2 || ((n & 1) && n < 9))) return false;
+    if (waste >= 128 && n < 6) return false;
+    return true;
+}
 
 // Host-side launch args: the ABI struct plus derived values.
 struct KArgs {

@@ -12,6 +12,13 @@ def test_random_cases_agree_with_oracle(kind, n):
     fuzz_cases.run(kind, seed=20260928, n=n)
 
 
+def test_random_long_cases_on_the_hand_scheduled_kernels(monkeypatch):
+    """the same long dense cases with the dispatch heuristic off (FA_ASM_FORCE=1): lengths the 256-row kernels are correct
+    but not fastest for (3 / 5 / 7 blocks, half-empty last block) stay covered"""
+    monkeypatch.setenv("FA_ASM_FORCE", "1")
+    fuzz_cases.run("dense_long", seed=20260929, n=16)
+
+
 # the three cases the round-2 soak logged (gpurun_out/soak_{1001,1005,1008}.log): two-key sequences whose dQ is a small
 # difference.  Pinned here with the checker in its independent form (the oracle backward is fed round_to(o_ref), not the
 # kernel's own output).
