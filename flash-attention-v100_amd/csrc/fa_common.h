@@ -303,6 +303,36 @@ static inline int work_grid(int batch, int nheads_q, int nheads_k, int n_qblocks
     return 8 * upx * (nheads_q / nheads_k) * n_qblocks;
 }
 
+// 16 x fp8-e4m3 -> 16 x 16-bit with gfx950's packed converts: one VALU op per TWO elements
+// (v_cvt_scalef32_pk_{f16,bf16}_fp8; probed in tools/probes/probe_cvt_scalef32.hip: exact for all
+// 256 byte patterns at scale 1.0, and the f32 scale operand contributes only its exponent - so the
+// cache descales stay folded into the softmax scale / the final normalisation).
+template <typename T>
+__device__ __forceinline__ uint32_t fp8x2_to_16bit(uint32_t w, bool hi_word);
+template <>
+__device__ __forceinline__ uint32_t fp8x2_to_16bit<fp16_tag>(uint32_t w, bool hi_word) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const h2 r = hi_word ? __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w, 1.0f, true)
+                         : __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w, 1.0f, false);
+    return __builtin_bit_cast(uint32_t, r);
+}
+template <>
+__device__ __forceinline__ uint32_t fp8x2_to_16bit<bf16_tag>(uint32_t w, bool hi_word) {
+    typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+    const b2 r = hi_word ? __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w, 1.0f, true)
+                         : __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w, 1.0f, false);
+    return __builtin_bit_cast(uint32_t, r);
+}
+template <typename T>
+__device__ __forceinline__ void fp8x16_to_16bit(const u32x4& in, u32x4& lo, u32x4& hi) {
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const uint32_t p0 = fp8x2_to_16bit<T>(in[w], false), p1 = fp8x2_to_16bit<T>(in[w], true);
+        if (w < 2) { lo[2 * w] = p0; lo[2 * w + 1] = p1; }
+        else       { hi[2 * (w - 2)] = p0; hi[2 * (w - 2) + 1] = p1; }
+    }
+}
+
 // Raise a kernel's dynamic-LDS limit once per instantiation AND DEVICE: the attribute belongs to the device's copy of
 // the function, and one process may drive several GPUs (the Python layer wraps every call in torch.cuda.device(q.device)).
 // `done` is a per-instantiation bit mask over device ordinals (devices >= 64 set the attribute on every launch); a failed

@@ -50,7 +50,10 @@ template <int D> struct FwdSmem {
 
 // BIAS: 0 none, 1 general (ALiBi and/or softcap per element), 2 causal ALiBi through the matrix pipe,
 //       3 softcap only (constants folded: exp2, add, rcp, fma per element)
-template <typename T, int D, int BIAS, bool PAGED, bool DROPOUT>
+// KV8: the K / V rows are fp8-e4m3 (KV cache): a tile is fetched to registers (16 codes per chunk), dequantised with the
+//      packed converts of fa_common.h and written to the same LDS images - ONCE per 128 query rows (chunked prefill over an
+//      fp8 cache); `k_descale` folds into the softmax scale, `v_descale` into the final normalisation.
+template <typename T, int D, int BIAS, bool PAGED, bool DROPOUT, bool KV8 = false>
 __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : FA_FWD_OCC)) fa_fwd_kernel(const KArgs a) {
     using E = Elem<T>;
     constexpr int KSTEPS = D / 16;
@@ -155,6 +158,16 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : FA_FWD_OCC)) fa_fw
         vp += vb_off + k_row0 * p.v_row_stride;
     }
     const int32_t* btab = PAGED ? p.block_table + (int64_t)w.b * p.block_table_batch_stride : nullptr;
+    // fp8 cache: byte pointers (strides are in elements = bytes)
+    const uint8_t* kp8 = nullptr; const uint8_t* vp8 = nullptr;
+    if (KV8) {
+        kp8 = reinterpret_cast<const uint8_t*>(p.k) + (int64_t)w.hk * p.k_head_stride;
+        vp8 = reinterpret_cast<const uint8_t*>(p.v) + (int64_t)w.hk * p.v_head_stride;
+        if (!PAGED) {
+            kp8 += (int64_t)kv_b * p.k_batch_stride + k_row0 * p.k_row_stride;
+            vp8 += (int64_t)kv_b * p.v_batch_stride + k_row0 * p.v_row_stride;
+        }
+    }
 
     float slope = 0.f;                                 // ALiBi slope (natural-log score units)
     if (BIAS && p.alibi_slopes) slope = p.alibi_slopes[w.b * p.alibi_batch_stride + w.h];
@@ -208,6 +221,9 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : FA_FWD_OCC)) fa_fw
     // Paged K/V: one page lookup per row -> global_load to registers, ds_write after the MFMAs.
     constexpr int ROWS_PI = 64 / CPR;
     u32x4 kreg[PAGED ? CHUNKS : 1], vreg[PAGED ? CHUNKS : 1];
+    constexpr int CPR8 = D / 16;                                        // 16-byte chunks (16 codes) per fp8 row
+    constexpr int CH8 = FWD_BN * CPR8 / FWD_THREADS;                    // fp8 chunks per thread and tile
+    u32x4 k8reg[KV8 ? CH8 : 1], v8reg[KV8 ? CH8 : 1];
     uint32_t k_voff[CHUNKS], v_voff[CHUNKS];
     int k_lds[CHUNKS], v_lds[CHUNKS];
 #pragma unroll
@@ -233,7 +249,7 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : FA_FWD_OCC)) fa_fw
     // Paged K/V, aligned case (a 64-key tile never straddles a page: page % 64 == 0 by contract and the left
     // pad is a multiple of 64): the same LDS-DMA as the contiguous path through a per-tile descriptor built
     // from ONE block-table lookup; otherwise the per-row register path.
-    const bool paged_dma = PAGED && (k_row0 % FWD_BN == 0) && (p.page_block_size % FWD_BN == 0);
+    const bool paged_dma = PAGED && !KV8 && (k_row0 % FWD_BN == 0) && (p.page_block_size % FWD_BN == 0);
     uint32_t pk_voff[PAGED ? CHUNKS : 1], pv_voff[PAGED ? CHUNKS : 1];
     if (PAGED) {
 #pragma unroll
@@ -255,6 +271,31 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : FA_FWD_OCC)) fa_fw
     // issue the loads of tile nb; for the DMA path they land directly in LDS stage `stage`
     auto load_tile = [&](int nb, auto stage_c) {
         constexpr int stage = decltype(stage_c)::value;
+        if constexpr (KV8) {
+            const int n0 = nb * FWD_BN;
+#pragma unroll
+            for (int i = 0; i < CH8; ++i) {
+                const int c8 = tid + i * FWD_THREADS;
+                const int row = c8 / CPR8, cc8 = c8 % CPR8;
+                const int j = n0 + row;
+                u32x4 z = {0, 0, 0, 0};
+                k8reg[i] = z; v8reg[i] = z;
+                if (j < seqlen_k && cc8 * 16 < dv) {
+                    if (PAGED) {
+                        const int pos = j + (int)k_row0;
+                        const int pg = pos / p.page_block_size;
+                        const int pr = pos - pg * p.page_block_size;
+                        const int64_t phys = btab[pg];
+                        k8reg[i] = *reinterpret_cast<const u32x4*>(kp8 + phys * p.k_batch_stride + (int64_t)pr * p.k_row_stride + cc8 * 16);
+                        v8reg[i] = *reinterpret_cast<const u32x4*>(vp8 + phys * p.v_batch_stride + (int64_t)pr * p.v_row_stride + cc8 * 16);
+                    } else {
+                        k8reg[i] = *reinterpret_cast<const u32x4*>(kp8 + (int64_t)j * p.k_row_stride + cc8 * 16);
+                        v8reg[i] = *reinterpret_cast<const u32x4*>(vp8 + (int64_t)j * p.v_row_stride + cc8 * 16);
+                    }
+                }
+            }
+            return;
+        }
         if (PAGED && paged_dma) {
             const int n0 = nb * FWD_BN;
             const int pos0 = n0 + (int)k_row0;
@@ -300,6 +341,22 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : FA_FWD_OCC)) fa_fw
     };
     auto store_tile = [&](auto stage_c) {
         constexpr int stage = decltype(stage_c)::value;
+        if constexpr (KV8) {
+            char* base = smem + stage * STAGE;
+#pragma unroll
+            for (int i = 0; i < CH8; ++i) {
+                const int c8 = tid + i * FWD_THREADS;
+                const int row = c8 / CPR8, cc8 = c8 % CPR8;
+                u32x4 l0, h0, l1, h1;
+                fp8x16_to_16bit<T>(k8reg[i], l0, h0);
+                fp8x16_to_16bit<T>(v8reg[i], l1, h1);
+                lds_write_b128(base + swz_row_off<D>(row, cc8 * 32), l0);
+                lds_write_b128(base + swz_row_off<D>(row, cc8 * 32 + 16), h0);
+                lds_write_b128(base + TILE + swzt_row_off<D>(row, cc8 * 32), l1);
+                lds_write_b128(base + TILE + swzt_row_off<D>(row, cc8 * 32 + 16), h1);
+            }
+            return;
+        }
         if (PAGED && !paged_dma) {
             char* base = smem + stage * STAGE;
 #pragma unroll
@@ -346,7 +403,7 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : FA_FWD_OCC)) fa_fw
     // split into a 16-bit head and tail.  No per-element VALU work is left, versus 5 per element
     // on the general path below (measured at BASELINE config 5's shard: 652 -> see DESIGN.md).
     constexpr bool lin = BIAS == 2;        // host guarantees: slopes given, no softcap, wr == 0
-    const float c = ((BIAS == 1) || (BIAS == 3)) ? 1.0f : a.scale_log2e;
+    const float c = ((BIAS == 1) || (BIAS == 3)) ? 1.0f : a.scale_log2e * (KV8 ? p.k_descale : 1.0f);
     const float slope2 = slope * kLog2e;
     u32x4 pos_a[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
     u32x4 slope_b = {0, 0, 0, 0};
@@ -609,7 +666,7 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : FA_FWD_OCC)) fa_fw
 
     // ---- epilogue: O / l, LSE ---------------------------------------------------------------
     const float l_tot = xhalf_sum(l_run);
-    const float inv = l_tot > 0.f ? (DROPOUT ? a.rp_dropout : 1.0f) / l_tot : 0.f;
+    const float inv = l_tot > 0.f ? (DROPOUT ? a.rp_dropout : (KV8 ? p.v_descale : 1.0f)) / l_tot : 0.f;
     if (my_row < seqlen_q) {
         uint16_t* op = reinterpret_cast<uint16_t*>(p.o) + (p.cu_seqlens_q ? 0 : (int64_t)w.b * p.o_batch_stride)
                        + (q_row0 + my_row) * p.o_row_stride + (int64_t)w.h * p.o_head_stride;
@@ -643,6 +700,22 @@ static int launch_fwd_td(const KArgs& a, bool paged, hipStream_t stream) {
         FA_SET_LDS_ONCE(kern, smem);               /* once per instantiation and device */    \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(FWD_THREADS), smem, stream, a);               \
     } while (0)
+    if (a.p.kv_dtype == FA_FP8_E4M3) {             // fp8 KV cache (general path: more than 32 packed query rows per kv-head)
+        if constexpr (D <= 128) {
+            if (a.has_bias || a.p.p_dropout > 0.f) return -2;
+#define FA_LAUNCH8(PAGED)                                                                       \
+            do {                                                                                \
+                auto kern = fa_fwd_kernel<T, D, 0, PAGED, false, true>;                         \
+                FA_SET_LDS_ONCE(kern, smem);                                                    \
+                hipLaunchKernelGGL(kern, dim3(grid), dim3(FWD_THREADS), smem, stream, a);       \
+            } while (0)
+            if (paged) FA_LAUNCH8(true); else FA_LAUNCH8(false);
+#undef FA_LAUNCH8
+            return 0;
+        } else {
+            return -2;
+        }
+    }
     const bool drop = a.p.p_dropout > 0.f;
     const bool lin_alibi = a.p.alibi_slopes && a.p.softcap <= 0.f && (a.p.is_causal || a.p.window_right == 0);
     if (drop) { if (a.has_bias) FA_LAUNCH(1, false, true); else FA_LAUNCH(0, false, true); }

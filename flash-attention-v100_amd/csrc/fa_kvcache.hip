@@ -103,8 +103,13 @@ int launch_decode(const KArgs& a_in, hipStream_t stream) {
     fa_params& p = a.p;
     const bool bf = p.dtype == FA_BF16;
     const bool kv8 = p.kv_dtype == FA_FP8_E4M3;
-    const bool fast = decode_applicable(p);
-    if (kv8 && !fast) return -2;                         // fp8 cache is served by the decode kernel only
+    if (kv8 && (p.alibi_slopes || p.softcap > 0.f || !(p.head_dim == 64 || p.head_dim == 128) || p.head_dim_v != 0)) return -2;
+    // up to 32 packed query rows per kv-head: the decode kernels (one K / V stream per kv-head); more - chunked prefill,
+    // long speculative blocks -: fa_fwd_kernel on the cache, which dequantises an fp8 tile once per 128 query rows
+    // (measured, tools/bench_fp8_prefill.py: 64 packed rows over an 8 k fp8 cache 0.080 ms on the decode kernel's two row
+    //  blocks vs 0.186 ms here; 128 rows 0.455 vs 0.213, 256 rows 0.229 vs 0.141, 2048 rows 1.49 vs 0.57)
+    const int packed_rows = p.seqlen_q * (p.nheads_q / p.nheads_k);
+    const bool fast = decode_applicable(p) && packed_rows <= (kv8 ? 64 : 32);
     if (p.k_new) {
         const int64_t total = (int64_t)p.batch * p.seqlen_new * p.nheads_k * (valid_cols(p) / 8);
         const int grid = (int)((total + 255) / 256);

@@ -182,8 +182,9 @@ def test_decode_fp8_kv_cache(Hk):
     (40, 6, 2, 128, False, False, (50, 10), False),     # G = 3: rows of one query position straddle row blocks
 ])
 def test_fp8_cache_multi_token_queries(Tq, Hq, Hk, D, paged, causal, window, rot):
-    """Chunked prefill / speculative decode over an fp8-e4m3 cache: T_q * H_q/H_k > 32 packed rows run as 32-row blocks
-    of the dequantising decode kernel (reference semantics: fused_mha_forward_kvcache.cu:344 takes any T_Q).
+    """Chunked prefill / speculative decode over an fp8-e4m3 cache (reference semantics: fused_mha_forward_kvcache.cu:344
+    takes any T_Q): up to 64 packed rows T_q * H_q/H_k run as 32-row blocks of the dequantising decode kernel, more on
+    fa_fwd_kernel<..., KV8> (an fp8 tile is dequantised once per 128 query rows) - the cases cover both.
     Tolerance: the fp8 cases' (out 1.5 x the io tolerance, LSE 3e-2) - the oracle reads the same fp8 codes."""
     B, page, dt = 3, 128, "bf16"
     kd, vd = 0.05, 0.04
