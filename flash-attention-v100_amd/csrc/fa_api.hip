@@ -228,7 +228,7 @@ int fa_fwd_kvcache(const fa_params* pp, void* stream) {
     a.leftpad_k = p.cache_leftpad;
     a.kv_mode = 1;
     rc = fa::launch_decode(a, s);
-    if (rc == -2) return fail(FA_ERR_UNSUPPORTED, "no kvcache kernel for this configuration (fp8 caches: head_dim 64 / 128, no ALiBi / softcap)");
+    if (rc == -2) return fail(FA_ERR_UNSUPPORTED, "no kvcache kernel for this configuration (fp8 caches: head_dim 64 or 128)");
     if (rc == -1) return fail(FA_ERR_INVALID_ARGUMENT, "workspace too small: query fa_fwd_kvcache_workspace_bytes()");
     if (rc) return rc;
     return check_hip("fa_fwd_kvcache launch");

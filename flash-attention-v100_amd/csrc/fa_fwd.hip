@@ -485,7 +485,7 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : FA_FWD_OCC)) fa_fw
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int j = n0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
-                    float s = sacc[kb][r] * p.softmax_scale;
+                    float s = sacc[kb][r] * (p.softmax_scale * (KV8 ? p.k_descale : 1.0f));
                     const int dist = my_row + off - j;
                     s = fmaf(-slope, fabsf((float)dist), s);
                     if (cap > 0.f) s = cap * fast_tanh(s * rcap);
@@ -700,16 +700,17 @@ static int launch_fwd_td(const KArgs& a, bool paged, hipStream_t stream) {
         FA_SET_LDS_ONCE(kern, smem);               /* once per instantiation and device */    \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(FWD_THREADS), smem, stream, a);               \
     } while (0)
-    if (a.p.kv_dtype == FA_FP8_E4M3) {             // fp8 KV cache (general path: more than 32 packed query rows per kv-head)
+    if (a.p.kv_dtype == FA_FP8_E4M3) {             // fp8 KV cache (general path: long query blocks, ALiBi, softcap)
         if constexpr (D <= 128) {
-            if (a.has_bias || a.p.p_dropout > 0.f) return -2;
-#define FA_LAUNCH8(PAGED)                                                                       \
+            if (a.p.p_dropout > 0.f) return -2;
+#define FA_LAUNCH8(BIAS, PAGED)                                                                 \
             do {                                                                                \
-                auto kern = fa_fwd_kernel<T, D, 0, PAGED, false, true>;                         \
+                auto kern = fa_fwd_kernel<T, D, BIAS, PAGED, false, true>;                      \
                 FA_SET_LDS_ONCE(kern, smem);                                                    \
                 hipLaunchKernelGGL(kern, dim3(grid), dim3(FWD_THREADS), smem, stream, a);       \
             } while (0)
-            if (paged) FA_LAUNCH8(true); else FA_LAUNCH8(false);
+            if (a.has_bias) { if (paged) FA_LAUNCH8(1, true); else FA_LAUNCH8(1, false); }       // per-element ALiBi / softcap
+            else            { if (paged) FA_LAUNCH8(0, true); else FA_LAUNCH8(0, false); }
 #undef FA_LAUNCH8
             return 0;
         } else {

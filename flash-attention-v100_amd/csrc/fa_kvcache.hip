@@ -103,7 +103,7 @@ int launch_decode(const KArgs& a_in, hipStream_t stream) {
     fa_params& p = a.p;
     const bool bf = p.dtype == FA_BF16;
     const bool kv8 = p.kv_dtype == FA_FP8_E4M3;
-    if (kv8 && (p.alibi_slopes || p.softcap > 0.f || !(p.head_dim == 64 || p.head_dim == 128) || p.head_dim_v != 0)) return -2;
+    if (kv8 && (!(p.head_dim == 64 || p.head_dim == 128) || p.head_dim_v != 0)) return -2;
     // up to 32 packed query rows per kv-head: the decode kernels (one K / V stream per kv-head); more - chunked prefill,
     // long speculative blocks -: fa_fwd_kernel on the cache, which dequantises an fp8 tile once per 128 query rows
     // (measured, tools/bench_fp8_prefill.py: 64 packed rows over an 8 k fp8 cache 0.080 ms on the decode kernel's two row

@@ -282,7 +282,7 @@ def kvcache_case(rng, idx):
         slopes = torch.tensor([0.05 * (i + 1) for i in range(Hq)], dtype=torch.float32, device="cuda")
     splits = int(rng.choice([0, 0, 1, 2, 3, 5]))
     group = Hq // Hk
-    fp8 = slopes is None and D in (64, 128) and rng.random() < 0.3      # (any T_q x group: 32 packed rows per workgroup)
+    fp8 = D in (64, 128) and rng.random() < 0.3      # (any T_q x group, ALiBi included: decode kernels or fa_fwd_kernel<KV8>)
     kd, vd = (0.05, 0.04) if fp8 else (None, None)
     g = torch.Generator().manual_seed(7000 + idx)
     lp = torch.randint(0, 17, (B,), generator=g, dtype=torch.int32) if use_lp else None

@@ -222,6 +222,28 @@ def test_fp8_cache_multi_token_queries(Tq, Hq, Hk, D, paged, causal, window, rot
     assert_close(f64(out2), o_ref, dt, "out (3 splits, no append)", mult=1.5)
 
 
+@pytest.mark.parametrize("Tq,softcap,alibi", [(1, 0.0, True), (5, 30.0, False), (70, 0.0, True), (130, 50.0, False)])
+def test_fp8_cache_with_alibi_or_softcap(Tq, softcap, alibi):
+    """fp8 caches with ALiBi or softcap (round 2 returned FA_ERR_UNSUPPORTED): the general kernel's per-element bias path on
+    dequantised tiles, for single tokens and chunks alike; same tolerance as the other fp8 cases."""
+    B, Hq, Hk, D, dt, Smax = 2, 4, 2, 128, "bf16", 768
+    kd, vd = 0.05, 0.04
+    kc16 = rand16((B, Smax, Hk, D), dt, 2, scale=1.5); vc16 = rand16((B, Smax, Hk, D), dt, 3, scale=1.5)
+    kc = (kc16.float() / kd).to(torch.float8_e4m3fn); vc = (vc16.float() / vd).to(torch.float8_e4m3fn)
+    q = rand16((B, Tq, Hq, D), dt, 1)
+    seqlens = torch.tensor([Smax - 40, 333], dtype=torch.int32)
+    slopes = torch.tensor([0.05 * (i + 1) for i in range(Hq)], dtype=torch.float32, device="cuda") if alibi else None
+    causal = softcap == 0.0         # (the kvcache op rejects softcap with a window - causal is one -, as the reference's does)
+    out, lse = _fa().flash_attn_with_kvcache(q, kc, vc, cache_seqlens=seqlens.cuda(), causal=causal, softcap=softcap,
+                                             alibi_slopes=slopes, return_softmax_lse=True, k_descale=kd, v_descale=vd)
+    o_ref, lse_ref = oracle.kvcache_fwd(f64(q), kc.float().double().cpu().numpy(), vc.float().double().cpu().numpy(),
+                                        cache_seqlens=seqlens.numpy(), causal=causal, softcap=softcap,
+                                        alibi_slopes=None if slopes is None else f64(slopes), io_dtype=dt,
+                                        k_descale=kd, v_descale=vd)
+    assert_close(f64(out), o_ref, dt, "out", mult=1.5)
+    assert_lse_close(f64(lse), lse_ref, "lse", atol=3e-2)
+
+
 def test_full_size_config4_decode_paged_rotary_fp8():
     """BASELINE config 4 at full size (B128, 32 heads, D128, cache_seqlen 8192, paged KV with a random
     block table, NeoX rotary, fp8-e4m3 KV), checked through size-independent properties:
