@@ -216,3 +216,21 @@ def test_large_lds_kernels_on_every_visible_device():
             ref = got
         else:
             assert all(torch.equal(a, b) for a, b in zip(ref, got)), f"device {dev} differs from device 0"
+
+
+def test_backward_without_workspace_matches(monkeypatch):
+    """workspace = NULL is legal: the generated dQ kernel then has no statistics planes to leave behind
+    (empty descriptor) and the compiler-scheduled dK/dV kernel runs - same gradients as with the workspace."""
+    import flash_attn
+    from flash_attn_mi355 import flash_attn_interface as fi
+    q = rand16((2, 1024, 4, 128), "bf16", 1).requires_grad_(True)
+    k = rand16((2, 1024, 2, 128), "bf16", 2).requires_grad_(True)
+    v = rand16((2, 1024, 2, 128), "bf16", 3).requires_grad_(True)
+    do = rand16((2, 1024, 4, 128), "bf16", 4)
+    o = flash_attn.flash_attn_func(q, k, v, causal=True)
+    ref = torch.autograd.grad(o, (q, k, v), do, retain_graph=True)
+    monkeypatch.setattr(fi, "_workspace", lambda nbytes, device: None)
+    got = torch.autograd.grad(o, (q, k, v), do)
+    assert torch.equal(got[0], ref[0])                                   # same dQ kernel, same bits
+    assert_close(f64(got[1]), f64(ref[1]), "bf16", "dk (no workspace)", mult=0.25)
+    assert_close(f64(got[2]), f64(ref[2]), "bf16", "dv (no workspace)", mult=0.25)
