@@ -86,6 +86,8 @@ S_VJ = 78                # s78..s80
 S_LAST = 80
 S_RC, S_FASTLO, S_FASTEND = 81, 82, 83     # in: 1 / c; fast-loop iteration range [lo, end)
 S_QRB = 84               # in (D = 128): bytes per Q row
+S_HIMAX = (85, 86)       # in: max over the q-block's rows of the last visible key (a 32-key sub-block that starts past it is masked
+                         # for every row: the mask routine fills it instead of testing each element)
 
 # ----------------------------------------------------------------------------- head dimension (128 or 64)
 HD = 128
@@ -635,13 +637,31 @@ class Gen:
         o.append(f"v_subrev_u32 {tlo}, s{S_N0}, v{V_LOG[qb]}")          # lo_t = (lo - 4g) - n0
         o.append(f"v_mov_b32 {tinf}, 0xff800000")
         o.append("s_nop 0")
+        st = S_SUB                                                       # s62, s63: idle after the set-up (the caller's temps are s56..s59)
         for kb in range(2):
+            # wave-uniform state of the 32-key sub-block: every row sees all of it (nothing to do - on a causal diagonal
+            # that is one of the two sub-blocks of a tile), no row sees any of it (fill), or mixed (test every element)
+            u = self.uid()
+            o.append(f"s_add_u32 s{st}, s{S_N0}, {32 * kb}")
+            o.append(f"s_add_u32 s{st + 1}, s{st}, 31")
+            o.append(f"s_cmp_gt_i32 s{st}, s{S_HIMAX[qb]}")
+            o.append(f"s_cbranch_scc1 L_mfill{u}_%=")
+            o.append(f"s_cmp_gt_i32 s{st + 1}, s{S_HIMIN[qb]}")
+            o.append(f"s_cbranch_scc1 L_mpart{u}_%=")
+            o.append(f"s_cmp_lt_i32 s{st}, s{S_LOMAX[qb]}")
+            o.append(f"s_cbranch_scc0 L_mnext{u}_%=")
+            o.append(f"L_mpart{u}_%=:")
             for r in range(16):
                 c = 32 * kb + (r & 3) + 8 * (r >> 2)
                 t = f"v{T + 2 + (r & 3)}"
                 o.append(f"v_sub_u32 {t}, {c}, {tlo}")
                 o.append(f"v_cmp_gt_u32 vcc, {t}, v{V_WIDTH[qb]}")
                 o.append(f"v_cndmask_b32 v{S + 16 * kb + r}, v{S + 16 * kb + r}, {tinf}, vcc")
+            o.append(f"s_branch L_mnext{u}_%=")
+            o.append(f"L_mfill{u}_%=:")
+            for r in range(16):
+                o.append(f"v_mov_b32 v{S + 16 * kb + r}, {tinf}")
+            o.append(f"L_mnext{u}_%=:")
         o.append(f"s_setpc_b64 {sr(S_RET, 2)}")
         return o
 
