@@ -407,8 +407,12 @@ class DQ(Gen):
                 A(f"v_or_b32 {b0}, {h}, {m}")
                 A(f"v_lshrrev_b32 {b1}, 16, {r}")
             else:
-                A(f"v_cvt_f16_f32 {h}, {nd}")
+                # fp16: the first term travels scaled by 2^-12 (its ones-slot holds 4096): -D may exceed the fp16 range -
+                # loss-scaled gradients do - as long as |D| < 65504 * 4096 (where dS itself no longer fits the format)
+                A(f"v_mul_f32 {lo_}, 0x39800000, {nd}")                      # * 2^-12
+                A(f"v_cvt_f16_f32 {h}, {lo_}")
                 A(f"v_cvt_f32_f16 {lo_}, {h}")
+                A(f"v_mul_f32 {lo_}, 0x45800000, {lo_}")                     # * 4096: exact
                 A(f"v_sub_f32 {r}, {nd}, {lo_}")
                 A(f"v_cvt_f16_f32 {m}, {r}")
                 A(f"v_cvt_f32_f16 {lo_}, {m}")
@@ -425,7 +429,8 @@ class DQ(Gen):
             A(f"v_mov_b32 v{V_ND[qb] + 3}, 0")
             if qb == 0:
                 one = 0x3f80 if self.dtype == "bf16" else 0x3c00
-                A(f"v_mov_b32 {m}, 0x{one | (one << 16):08x}")
+                first = one if self.dtype == "bf16" else 0x6c00                 # fp16: 4096.0 (see the split above)
+                A(f"v_mov_b32 {m}, 0x{first | (one << 16):08x}")
                 A(f"v_mov_b32 {lo_}, 0x{one:08x}")
                 A(f"v_cndmask_b32 v{V_ONE}, 0, {m}, vcc")
                 A(f"v_cndmask_b32 v{V_ONE + 1}, 0, {lo_}, vcc")

@@ -234,3 +234,21 @@ def test_backward_without_workspace_matches(monkeypatch):
     assert torch.equal(got[0], ref[0])                                   # same dQ kernel, same bits
     assert_close(f64(got[1]), f64(ref[1]), "bf16", "dk (no workspace)", mult=0.25)
     assert_close(f64(got[2]), f64(ref[2]), "bf16", "dv (no workspace)", mult=0.25)
+
+
+@pytest.mark.parametrize("dt,scale", [("fp16", 2048.0), ("fp16", 1.0 / 64.0), ("bf16", 1048576.0)])
+def test_backward_with_loss_scaled_gradients(dt, scale):
+    """dO far from O(1) (mixed-precision loss scaling, or small gradients; powers of two, and small enough that dS stays a
+    normal fp16 number): D = rowsum(dO o O) leaves the fp16 range at scale 2048 (|D| up to ~1e5) - the generated dQ kernel carries it as three 16-bit terms through the matrix pipe, the first one
+    scaled by 2^-12 for fp16 - and the gradients must simply scale with dO."""
+    import flash_attn
+    q = rand16((1, 1024, 2, 128), dt, 1).requires_grad_(True)
+    k = rand16((1, 1024, 2, 128), dt, 2).requires_grad_(True)
+    v = rand16((1, 1024, 2, 128), dt, 3, scale=2.0).requires_grad_(True)
+    do1 = rand16((1, 1024, 2, 128), dt, 4)
+    o = flash_attn.flash_attn_func(q, k, v, causal=True)
+    ref = torch.autograd.grad(o, (q, k, v), do1, retain_graph=True)
+    got = torch.autograd.grad(o, (q, k, v), (do1.float() * scale).to(do1.dtype))          # (a power of two: exact)
+    for name, g, r in zip(("dq", "dk", "dv"), got, ref):
+        assert torch.isfinite(g.float()).all(), name
+        assert_close(f64(g) / scale, f64(r), dt, f"{name} at dO x {scale}", mult=1.0)
