@@ -410,6 +410,8 @@ class DQ(Gen):
                 # fp16: the first term travels scaled by 2^-12 (its ones-slot holds 4096): -D may exceed the fp16 range -
                 # loss-scaled gradients do - as long as |D| < 65504 * 4096 (where dS itself no longer fits the format)
                 A(f"v_mul_f32 {lo_}, 0x39800000, {nd}")                      # * 2^-12
+                A(f"v_cmp_lt_f32 vcc, |{nd}|, 0.5")                          # small D: the unscaled terms carry all of it (a scaled
+                A(f"v_cndmask_b32 {lo_}, {lo_}, 0, vcc")                     # first term would be an fp16 subnormal)
                 A(f"v_cvt_f16_f32 {h}, {lo_}")
                 A(f"v_cvt_f32_f16 {lo_}, {h}")
                 A(f"v_mul_f32 {lo_}, 0x45800000, {lo_}")                     # * 4096: exact
