@@ -252,3 +252,24 @@ def test_backward_with_loss_scaled_gradients(dt, scale):
     for name, g, r in zip(("dq", "dk", "dv"), got, ref):
         assert torch.isfinite(g.float()).all(), name
         assert_close(f64(g) / scale, f64(r), dt, f"{name} at dO x {scale}", mult=1.0)
+
+
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+def test_peaky_softmax_forward_and_backward(dt):
+    """q, k three times the usual scale: logits of +-40, one or two keys carry a row - late rescales of the running maximum
+    in the forward, P = exp2(S c - lse2) recomputed near 1 and near 0 in the backward kernels; against the oracle."""
+    import flash_attn
+    B, S, H, D = 1, 1024, 2, 128
+    q = rand16((B, S, H, D), dt, 1, scale=3.0).requires_grad_(True)
+    k = rand16((B, S, H, D), dt, 2, scale=3.0).requires_grad_(True)
+    v = rand16((B, S, H, D), dt, 3).requires_grad_(True)
+    do = rand16((B, S, H, D), dt, 4)
+    o, lse, _ = flash_attn.flash_attn_func(q, k, v, causal=True, return_attn_probs=True)
+    g = torch.autograd.grad(o, (q, k, v), do)
+    t = lambda x: f64(x).transpose(0, 2, 1, 3)
+    o_ref, lse_ref, _ = oracle.attn_fwd(t(q), t(k), t(v), D ** -0.5, causal=True)
+    g_ref = oracle.attn_bwd(t(do), t(q), t(k), t(v), oracle.round_to(o_ref, dt), lse_ref.astype(np.float64), D ** -0.5, causal=True)
+    assert_close(t(o), o_ref, dt, "out", mult=1.5)
+    assert np.abs(f64(lse) - lse_ref).max() <= 1e-4
+    for name, a, b in zip(("dq", "dk", "dv"), g, g_ref):
+        assert_close(t(a), b, dt, name, mult=2.0)
