@@ -28,7 +28,7 @@ fl = 4.0 * D * H * sum(pairs(int(L), -1) for L in lens)
 run("varlen causal (no window) D64", lambda q, k, v: flash_attn.flash_attn_varlen_func(q, k, v, cu, cu, 2048, 2048, causal=True), fl)
 Bd, S = 32, 2048
 q, k, v = mk(Bd, S, H, D), mk(Bd, S, H, D), mk(Bd, S, H, D); INS = (q, k, v)
-run("dense causal B32 S2048 D64", lambda: flash_attn.flash_attn_func(q, k, v, causal=True), 4.0 * D * H * Bd * S * S / 2)
-run("dense window(512,0) B32 S2048 D64", lambda: flash_attn.flash_attn_func(q, k, v, causal=True, window_size=(W, 0)), 4.0 * D * H * Bd * pairs(S, W))
+run("dense causal B32 S2048 D64", lambda q, k, v: flash_attn.flash_attn_func(q, k, v, causal=True), 4.0 * D * H * Bd * S * S / 2)
+run("dense window(512,0) B32 S2048 D64", lambda q, k, v: flash_attn.flash_attn_func(q, k, v, causal=True, window_size=(W, 0)), 4.0 * D * H * Bd * pairs(S, W))
 q, k, v = mk(Bd, S, 16, 128), mk(Bd, S, 16, 128), mk(Bd, S, 16, 128); INS = (q, k, v)
-run("dense causal B32 S2048 H16 D128", lambda: flash_attn.flash_attn_func(q, k, v, causal=True), 4.0 * 128 * 16 * Bd * S * S / 2)
+run("dense causal B32 S2048 H16 D128", lambda q, k, v: flash_attn.flash_attn_func(q, k, v, causal=True), 4.0 * 128 * 16 * Bd * S * S / 2)
