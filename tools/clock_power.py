@@ -128,7 +128,8 @@ def main():
         loop("fwd  causal 4k, ZERO inputs (same instruction stream, no data toggling)", lambda: flash_attn.flash_attn_func(z, z, z, causal=True), seconds, smi, ff)
     q.requires_grad_(True); k.requires_grad_(True); v.requires_grad_(True)
     o = flash_attn.flash_attn_func(q, k, v, causal=True)
-    loop("bwd dQ kernel (dq only)", lambda: torch.autograd.grad(o, (q,), do, retain_graph=True), seconds, smi, 0.5 * ff)
+    oq = flash_attn.flash_attn_func(q, k.detach(), v.detach(), causal=True)      # frozen K / V: the backward is the dQ kernel alone
+    loop("bwd dQ kernel (dq only)", lambda: torch.autograd.grad(oq, (q,), do, retain_graph=True), seconds, smi, 0.5 * ff)
     loop("bwd dQ + dK/dV kernels", lambda: torch.autograd.grad(o, (q, k, v), do, retain_graph=True), seconds, smi, 2.5 * ff)
 
     def step():
