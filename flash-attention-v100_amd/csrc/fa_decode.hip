@@ -435,6 +435,102 @@ __global__ void __launch_bounds__(256) decode_combine_kernel(const DecArgs da) {
     if (cc == 0) p.lse[b * p.lse_batch_stride + (int64_t)hq * p.lse_head_stride + t] = den > 0.f ? m + __logf(den) : -INFINITY;
 }
 
+// The same merge for MANY partials (small batches split the key range until the grid fills the chip: up to 256 partial
+// rows per output row).  The kernel above walks the partials one after the other in every thread - 126 dependent trips
+// to L2 = 80 us for a 15 us decode (rocprofv3, B 1, H 32/8, 4k context).  Here one workgroup owns an output row: the
+// weights are computed once (one partial per thread, two block reductions), then D / 4 column groups x 256 / (D / 4)
+// partial lanes stream the partial rows with independent 16-byte loads and meet in LDS.
+template <typename T>
+__global__ void __launch_bounds__(256) decode_combine_wide_kernel(const DecArgs da) {
+    using E = Elem<T>;
+    const fa_params& p = da.a.p;
+    const int D = p.head_dim;
+    const int ncg = D / 4;                                  // float4 column groups: 32 (D 128) or 16 (D 64)
+    const int npl = 256 / ncg;                              // partial lanes: 8 or 16
+    const int64_t rows = (int64_t)p.batch * p.nheads_q * p.seqlen_q;
+    const int64_t row = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = da.n_splits;
+    __shared__ float s_w[256];
+    __shared__ float s_red[8];
+    __shared__ f32x4 s_acc[256];
+    // ---- weights: w_s = exp(lse_s - max) / sum ----
+    float m = -INFINITY;
+    for (int s = tid; s < n; s += 256) m = fmaxf(m, da.lse_partial[(int64_t)s * rows + row]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if (lane == 0) s_red[wave] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+    const float m_s = (m == -INFINITY) ? 0.f : m;
+    float den = 0.f;
+    for (int s = tid; s < n; s += 256) den += __expf(da.lse_partial[(int64_t)s * rows + row] - m_s);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) den += __shfl_xor(den, o);
+    if (lane == 0) s_red[4 + wave] = den;
+    __syncthreads();
+    den = (s_red[4] + s_red[5]) + (s_red[6] + s_red[7]);
+    const float rden = den > 0.f ? 1.0f / den : 0.f;
+    const int cg = tid % ncg, pl = tid / ncg;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int s0 = 0; s0 < n; s0 += 256) {                   // (n <= 256 in practice: one trip)
+        __syncthreads();
+        if (s0 + tid < n) s_w[tid] = __expf(da.lse_partial[(int64_t)(s0 + tid) * rows + row] - m_s) * rden;
+        __syncthreads();
+        const int cnt = n - s0 < 256 ? n - s0 : 256;
+        const float* base = da.o_partial + ((int64_t)s0 * rows + row) * D + cg * 4;
+        const int64_t stride = rows * D;
+        int s = pl;
+        for (; s + 3 * npl < cnt; s += 4 * npl) {           // four independent loads in flight per thread
+            const f32x4 x0 = *reinterpret_cast<const f32x4*>(base + (int64_t)s * stride);
+            const f32x4 x1 = *reinterpret_cast<const f32x4*>(base + (int64_t)(s + npl) * stride);
+            const f32x4 x2 = *reinterpret_cast<const f32x4*>(base + (int64_t)(s + 2 * npl) * stride);
+            const f32x4 x3 = *reinterpret_cast<const f32x4*>(base + (int64_t)(s + 3 * npl) * stride);
+            const float w0 = s_w[s], w1 = s_w[s + npl], w2 = s_w[s + 2 * npl], w3 = s_w[s + 3 * npl];
+#pragma unroll
+            for (int x = 0; x < 4; ++x) acc[x] = fmaf(x0[x], w0, fmaf(x1[x], w1, fmaf(x2[x], w2, fmaf(x3[x], w3, acc[x]))));
+        }
+        for (; s < cnt; s += npl) {
+            const f32x4 x0 = *reinterpret_cast<const f32x4*>(base + (int64_t)s * stride);
+            const float w0 = s_w[s];
+#pragma unroll
+            for (int x = 0; x < 4; ++x) acc[x] = fmaf(x0[x], w0, acc[x]);
+        }
+    }
+    s_acc[tid] = acc;
+    __syncthreads();
+    if (tid < ncg) {
+        for (int q = 1; q < npl; ++q) {
+            const f32x4 y = s_acc[q * ncg + tid];
+#pragma unroll
+            for (int x = 0; x < 4; ++x) acc[x] += y[x];
+        }
+        const int t = row % p.seqlen_q;
+        const int64_t bh = row / p.seqlen_q;
+        const int hq = bh % p.nheads_q;
+        const int64_t b = bh / p.nheads_q;
+        uint16_t* out = reinterpret_cast<uint16_t*>(p.o) + b * p.o_batch_stride + (int64_t)t * p.o_row_stride +
+                        (int64_t)hq * p.o_head_stride + tid * 4;
+        u32x2 o2 = {E::pack2(acc[0], acc[1]), E::pack2(acc[2], acc[3])};
+        *reinterpret_cast<u32x2*>(out) = o2;
+        if (tid == 0) p.lse[b * p.lse_batch_stride + (int64_t)hq * p.lse_head_stride + t] = den > 0.f ? m + __logf(den) : -INFINITY;
+    }
+}
+
+// more than this many partial rows per output row: one workgroup per row (decode_combine_wide_kernel)
+constexpr int DEC_COMBINE_WIDE_MIN = 8;
+template <typename T>
+static void launch_decode_combine(const DecArgs& da, hipStream_t stream) {
+    const fa_params& p = da.a.p;
+    const int64_t rows = (int64_t)p.batch * p.nheads_q * p.seqlen_q;
+    if (da.n_splits > DEC_COMBINE_WIDE_MIN) {
+        hipLaunchKernelGGL(decode_combine_wide_kernel<T>, dim3((unsigned)rows), dim3(256), 0, stream, da);
+    } else {
+        const int64_t total = rows * (p.head_dim / 8);
+        hipLaunchKernelGGL(decode_combine_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, da);
+    }
+}
+
 
 // ---------------------------------------------------------------------------------------------
 // fp8 KV, ONE query row per kv-head (T_q = 1, H_q == H_k: BASELINE config 4): streaming matrix-vector kernel.
@@ -965,8 +1061,11 @@ static int device_cu_count() {
     return n;
 }
 
+// grid splits of the key range (x up to 4 key sub-ranges per workgroup in the token-major kernel: <= 1024 partial rows per
+// output row, merged by decode_combine_wide_kernel)
+constexpr int DEC_MAX_SPLITS = 256;
 int decode_num_splits(const fa_params& p) {
-    if (p.num_splits >= 1) return p.num_splits > 64 ? 64 : p.num_splits;
+    if (p.num_splits >= 1) return p.num_splits > DEC_MAX_SPLITS ? DEC_MAX_SPLITS : p.num_splits;
     const int units = p.batch * p.nheads_k * ((p.seqlen_q * (p.nheads_q / p.nheads_k) + 31) / 32);   // x row blocks
     const int max_tiles = (p.seqlen_k + DEC_BN - 1) / DEC_BN;
     int s = 1;
@@ -978,8 +1077,11 @@ int decode_num_splits(const fa_params& p) {
         // token-major streaming kernel: grid = batch x splits.  Measured at config 4
         // (tools/decode_splits_probe.py): one workgroup per CU in ONE round is best, every doubling
         // beyond costs ~2 %, a partial last round costs its idle share - pick the split count with the best of both.
-        const double resident = 1.0 * device_cu_count();   // (one workgroup per CU streams best: 2 splits 7.0 TB/s, 4 splits 6.8, 12 splits 6.4)
-        const int cap = p.seqlen_k / 64 > 0 ? (p.seqlen_k / 64 < 64 ? p.seqlen_k / 64 : 64) : 1;
+        // (one workgroup per CU streams best at 32 kv-heads: 2 splits 7.0 TB/s, 4 splits 6.8, 12 splits 6.4; with few kv-heads -
+        // the waves of a workgroup share head groups and take key sub-ranges - two per CU are 11-16 % faster than one
+        // and than four: tools/decode_splits_sweep.py, H 32/8 fp16 and fp8, B 16-256)
+        const double resident = (gemv_tm_ksub(p) > 1 ? 2.0 : 1.0) * device_cu_count();
+        const int cap = p.seqlen_k / 64 > 0 ? (p.seqlen_k / 64 < DEC_MAX_SPLITS ? p.seqlen_k / 64 : DEC_MAX_SPLITS) : 1;
         int best = 1;
         double best_score = -1.0;
         for (int k = 1; k <= cap; ++k) {
@@ -1035,20 +1137,14 @@ static int launch_decode_td(DecArgs& da, hipStream_t stream) {
             if (kv8) { if (da.group == 1) FA_LAUNCH_TM(true, 1); else if (da.group == 2) FA_LAUNCH_TM(true, 2); else FA_LAUNCH_TM(true, 4); }
             else { if (da.group == 1) FA_LAUNCH_TM(false, 1); else if (da.group == 2) FA_LAUNCH_TM(false, 2); else FA_LAUNCH_TM(false, 4); }
 #undef FA_LAUNCH_TM
-            if (da.n_splits > 1) {
-                const int64_t total = (int64_t)p.batch * p.nheads_q * p.seqlen_q * (D / 8);
-                hipLaunchKernelGGL(decode_combine_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, da);
-            }
+            if (da.n_splits > 1) launch_decode_combine<T>(da, stream);
             return 0;
         }
         // fp8 cache, one query row per kv-head, a head layout the token-major kernel does not take: one workgroup per head
         if (kv8 && da.rows == 1 && da.group == 1) {
             if (paged) hipLaunchKernelGGL((fa_decode_gemv_fp8_kernel<T, true>), grid, dim3(GEMV_THREADS), 0, stream, da);
             else       hipLaunchKernelGGL((fa_decode_gemv_fp8_kernel<T, false>), grid, dim3(GEMV_THREADS), 0, stream, da);
-            if (da.n_splits > 1) {
-                const int64_t total = (int64_t)p.batch * p.nheads_q * p.seqlen_q * (D / 8);
-                hipLaunchKernelGGL(decode_combine_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, da);
-            }
+            if (da.n_splits > 1) launch_decode_combine<T>(da, stream);
             return 0;
         }
     }
@@ -1061,10 +1157,7 @@ static int launch_decode_td(DecArgs& da, hipStream_t stream) {
     if (kv8) { if (paged) FA_LAUNCH_DEC(true, true); else FA_LAUNCH_DEC(true, false); }
     else     { if (paged) FA_LAUNCH_DEC(false, true); else FA_LAUNCH_DEC(false, false); }
 #undef FA_LAUNCH_DEC
-    if (da.n_splits > 1) {
-        const int64_t total = (int64_t)p.batch * p.nheads_q * p.seqlen_q * (D / 8);
-        hipLaunchKernelGGL(decode_combine_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, da);
-    }
+    if (da.n_splits > 1) launch_decode_combine<T>(da, stream);
     return 0;
 }
 

@@ -116,6 +116,12 @@ def test_kvcache_argument_errors():
     (3, 4, 16, 2, 64, 1000, 64, "bf16", 4),       # 32 packed rows, explicit 4 splits
     (2, 2, 4, 4, 128, 517, 0, "fp16", 3),         # non-paged, odd split count, Tq = 2 causal
     (130, 1, 4, 4, 128, 300, 0, "fp16", 1),       # many units, no split
+    # many partial rows per output row: the one-workgroup-per-row merge (decode_combine_wide_kernel)
+    (1, 1, 32, 8, 128, 5000, 256, "fp16", 0),     # batch 1: the heuristic splits until the chip is full (token-major kernel, 2 sub-ranges)
+    (1, 1, 64, 8, 128, 9000, 256, "bf16", 0),     # G = 8: MFMA decode kernel, 32 splits
+    (2, 1, 8, 8, 128, 2100, 0, "bf16", 200),      # 200 grid splits of ~10 keys, most of a short sequence's splits empty
+    (2, 3, 8, 2, 64, 1500, 64, "fp16", 37),       # D = 64 (16 column groups x 16 partial lanes), odd count, T_q = 3
+    (1, 1, 4, 4, 128, 700, 0, "fp16", 256),       # more splits than 64-key tiles
 ])
 def test_decode_splitkv_gqa_packing(case):
     B, Tq, Hq, Hk, D, L, page, dt, nsplit = case
