@@ -1069,7 +1069,9 @@ int decode_num_splits(const fa_params& p) {
     const int units = p.batch * p.nheads_k * ((p.seqlen_q * (p.nheads_q / p.nheads_k) + 31) / 32);   // x row blocks
     const int max_tiles = (p.seqlen_k + DEC_BN - 1) / DEC_BN;
     int s = 1;
-    while (units * s < 512 && s < 32 && max_tiles / (s * 2) >= 8) s *= 2;       // >= 8 tiles (256 keys) per split
+    // one workgroup per CU: every further doubling costs 6-15 % in this kernel (each split re-reads the query rows and
+    // writes a partial row; tools/decode_splits_sweep.py, H 64/8 and 32/2, B 2-64)
+    while (units * s < device_cu_count() && s < 64 && max_tiles / (s * 2) >= 8) s *= 2;       // >= 8 tiles (256 keys) per split
     // The streaming fp8 kernel keeps three workgroups per CU resident: with 4096 units on 256 CUs the grid runs 5.33
     // "rounds" and the last one is a third full (11 % of the time at a third of the rate).  Split the key range so that
     // the grid is a near-multiple of what is resident; the partials cost 4 MB and one tiny combine launch.
@@ -1081,7 +1083,7 @@ int decode_num_splits(const fa_params& p) {
         // the waves of a workgroup share head groups and take key sub-ranges - two per CU are 11-16 % faster than one
         // and than four: tools/decode_splits_sweep.py, H 32/8 fp16 and fp8, B 16-256)
         const double resident = (gemv_tm_ksub(p) > 1 ? 2.0 : 1.0) * device_cu_count();
-        const int cap = p.seqlen_k / 64 > 0 ? (p.seqlen_k / 64 < DEC_MAX_SPLITS ? p.seqlen_k / 64 : DEC_MAX_SPLITS) : 1;
+        const int cap = p.seqlen_k / 32 > 0 ? (p.seqlen_k / 32 < DEC_MAX_SPLITS ? p.seqlen_k / 32 : DEC_MAX_SPLITS) : 1;     // >= 32 keys per split
         int best = 1;
         double best_score = -1.0;
         for (int k = 1; k <= cap; ++k) {
