@@ -32,7 +32,9 @@ template <int D> struct DecSmem {
 struct DecArgs {
     KArgs a;
     int n_splits;
-    int rows;                  // T_q * G; a workgroup takes 32 of them (blockIdx.z = row block: fp8 caches with more than 32)
+    int rows;                  // T_q * G; a workgroup takes 32 of them (row block)
+    int n_rb;                  // row blocks
+    int grid_splits;           // fa_decode_kernel: key splits of the grid (= n_splits there)
     int group;                 // G
     int local;                 // RoPE position advances with the query row (causal / window)
     int page_shift;            // log2(page_block_size) or -1
@@ -54,8 +56,20 @@ __global__ void __launch_bounds__(DEC_THREADS, 1) fa_decode_kernel(const DecArgs
 
     const KArgs& a = da.a;
     const fa_params& p = a.p;
-    const int unit = blockIdx.x;                            // (b, hk)
-    const int split = blockIdx.y;
+    // grid (units, splits, 1) with one row block; with several - every row block streams the kv-head's cache again - a
+    // 1-D grid places the row blocks of a (unit, split) on ONE XCD, back to back: workgroup ids go round-robin over the 8
+    // XCDs, each with its own L2, so id = ((pair / 8) * n_rb + rb) * 8 + pair % 8 keeps them 8 ids apart.  The second
+    // and later row blocks then read the stream from L2 instead of HBM (tools/spec_decode_sweep.py).
+    int unit = blockIdx.x, split = blockIdx.y, rb = 0;      // unit = (b, hk)
+    if (da.n_rb > 1) {
+        const int slot = blockIdx.x & 7, rest = blockIdx.x >> 3;
+        rb = rest % da.n_rb;
+        const int pair = (rest / da.n_rb) * 8 + slot;
+        const int n_units = p.batch * p.nheads_k;
+        if (pair >= n_units * da.grid_splits) return;
+        unit = pair % n_units;
+        split = pair / n_units;
+    }
     const int b = unit / p.nheads_k, hk = unit - b * p.nheads_k;
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, g = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -72,7 +86,7 @@ __global__ void __launch_bounds__(DEC_THREADS, 1) fa_decode_kernel(const DecArgs
 
     // ---- my packed query row: r = t * G + gq; blockIdx.z picks the 32-row block (multi-token queries over an fp8 cache:
     //      every row block streams the kv-head's cache again, dequantised into the same LDS tiles) ----
-    const int rbase = 32 * (int)blockIdx.z;
+    const int rbase = 32 * rb;
     const int r = rbase + l31;
     const int t_row = r / G, gq = r - t_row * G;
     const int h = hk * G + gq;
@@ -1045,11 +1059,31 @@ __global__ void __launch_bounds__(GEMV_THREADS) fa_decode_gemv_tm_kernel(const D
 // ---- host ---------------------------------------------------------------------------------------
 bool decode_applicable(const fa_params& p) {
     if (p.alibi_slopes || p.softcap > 0.f) return false;
-    const int G = p.nheads_q / p.nheads_k;
     if (!((p.head_dim == 64 || p.head_dim == 128) && p.head_dim_v == 0)) return false;
-    // 16-bit caches: up to 32 packed rows (longer query blocks run fa_fwd_kernel on the cache); fp8 caches: any number of
-    // rows, 32 per workgroup - this kernel is the one that dequantises (chunked prefill / speculative decode over fp8 KV)
-    return p.kv_dtype == FA_FP8_E4M3 || p.seqlen_q * G <= 32;
+    return true;                  // any number of packed rows, 32 per workgroup (blockIdx.z); decode_takes() decides who runs
+}
+
+static int device_cu_count();
+// Which kernel serves a multi-token query block (speculative / tree decode, chunked prefill) over the cache?  Both stream
+// the K / V of a kv-head once per "pass": the decode kernel per 32 PACKED rows (t x G + g: the heads of a group share the
+// stream, split-KV fills the chip at small batch; row blocks after the first read from L2), fa_fwd_kernel per 128 query
+// positions of ONE head (no packing: G passes per kv-head, no split).  At large batch a pass costs about the same in
+// both (tools/spec_decode_sweep.py: ~150 us per row block vs 156 us per head pass at B 64, H 64/8, 4 k fp8), so the
+// decode kernel runs while it needs no more passes - i.e. up to 32 query positions whatever the group size (16-bit
+// caches stopped at 32 packed ROWS before: T_q 9 at G = 4 fell onto the general path at 6 x the time).  When the general
+// path cannot fill the chip (batch x heads x 128-row blocks < 2 x CUs) the decode kernel's split-KV is worth up to
+// 8 x the passes (B 1, H 32/8, T_q 128 over 8 k: 72 us against 240).  fp8 caches with two row blocks stay here too.
+bool decode_takes(const fa_params& p) {
+    if (!decode_applicable(p)) return false;
+    const int G = p.nheads_q / p.nheads_k;
+    const int row_blocks = (p.seqlen_q * G + 31) / 32;
+    const int fwd_blocks = (p.seqlen_q + 127) / 128;
+    const int fwd_passes = G * fwd_blocks;
+    const int64_t fwd_wgs = (int64_t)p.batch * p.nheads_q * fwd_blocks;
+    int64_t factor = 2 * device_cu_count() / (fwd_wgs > 0 ? fwd_wgs : 1);
+    factor = factor < 1 ? 1 : (factor > 8 ? 8 : factor);
+    if (row_blocks <= factor * fwd_passes) return true;
+    return p.kv_dtype == FA_FP8_E4M3 && row_blocks <= 2;
 }
 
 static int device_cu_count() {
@@ -1125,7 +1159,10 @@ static int launch_decode_td(DecArgs& da, hipStream_t stream) {
     const fa_params& p = da.a.p;
     const bool kv8 = p.kv_dtype == FA_FP8_E4M3;
     const bool paged = p.block_table != nullptr;
-    dim3 grid(p.batch * p.nheads_k, da.n_splits, (da.rows + 31) / 32);
+    da.n_rb = (da.rows + 31) / 32;
+    da.grid_splits = da.n_splits;
+    dim3 grid(p.batch * p.nheads_k, da.n_splits, 1);
+    if (da.n_rb > 1) grid = dim3((unsigned)(((p.batch * p.nheads_k * da.n_splits + 7) / 8) * 8 * da.n_rb), 1, 1);
     const size_t smem = DecSmem<D>::TOTAL;
     if constexpr (D == 128) {
         // one query position, heads adjacent in the cache rows: the token-major streaming kernel (fp8 and 16-bit caches, GQA)

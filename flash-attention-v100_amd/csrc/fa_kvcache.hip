@@ -16,6 +16,7 @@ namespace fa {
 
 int launch_fwd(const KArgs& a, hipStream_t stream);
 bool decode_applicable(const fa_params& p);
+bool decode_takes(const fa_params& p);
 size_t decode_split_workspace_bytes(const fa_params& p);
 int launch_decode_splitkv(const KArgs& a, void* ws, hipStream_t stream);
 
@@ -94,7 +95,7 @@ __global__ void __launch_bounds__(256) kv_append_kernel(const KArgs a) {
 }
 
 size_t decode_workspace_bytes(const fa_params& p) {
-    if (decode_applicable(p)) return decode_split_workspace_bytes(p);
+    if (decode_takes(p)) return decode_split_workspace_bytes(p);
     return 0;                       // the general path rotates Q inside fa_fwd_kernel (KArgs::rope_q): no scratch
 }
 
@@ -104,12 +105,10 @@ int launch_decode(const KArgs& a_in, hipStream_t stream) {
     const bool bf = p.dtype == FA_BF16;
     const bool kv8 = p.kv_dtype == FA_FP8_E4M3;
     if (kv8 && (!(p.head_dim == 64 || p.head_dim == 128) || p.head_dim_v != 0)) return -2;
-    // up to 32 packed query rows per kv-head: the decode kernels (one K / V stream per kv-head); more - chunked prefill,
-    // long speculative blocks -: fa_fwd_kernel on the cache, which dequantises an fp8 tile once per 128 query rows
-    // (measured, tools/bench_fp8_prefill.py: 64 packed rows over an 8 k fp8 cache 0.080 ms on the decode kernel's two row
-    //  blocks vs 0.186 ms here; 128 rows 0.455 vs 0.213, 256 rows 0.229 vs 0.141, 2048 rows 1.49 vs 0.57)
-    const int packed_rows = p.seqlen_q * (p.nheads_q / p.nheads_k);
-    const bool fast = decode_applicable(p) && packed_rows <= (kv8 ? 64 : 32);
+    // few query positions per sequence: the decode kernels (one K / V stream per kv-head and 32 packed rows, split-KV); more -
+    // chunked prefill, long speculative blocks -: fa_fwd_kernel on the cache, which dequantises an fp8 tile once per 128
+    // query rows.  decode_takes() (fa_decode.hip) holds the rule and the measurements behind it.
+    const bool fast = decode_takes(p);
     if (p.k_new) {
         const int64_t total = (int64_t)p.batch * p.seqlen_new * p.nheads_k * (valid_cols(p) / 8);
         const int grid = (int)((total + 255) / 256);

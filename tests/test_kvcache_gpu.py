@@ -228,6 +228,57 @@ def test_fp8_cache_multi_token_queries(Tq, Hq, Hk, D, paged, causal, window, rot
     assert_close(f64(out2), o_ref, dt, "out (3 splits, no append)", mult=1.5)
 
 
+@pytest.mark.parametrize("B,Tq,Hq,Hk,D,dt,paged,causal,window,rot,lp", [
+    (2, 9, 32, 8, 128, "fp16", True, True, (-1, -1), True, False),      # G = 4, 36 packed rows: two row blocks (the old cliff)
+    (3, 5, 64, 8, 128, "bf16", True, True, (-1, -1), True, True),       # G = 8, 40 rows, leftpad, NeoX rope on q per position
+    (1, 32, 16, 2, 64, "fp16", False, True, (-1, -1), False, False),    # G = 8, 256 rows = 8 row blocks, D = 64
+    (2, 17, 8, 2, 128, "bf16", True, False, (300, 5), False, False),    # window: the row blocks' key ranges differ
+    (1, 100, 16, 4, 128, "fp16", True, True, (-1, -1), True, False),    # batch 1: 13 row blocks > 4 head passes, taken for its split-KV
+    (9, 3, 24, 2, 128, "bf16", False, True, (-1, -1), False, False),    # G = 12: rows of one position straddle row blocks; 9 x 2 units (padded 1-D grid)
+])
+def test_multi_token_queries_on_decode_row_blocks(B, Tq, Hq, Hk, D, dt, paged, causal, window, rot, lp):
+    """Speculative / tree decode over a 16-bit cache: up to 32 query positions per sequence (any group size), and longer
+    blocks at small batch, run as 32-row blocks of the decode kernel (GQA-packed, split-KV, the row blocks of a kv-head
+    placed on one XCD) instead of fa_fwd_kernel on the cache - decode_takes() in csrc/fa_decode.hip.  Same semantics as
+    the reference's kvcache op for any T_Q (fused_mha_forward_kvcache.cu:344): append + RoPE at cache_seqlens, causal
+    alignment to the end of the cache.  Tolerance: the io dtype's."""
+    Smax, page = 1024, 128
+    g = torch.Generator().manual_seed(17)
+    seqlens = torch.randint(200, Smax - Tq - 24, (B,), generator=g, dtype=torch.int32)
+    seqlens[0] = Smax - Tq - 24
+    leftpad = torch.randint(0, 9, (B,), generator=g, dtype=torch.int32) if lp else None
+    q = rand16((B, Tq, Hq, D), dt, 1)
+    knew = rand16((B, Tq, Hk, D), dt, 4); vnew = rand16((B, Tq, Hk, D), dt, 5)
+    bt = None
+    if paged:
+        pps = Smax // page
+        nblk = B * pps
+        kc = rand16((nblk, page, Hk, D), dt, 2); vc = rand16((nblk, page, Hk, D), dt, 3)
+        bt = torch.randperm(nblk, generator=g).reshape(B, pps).to(torch.int32)
+    else:
+        kc = rand16((B, Smax, Hk, D), dt, 2); vc = rand16((B, Smax, Hk, D), dt, 3)
+    cos, sin = _rotary(Smax + 8, D // 2, dt) if rot else (None, None)
+    kc_ref, vc_ref = f64(kc).copy(), f64(vc).copy()
+    out, lse = _fa().flash_attn_with_kvcache(q, kc, vc, k=knew, v=vnew, rotary_cos=cos, rotary_sin=sin,
+                                             cache_seqlens=seqlens.cuda(), block_table=None if bt is None else bt.cuda(),
+                                             cache_leftpad=None if leftpad is None else leftpad.cuda(),
+                                             causal=causal, window_size=window, rotary_interleaved=False, return_softmax_lse=True)
+    o_ref, lse_ref = oracle.kvcache_fwd(f64(q), kc_ref, vc_ref, k=f64(knew), v=f64(vnew),
+                                        rotary_cos=None if cos is None else f64(cos), rotary_sin=None if sin is None else f64(sin),
+                                        cache_seqlens=seqlens.numpy(), block_table=None if bt is None else bt.numpy(),
+                                        cache_leftpad=None if leftpad is None else leftpad.numpy(),
+                                        causal=causal, window=window, rotary_interleaved=False, io_dtype=dt)
+    assert np.array_equal(f64(kc), kc_ref) and np.array_equal(f64(vc), vc_ref)        # appended rows, bit for bit
+    assert_close(f64(out), o_ref, dt, "out")
+    assert_lse_close(f64(lse), lse_ref, "lse")
+    if rot or lp:
+        return
+    # split-KV invariance on the same rows (no append: the cache already holds them)
+    out2 = _fa().flash_attn_with_kvcache(q, kc, vc, cache_seqlens=(seqlens + Tq).cuda(), block_table=None if bt is None else bt.cuda(),
+                                         causal=causal, window_size=window, num_splits=5)
+    assert_close(f64(out2), o_ref, dt, "out (5 splits, no append)")
+
+
 @pytest.mark.parametrize("Tq,softcap,alibi", [(1, 0.0, True), (5, 30.0, False), (70, 0.0, True), (130, 50.0, False)])
 def test_fp8_cache_with_alibi_or_softcap(Tq, softcap, alibi):
     """fp8 caches with ALiBi or softcap (round 2 returned FA_ERR_UNSUPPORTED): the general kernel's per-element bias path on
