@@ -13,7 +13,8 @@
 //   * paged KV (block_table), cache_batch_idx, cache_leftpad, in-kernel RoPE on Q, causal /
 //     window masks, and fp8-e4m3 K/V (dequantised while staging; k_descale folds into the softmax
 //     scale, v_descale into the final normalisation).
-// ALiBi / softcap decode falls back to the general forward kernel (fa_fwd.hip).
+// ALiBi / softcap: per-element score path of fa_decode_kernel (the token-major kernels step aside).
+// Head dims: widths 64 / 128 / 256 (256: 16-key tiles), narrower rows through the NARROW instantiations.
 #include "fa_common.h"
 #include "fa_rope.h"
 
@@ -24,9 +25,13 @@ constexpr int DEC_BN = 32;                     // keys per wave tile
 constexpr float DEC_RESCALE_THR = 8.0f;        // log2 units
 
 template <int D> struct DecSmem {
-    static constexpr int TILE = DEC_BN * D * 2;            // one 16-bit K (or V) tile
+    // D = 256: 16-key tiles (the same 8 KiB per tile and the same staging registers as 32 keys at D = 128); the S^T MFMA
+    // still spans 32 key rows - the upper 16 are masked - and P V takes one 16-key k-step
+    static constexpr int BN = D > 128 ? 16 : DEC_BN;
+    static constexpr int TILE = BN * D * 2;                // one 16-bit K (or V) tile
     static constexpr int WAVE = 4 * TILE;                  // 2 stages x (K + V), private per wave
-    static constexpr int TOTAL = 4 * WAVE;
+    static constexpr int MERGE = 2 * 4 * 32 * 4 + 4 * 32 * D * 4;     // the 4 waves' (m, l, O) at the end
+    static constexpr int TOTAL = 4 * WAVE > MERGE ? 4 * WAVE : MERGE;
 };
 
 struct DecArgs {
@@ -34,6 +39,7 @@ struct DecArgs {
     int n_splits;
     int rows;                  // T_q * G; a workgroup takes 32 of them (row block)
     int n_rb;                  // row blocks
+    int bias;                  // ALiBi slopes or softcap: per-element score path in fa_decode_kernel
     int grid_splits;           // fa_decode_kernel: key splits of the grid (= n_splits there)
     int group;                 // G
     int local;                 // RoPE position advances with the query row (causal / window)
@@ -43,7 +49,7 @@ struct DecArgs {
     float* lse_partial;        // [n_splits, B, Hq, T_q]
 };
 
-template <typename T, int D, bool KV8, bool PAGED>
+template <typename T, int D, bool KV8, bool PAGED, bool NARROW = false>
 __global__ void __launch_bounds__(DEC_THREADS, 1) fa_decode_kernel(const DecArgs da) {
     using E = Elem<T>;
     constexpr int KSTEPS = D / 16;
@@ -51,7 +57,8 @@ __global__ void __launch_bounds__(DEC_THREADS, 1) fa_decode_kernel(const DecArgs
     constexpr int TILE = DecSmem<D>::TILE;
     constexpr int EB = KV8 ? 1 : 2;                         // bytes per cache element
     constexpr int CPR = D * EB / 16;                        // 16-byte chunks per cache row
-    constexpr int CH = DEC_BN * CPR / 64;                   // chunks per lane per tile
+    constexpr int BN = DecSmem<D>::BN;                      // keys per wave tile
+    constexpr int CH = BN * CPR / 64;                       // chunks per lane per tile
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const KArgs& a = da.a;
@@ -96,6 +103,9 @@ __global__ void __launch_bounds__(DEC_THREADS, 1) fa_decode_kernel(const DecArgs
     if (wl >= 0) { const int l2 = t_row + off - wl; lo = l2 > lo ? l2 : lo; }
     if (!row_ok) { lo = 0x7fffffff; hi = -1; }
 
+    // NARROW: rows of head_dim_v (< D, a multiple of 8) valid columns in a D-wide kernel (D = 96 on the 128 width ...):
+    // the missing columns are zeros in Q and in the LDS tiles, and are not written
+    const int vcols = NARROW ? p.head_dim_v : D;
     // ---- Q fragments (B operand), RoPE applied in registers ----
     u32x4 qf[KSTEPS];
     {
@@ -109,7 +119,7 @@ __global__ void __launch_bounds__(DEC_THREADS, 1) fa_decode_kernel(const DecArgs
         for (int ks = 0; ks < KSTEPS; ++ks) {
             const int d_base = 16 * ks + 8 * g;
             u32x4 x = {0, 0, 0, 0};
-            if (row_ok) {
+            if (row_ok && (!NARROW || d_base < vcols)) {
                 x = *reinterpret_cast<const u32x4*>(qrow + d_base);
                 if (p.rotary_dim > 0 && d_base < p.rotary_dim && pos >= 0 && pos < p.seqlen_ro) {
                     u32x4 xp = x;
@@ -128,9 +138,9 @@ __global__ void __launch_bounds__(DEC_THREADS, 1) fa_decode_kernel(const DecArgs
     int tile_lo = 0;
     const int t_first = rbase / G;                                       // query positions of this row block
     const int t_last = (rbase + 31) / G < Tq - 1 ? (rbase + 31) / G : Tq - 1;
-    if (wl >= 0) { const int kmin = t_first + off - wl; if (kmin > 0) tile_lo = kmin / DEC_BN; }
-    int tile_hi = (seqlen_k + DEC_BN - 1) / DEC_BN;
-    if (wr >= 0) { const int kmax = t_last + off + wr; const int t2 = kmax < 0 ? 0 : kmax / DEC_BN + 1; tile_hi = t2 < tile_hi ? t2 : tile_hi; }
+    if (wl >= 0) { const int kmin = t_first + off - wl; if (kmin > 0) tile_lo = kmin / BN; }
+    int tile_hi = (seqlen_k + BN - 1) / BN;
+    if (wr >= 0) { const int kmax = t_last + off + wr; const int t2 = kmax < 0 ? 0 : kmax / BN + 1; tile_hi = t2 < tile_hi ? t2 : tile_hi; }
     const int n_all = tile_hi > tile_lo ? tile_hi - tile_lo : 0;
     const int per_split = ((n_all + da.n_splits - 1) / da.n_splits + 3) & ~3;     // multiple of 4 waves
     const int s_lo = tile_lo + split * per_split;
@@ -148,23 +158,28 @@ __global__ void __launch_bounds__(DEC_THREADS, 1) fa_decode_kernel(const DecArgs
 #ifndef FA_DEC_NS16
 #define FA_DEC_NS16 2
 #endif
-    constexpr int NS = KV8 ? FA_DEC_NS8 : FA_DEC_NS16;
+    constexpr int NS = D > 128 ? 1 : (KV8 ? FA_DEC_NS8 : FA_DEC_NS16);     // (D = 256: register budget)
     u32x4 kS[NS][CH], vS[NS][CH];
     // loop-invariant per-lane byte offsets inside a tile (row * row_stride + 16-byte column)
     uint32_t k_voff[CH], v_voff[CH];
+    bool cok[CH];                                           // NARROW: is this lane's chunk inside the row?
+    const int vchunks = vcols * EB / 16;
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
         const int cidx = lane + 64 * i;
         const int row = cidx / CPR, cc = cidx % CPR;
-        k_voff[i] = (uint32_t)(row * p.k_row_stride * EB + cc * 16);
-        v_voff[i] = (uint32_t)(row * p.v_row_stride * EB + cc * 16);
+        cok[i] = !NARROW || cc < vchunks;
+        const int ccl = cok[i] ? cc : 0;                    // (a chunk past the row reads chunk 0 and is zeroed)
+        k_voff[i] = (uint32_t)(row * p.k_row_stride * EB + ccl * 16);
+        v_voff[i] = (uint32_t)(row * p.v_row_stride * EB + ccl * 16);
     }
+    const u32x4 zero4 = {0, 0, 0, 0};
     // a 32-key tile lies inside one page when the left pad keeps tiles 32-aligned (page % 64 == 0)
-    const bool tiles_aligned = !PAGED || ((lp & (DEC_BN - 1)) == 0);
+    const bool tiles_aligned = !PAGED || ((lp & (BN - 1)) == 0);
     // a full, page-aligned tile: ONE scalar base per tile, no predication, no branch (so that the
     // compiler can count the loads in flight: see the steady-state loop below)
     auto load_fast = [&](int tile, u32x4 (&kreg)[CH], u32x4 (&vreg)[CH]) {
-        const int pos0 = lp + tile * DEC_BN;
+        const int pos0 = lp + tile * BN;
         int64_t ko, vo;
         if (PAGED) {
             const int pg = da.page_shift >= 0 ? (pos0 >> da.page_shift) : pos0 / p.page_block_size;
@@ -183,9 +198,10 @@ __global__ void __launch_bounds__(DEC_THREADS, 1) fa_decode_kernel(const DecArgs
 #pragma unroll
         for (int i = 0; i < CH; ++i) vreg[i] = *reinterpret_cast<const u32x4*>(vb + v_voff[i]);
     };
+    (void)cok; (void)zero4;
     auto load_tile = [&](int tile, u32x4 (&kreg)[CH], u32x4 (&vreg)[CH]) {
-        const int j0 = tile * DEC_BN;
-        if (tiles_aligned && j0 + DEC_BN <= seqlen_k) { load_fast(tile, kreg, vreg); return; }
+        const int j0 = tile * BN;
+        if (tiles_aligned && j0 + BN <= seqlen_k) { load_fast(tile, kreg, vreg); return; }
 #pragma unroll 1
         for (int i = 0; i < CH; ++i) {
             const int cidx = lane + 64 * i;
@@ -193,7 +209,7 @@ __global__ void __launch_bounds__(DEC_THREADS, 1) fa_decode_kernel(const DecArgs
             const int j = j0 + row;
             u32x4 z = {0, 0, 0, 0};
             u32x4 kx = z, vx = z;
-            if (j < seqlen_k) {
+            if (j < seqlen_k && (!NARROW || cc < vchunks)) {
                 const int pos = lp + j;
                 int64_t ko, vo;
                 if (PAGED) {
@@ -230,8 +246,8 @@ __global__ void __launch_bounds__(DEC_THREADS, 1) fa_decode_kernel(const DecArgs
                 lds_write_b128(vs + swzt_row_off<D>(row, cc * 32), l1);
                 lds_write_b128(vs + swzt_row_off<D>(row, cc * 32 + 16), h1);
             } else {
-                lds_write_b128(ks + swz_row_off<D>(row, cc * 16), kreg[i]);
-                lds_write_b128(vs + swzt_row_off<D>(row, cc * 16), vreg[i]);
+                lds_write_b128(ks + swz_row_off<D>(row, cc * 16), (NARROW && !cok[i]) ? zero4 : kreg[i]);
+                lds_write_b128(vs + swzt_row_off<D>(row, cc * 16), (NARROW && !cok[i]) ? zero4 : vreg[i]);
             }
         }
     };
@@ -242,14 +258,21 @@ __global__ void __launch_bounds__(DEC_THREADS, 1) fa_decode_kernel(const DecArgs
 #pragma unroll
         for (int rr2 = 0; rr2 < 16; ++rr2) oacc[d][rr2] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
-    const float c = a.scale_log2e * (KV8 ? p.k_descale : 1.0f);
+    // score modifiers (ALiBi slopes, softcap; reference order: include/mat_mul.h:113-116 - bias, then cap): the scores are
+    // brought to log2 units element by element and the exponent's multiplier becomes 1.  A wave-uniform branch: this
+    // kernel waits for HBM, not for the VALU.
+    const bool bias = da.bias != 0;
+    const float c = bias ? 1.0f : a.scale_log2e * (KV8 ? p.k_descale : 1.0f);
+    const float sc_lin = p.softmax_scale * (KV8 ? p.k_descale : 1.0f);
+    const float slope = (bias && p.alibi_slopes && row_ok) ? p.alibi_slopes[(int64_t)b * p.alibi_batch_stride + h] : 0.f;
+    const float cap = p.softcap, rcap = p.softcap > 0.f ? 1.0f / p.softcap : 0.f;
     const int v_rr = (lane & 15) >> 2;
     const int v_cb = (((lane >> 4) & 1) << 5) + ((lane & 3) << 3);
 
     auto compute_tile = [&](int tile, int stage) {
         const char* ks = wsm + stage * 2 * TILE;
         const char* vs = ks + TILE;
-        const int n0 = tile * DEC_BN;
+        const int n0 = tile * BN;
         // S^T[key][row] = K Q^T
         f32x16 s;
 #pragma unroll
@@ -259,10 +282,19 @@ __global__ void __launch_bounds__(DEC_THREADS, 1) fa_decode_kernel(const DecArgs
             const u32x4 kf = lds_read_b128(ks + swz_row_off<D>(l31, 32 * ksx + 16 * g));
             s = E::mfma(kf, qf[ksx], s);
         }
+        if (bias) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int j = n0 + (i & 3) + 8 * (i >> 2) + 4 * g;
+                float x = fmaf(-slope, fabsf((float)(t_row + off - j)), s[i] * sc_lin);
+                if (cap > 0.f) x = cap * fast_tanh(x * rcap);
+                s[i] = x * kLog2e;
+            }
+        }
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int j = n0 + (i & 3) + 8 * (i >> 2) + 4 * g;
-            if (j < lo || j > hi) s[i] = -INFINITY;
+            if (j < lo || j > hi || (BN == 16 && i >= 8)) s[i] = -INFINITY;      // (16-key tiles: key rows 16..31 are not there)
         }
         float mx = s[0];
 #pragma unroll
@@ -288,7 +320,7 @@ __global__ void __launch_bounds__(DEC_THREADS, 1) fa_decode_kernel(const DecArgs
         for (int i = 0; i < 16; ++i) { s[i] = fast_exp2(fmaf(s[i], c, -m_use)); psum += s[i]; }
         l_run += psum;
 #pragma unroll
-        for (int t2 = 0; t2 < 2; ++t2) {
+        for (int t2 = 0; t2 < BN / 16; ++t2) {
             u32x4 pf;
 #pragma unroll
             for (int w2 = 0; w2 < 4; ++w2) pf[w2] = E::pack2(s[8 * t2 + 2 * w2], s[8 * t2 + 2 * w2 + 1]);
@@ -303,12 +335,14 @@ __global__ void __launch_bounds__(DEC_THREADS, 1) fa_decode_kernel(const DecArgs
         }
     };
 
+    // LDS stage of step s0 + j: a compile-time constant for even NS (s0 is a multiple of NS)
+    auto stage_of = [](int s0_, int j_) { return (NS % 2 == 0) ? (j_ & 1) : ((s0_ + j_) & 1); };
     // pipeline over this wave's tiles t0 + 4 s: LDS stage s & 1 holds tile s while the register sets
     // hold tiles s+1 .. s+NS-1 (landed / landing) and the set just stored is re-loaded with s+1+NS.
     const int t0 = s_lo + wave;
     const int n_my = t0 < s_hi ? (s_hi - t0 + 3) / 4 : 0;
     // my tiles that lie completely inside [0, seqlen_k): s < n_full
-    const int n_full = t0 < s_hi ? ((seqlen_k / DEC_BN < s_hi ? seqlen_k / DEC_BN : s_hi) - t0 + 3) / 4 : 0;
+    const int n_full = t0 < s_hi ? ((seqlen_k / BN < s_hi ? seqlen_k / BN : s_hi) - t0 + 3) / 4 : 0;
     int s0 = 0;
     if (tiles_aligned && 2 * NS < n_full) {
         // steady state: every store / load is unconditional, so the vmcnt waits in front of the
@@ -321,9 +355,9 @@ __global__ void __launch_bounds__(DEC_THREADS, 1) fa_decode_kernel(const DecArgs
 #pragma unroll
             for (int j = 0; j < NS; ++j) {
                 const int nxt = (j + 1) % NS;
-                store_tile((j + 1) & 1, kS[nxt], vS[nxt]);
+                store_tile(stage_of(s0, j + 1), kS[nxt], vS[nxt]);
                 load_fast(t0 + 4 * (s0 + j + 1 + NS), kS[nxt], vS[nxt]);
-                compute_tile(t0 + 4 * (s0 + j), j & 1);
+                compute_tile(t0 + 4 * (s0 + j), stage_of(s0, j));
             }
         }
     } else {
@@ -342,9 +376,9 @@ __global__ void __launch_bounds__(DEC_THREADS, 1) fa_decode_kernel(const DecArgs
             const int ss = s0 + j;
             if (ss < n_my) {
                 const int nxt = (j + 1) % NS;              // compile-time after unrolling
-                if (ss + 1 < n_my) store_tile((j + 1) & 1, kS[nxt], vS[nxt]);
+                if (ss + 1 < n_my) store_tile(stage_of(s0, j + 1), kS[nxt], vS[nxt]);
                 if (ss + 1 + NS < n_my) load_tile(t0 + 4 * (ss + 1 + NS), kS[nxt], vS[nxt]);
-                compute_tile(t0 + 4 * ss, j & 1);
+                compute_tile(t0 + 4 * ss, stage_of(s0, j));
             }
         }
     }
@@ -386,6 +420,7 @@ __global__ void __launch_bounds__(DEC_THREADS, 1) fa_decode_kernel(const DecArgs
                                (int64_t)hq * p.o_head_stride + cs;
 #pragma unroll
                 for (int x = 0; x < D / 8; x += 2) {
+                    if (NARROW && cs + x >= vcols) break;
                     float v0 = 0.f, v1 = 0.f;
 #pragma unroll
                     for (int w2 = 0; w2 < 4; ++w2) {
@@ -445,7 +480,7 @@ __global__ void __launch_bounds__(256) decode_combine_kernel(const DecArgs da) {
     u32x4 o4;
 #pragma unroll
     for (int x = 0; x < 4; ++x) o4[x] = E::pack2(acc[2 * x], acc[2 * x + 1]);
-    *reinterpret_cast<u32x4*>(out) = o4;
+    if (p.head_dim_v == 0 || cc * 8 < p.head_dim_v) *reinterpret_cast<u32x4*>(out) = o4;     // (narrow rows: valid columns only)
     if (cc == 0) p.lse[b * p.lse_batch_stride + (int64_t)hq * p.lse_head_stride + t] = den > 0.f ? m + __logf(den) : -INFINITY;
 }
 
@@ -526,7 +561,7 @@ __global__ void __launch_bounds__(256) decode_combine_wide_kernel(const DecArgs 
         uint16_t* out = reinterpret_cast<uint16_t*>(p.o) + b * p.o_batch_stride + (int64_t)t * p.o_row_stride +
                         (int64_t)hq * p.o_head_stride + tid * 4;
         u32x2 o2 = {E::pack2(acc[0], acc[1]), E::pack2(acc[2], acc[3])};
-        *reinterpret_cast<u32x2*>(out) = o2;
+        if (p.head_dim_v == 0 || tid * 4 < p.head_dim_v) *reinterpret_cast<u32x2*>(out) = o2;
         if (tid == 0) p.lse[b * p.lse_batch_stride + (int64_t)hq * p.lse_head_stride + t] = den > 0.f ? m + __logf(den) : -INFINITY;
     }
 }
@@ -1058,8 +1093,10 @@ __global__ void __launch_bounds__(GEMV_THREADS) fa_decode_gemv_tm_kernel(const D
 
 // ---- host ---------------------------------------------------------------------------------------
 bool decode_applicable(const fa_params& p) {
-    if (p.alibi_slopes || p.softcap > 0.f) return false;
-    if (!((p.head_dim == 64 || p.head_dim == 128) && p.head_dim_v == 0)) return false;
+    // widths 64 / 128 (16-bit and fp8 caches) and 256 (16-bit); narrower rows (head_dim_v valid columns, 16-bit caches)
+    const bool kv8 = p.kv_dtype == FA_FP8_E4M3;
+    if (!(p.head_dim == 64 || p.head_dim == 128 || (p.head_dim == 256 && !kv8))) return false;
+    if (p.head_dim_v != 0 && (kv8 || p.head_dim_v % 8 != 0 || p.head_dim_v > p.head_dim)) return false;
     return true;                  // any number of packed rows, 32 per workgroup (blockIdx.z); decode_takes() decides who runs
 }
 
@@ -1180,21 +1217,29 @@ static int launch_decode_td(DecArgs& da, hipStream_t stream) {
             return 0;
         }
         // fp8 cache, one query row per kv-head, a head layout the token-major kernel does not take: one workgroup per head
-        if (kv8 && da.rows == 1 && da.group == 1) {
+        if (kv8 && da.rows == 1 && da.group == 1 && !da.bias) {
             if (paged) hipLaunchKernelGGL((fa_decode_gemv_fp8_kernel<T, true>), grid, dim3(GEMV_THREADS), 0, stream, da);
             else       hipLaunchKernelGGL((fa_decode_gemv_fp8_kernel<T, false>), grid, dim3(GEMV_THREADS), 0, stream, da);
             if (da.n_splits > 1) launch_decode_combine<T>(da, stream);
             return 0;
         }
     }
-#define FA_LAUNCH_DEC(KV8, PAGED)                                                                                   \
+#define FA_LAUNCH_DEC(KV8, PAGED, NARROW)                                                                           \
     do {                                                                                                            \
-        auto kern = fa_decode_kernel<T, D, KV8, PAGED>;                                                             \
+        auto kern = fa_decode_kernel<T, D, KV8, PAGED, NARROW>;                                                     \
         FA_SET_LDS_ONCE(kern, smem); \
         hipLaunchKernelGGL(kern, grid, dim3(DEC_THREADS), smem, stream, da);                                        \
     } while (0)
-    if (kv8) { if (paged) FA_LAUNCH_DEC(true, true); else FA_LAUNCH_DEC(true, false); }
-    else     { if (paged) FA_LAUNCH_DEC(false, true); else FA_LAUNCH_DEC(false, false); }
+    const bool narrow = p.head_dim_v != 0;
+    if constexpr (D <= 128) {
+        if (kv8) { if (paged) FA_LAUNCH_DEC(true, true, false); else FA_LAUNCH_DEC(true, false, false); }
+        else if (!narrow) { if (paged) FA_LAUNCH_DEC(false, true, false); else FA_LAUNCH_DEC(false, false, false); }
+    }
+    if (!kv8 && (narrow || D > 128)) {
+        // one instantiation serves full-width D = 256 rows and every narrow width (vcols is a run-time count there)
+        if (D > 128 && !narrow) da.a.p.head_dim_v = D;
+        if (paged) FA_LAUNCH_DEC(false, true, true); else FA_LAUNCH_DEC(false, false, true);
+    }
 #undef FA_LAUNCH_DEC
     if (da.n_splits > 1) launch_decode_combine<T>(da, stream);
     return 0;
@@ -1208,6 +1253,7 @@ int launch_decode_splitkv(const KArgs& a, void* ws, hipStream_t stream) {
     da.group = p.nheads_q / p.nheads_k;
     da.rows = p.seqlen_q * da.group;
     da.local = (p.is_causal || p.window_left >= 0 || p.window_right >= 0) ? 1 : 0;
+    da.bias = (p.alibi_slopes != nullptr || p.softcap > 0.f) ? 1 : 0;
     da.n_splits = decode_num_partials(p);             // (token-major kernel: grid splits x key sub-ranges; else the grid's y)
     da.ksub = gemv_tm_applicable(p) ? gemv_tm_ksub(p) : 1;
     da.page_shift = -1;
@@ -1226,6 +1272,7 @@ int launch_decode_splitkv(const KArgs& a, void* ws, hipStream_t stream) {
     switch (p.head_dim) {
         case 64:  return bf ? launch_decode_td<bf16_tag, 64>(da, stream) : launch_decode_td<fp16_tag, 64>(da, stream);
         case 128: return bf ? launch_decode_td<bf16_tag, 128>(da, stream) : launch_decode_td<fp16_tag, 128>(da, stream);
+        case 256: return bf ? launch_decode_td<bf16_tag, 256>(da, stream) : launch_decode_td<fp16_tag, 256>(da, stream);
         default:  return -2;
     }
 }

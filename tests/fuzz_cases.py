@@ -261,7 +261,7 @@ def kvcache_case(rng, idx):
     B = int(rng.integers(1, 5))
     Hk = int(rng.choice([1, 2, 4, 8]))
     Hq = Hk * int(rng.choice([1, 2, 4, 8]))
-    D = int(rng.choice([16, 32, 64, 64, 128, 128, 128, 256]))
+    D = int(rng.choice([16, 32, 64, 64, 96, 128, 128, 128, 160, 256]))
     dt = str(rng.choice(["fp16", "bf16"]))
     Tq = int(rng.choice([1, 1, 1, 2, 5, 33, 70, 130]))
     Tn = Tq if rng.random() < 0.7 else 0
@@ -280,7 +280,11 @@ def kvcache_case(rng, idx):
     slopes = None
     if rng.random() < 0.15:
         slopes = torch.tensor([0.05 * (i + 1) for i in range(Hq)], dtype=torch.float32, device="cuda")
-    splits = int(rng.choice([0, 0, 1, 2, 3, 5]))
+    splits = int(rng.choice([0, 0, 1, 2, 3, 5, 40]))
+    # softcap: the kvcache op takes it without a window and without ALiBi only (fused_mha_forward_kvcache.cu:469-472)
+    softcap = 0.0
+    if slopes is None and rng.random() < 0.15:
+        softcap, causal, window = float(rng.choice([10.0, 30.0, 50.0])), False, (-1, -1)
     group = Hq // Hk
     fp8 = D in (64, 128) and rng.random() < 0.3      # (any T_q x group, ALiBi included: decode kernels or fa_fwd_kernel<KV8>)
     kd, vd = (0.05, 0.04) if fp8 else (None, None)
@@ -290,7 +294,7 @@ def kvcache_case(rng, idx):
     if rng.random() < 0.3:
         seqlens[0] = int(rng.choice([1, 63, 64, 65, 255, 256])) if Smax - Tn - 20 > 256 else 1
     desc = f"kvcache#{idx} B{B} Tq{Tq} Hq{Hq} Hk{Hk} D{D} Smax{Smax} Tn{Tn} {dt} causal={causal} window={window} rd={rd} " \
-           f"inter={inter} bidx={use_bidx} leftpad={use_lp} alibi={slopes is not None} paged={page if paged else 0} " \
+           f"inter={inter} bidx={use_bidx} leftpad={use_lp} alibi={slopes is not None} softcap={softcap} paged={page if paged else 0} " \
            f"splits={splits} fp8={fp8} seqlens={seqlens.tolist()}"
     s = 9000 + 10 * idx
     q = rand16((B, Tq, Hq, D), dt, s + 1)
@@ -320,14 +324,14 @@ def kvcache_case(rng, idx):
         q, kc, vc, k=knew, v=vnew, rotary_cos=cos, rotary_sin=sin, cache_seqlens=seqlens.cuda(),
         cache_batch_idx=None if bidx is None else bidx.cuda(), cache_leftpad=None if lp is None else lp.cuda(),
         block_table=None if bt is None else bt.cuda(), causal=causal, window_size=window,
-        rotary_interleaved=inter, alibi_slopes=slopes, num_splits=splits, return_softmax_lse=True,
+        rotary_interleaved=inter, alibi_slopes=slopes, num_splits=splits, return_softmax_lse=True, softcap=softcap,
         k_descale=kd, v_descale=vd)
     o_ref, lse_ref = oracle.kvcache_fwd(
         f64(q), kc_ref, vc_ref, k=None if knew is None else f64(knew), v=None if vnew is None else f64(vnew),
         rotary_cos=None if cos is None else f64(cos), rotary_sin=None if sin is None else f64(sin),
         cache_seqlens=seqlens.numpy(), cache_batch_idx=None if bidx is None else bidx.numpy(),
         cache_leftpad=None if lp is None else lp.numpy(), block_table=None if bt is None else bt.numpy(),
-        causal=causal, window=window, rotary_interleaved=inter,
+        causal=causal, window=window, rotary_interleaved=inter, softcap=softcap,
         alibi_slopes=None if slopes is None else f64(slopes), io_dtype=dt, k_descale=kd, v_descale=vd)
     if fp8:
         # appended rows are stored as fp8 codes: the oracle's cache holds the same codes' values (ties may round apart)

@@ -301,6 +301,105 @@ def test_fp8_cache_with_alibi_or_softcap(Tq, softcap, alibi):
     assert_lse_close(f64(lse), lse_ref, "lse", atol=3e-2)
 
 
+@pytest.mark.parametrize("B,Tq,Hq,Hk,D,dt,kv8,paged,softcap,alibi,nsplit", [
+    (2, 1, 32, 8, 128, "fp16", False, True, 50.0, None, 0),        # Gemma-style capped logits, GQA decode, heuristic split-KV
+    (3, 1, 16, 16, 128, "bf16", False, False, 0.0, "h", 0),        # ALiBi slopes [H], MHA: the token-major kernel steps aside
+    (2, 1, 8, 2, 64, "fp16", False, True, 0.0, "bh", 7),           # slopes [B, H], D = 64, explicit 7 splits
+    (2, 4, 16, 4, 128, "bf16", False, True, 0.0, "h", 0),          # 4 query positions: the bias follows each row's position
+    (2, 6, 16, 2, 128, "fp16", True, True, 30.0, None, 3),         # fp8 cache + softcap, two row blocks
+    (4, 1, 8, 8, 128, "bf16", True, False, 0.0, "h", 0),           # fp8 cache + ALiBi, one row per kv-head (not the gemv kernels)
+])
+def test_decode_with_softcap_or_alibi(B, Tq, Hq, Hk, D, dt, kv8, paged, softcap, alibi, nsplit):
+    """Score modifiers on the decode kernel (round 3: they fell onto fa_fwd_kernel, one workgroup per query head and no
+    split-KV - 5 to 20 x the plain decode step, tools/decode_features_sweep.py).  Semantics: include/mat_mul.h:113-116
+    (ALiBi -slope |i - j'| first, then cap tanh(s / cap)); the kvcache op rejects softcap with a window or ALiBi
+    (fused_mha_forward_kvcache.cu:469-472), so capped cases are non-causal.  Tolerance: the io dtype's (fp8: 1.5 x, LSE 3e-2)."""
+    Smax, page = 1536, 256
+    g = torch.Generator().manual_seed(23)
+    seqlens = torch.randint(300, Smax - Tq - 8, (B,), generator=g, dtype=torch.int32)
+    seqlens[0] = Smax - Tq - 8
+    q = rand16((B, Tq, Hq, D), dt, 1)
+    bt = None
+    if paged:
+        pps = Smax // page
+        nblk = B * pps
+        kc = rand16((nblk, page, Hk, D), dt, 2); vc = rand16((nblk, page, Hk, D), dt, 3)
+        bt = torch.randperm(nblk, generator=g).reshape(B, pps).to(torch.int32)
+    else:
+        kc = rand16((B, Smax, Hk, D), dt, 2); vc = rand16((B, Smax, Hk, D), dt, 3)
+    kw, okw = {}, {}
+    if kv8:
+        kd, vd = 0.0625, 0.03125
+        kc = (kc.float() / kd).to(torch.float8_e4m3fn); vc = (vc.float() / vd).to(torch.float8_e4m3fn)
+        kw = dict(k_descale=kd, v_descale=vd); okw = dict(kw)
+        kc_ref, vc_ref = kc.float().double().cpu().numpy(), vc.float().double().cpu().numpy()
+    else:
+        kc_ref, vc_ref = f64(kc), f64(vc)
+    slopes = None
+    if alibi == "h":
+        slopes = torch.tensor([2.0 ** (-8.0 * (i + 1) / Hq) for i in range(Hq)], dtype=torch.float32, device="cuda")
+    elif alibi == "bh":
+        slopes = (torch.rand(B, Hq, generator=g) * 0.2).to(torch.float32).cuda()
+    causal = softcap == 0.0
+    out, lse = _fa().flash_attn_with_kvcache(q, kc, vc, cache_seqlens=seqlens.cuda(), block_table=None if bt is None else bt.cuda(),
+                                             causal=causal, softcap=softcap, alibi_slopes=slopes, num_splits=nsplit,
+                                             return_softmax_lse=True, **kw)
+    o_ref, lse_ref = oracle.kvcache_fwd(f64(q), kc_ref, vc_ref, cache_seqlens=seqlens.numpy(),
+                                        block_table=None if bt is None else bt.numpy(), causal=causal, softcap=softcap,
+                                        alibi_slopes=None if slopes is None else f64(slopes), io_dtype=dt, **okw)
+    assert_close(f64(out), o_ref, dt, "out", mult=1.5 if kv8 else 1.0)
+    assert_lse_close(f64(lse), lse_ref, "lse", **(dict(atol=3e-2) if kv8 else {}))
+
+
+@pytest.mark.parametrize("B,Tq,Hq,Hk,D,dt,paged,rot,softcap,nsplit", [
+    (2, 1, 16, 8, 256, "bf16", True, True, 0.0, 0),         # D = 256 (Gemma-style heads): 16-key tiles on the decode kernel
+    (1, 1, 8, 4, 256, "fp16", False, False, 50.0, 0),       # D = 256 + capped logits, batch 1 (split until the chip is full)
+    (3, 5, 8, 2, 256, "bf16", True, True, 0.0, 3),          # D = 256, 5 query positions x G = 4, explicit splits
+    (2, 1, 12, 4, 96, "fp16", True, True, 0.0, 0),          # D = 96 on the 128 width: columns 96..127 are zeros, never stored
+    (2, 3, 8, 8, 80, "bf16", False, True, 0.0, 2),          # D = 80, MHA, 3 positions
+    (2, 1, 8, 2, 40, "fp16", True, False, 0.0, 0),          # D = 40 on the 64 width
+    (1, 2, 4, 2, 160, "bf16", False, True, 0.0, 5),         # D = 160 on the 256 width
+    (2, 1, 4, 1, 224, "fp16", True, False, 30.0, 0),        # D = 224 + softcap, MQA
+])
+def test_decode_head_dims_256_and_narrow(B, Tq, Hq, Hk, D, dt, paged, rot, softcap, nsplit):
+    """Head dims beyond 64 / 128 on the decode kernel (round 3: D = 256 and every D that is not a kernel width fell onto
+    fa_fwd_kernel - one workgroup per query head, no split-KV: 796 us against 33 us for a batch-1 step at 8 k context,
+    tools/decode_head_dims.py).  D = 256 runs 16-key tiles; other dims run the next width with the missing columns read
+    as zeros.  Semantics as every kvcache case (append + RoPE at cache_seqlens); tolerance: the io dtype's (x 2 with RoPE)."""
+    Smax, page = 1280, 256
+    g = torch.Generator().manual_seed(31)
+    seqlens = torch.randint(100, Smax - Tq - 8, (B,), generator=g, dtype=torch.int32)
+    seqlens[0] = Smax - Tq - 8
+    q = rand16((B, Tq, Hq, D), dt, 1)
+    knew = rand16((B, Tq, Hk, D), dt, 4); vnew = rand16((B, Tq, Hk, D), dt, 5)
+    bt = None
+    if paged:
+        pps = Smax // page
+        nblk = B * pps + 1
+        kc = rand16((nblk, page, Hk, D), dt, 2); vc = rand16((nblk, page, Hk, D), dt, 3)
+        bt = torch.randperm(nblk, generator=g)[: B * pps].reshape(B, pps).to(torch.int32)
+    else:
+        kc = rand16((B, Smax, Hk, D), dt, 2); vc = rand16((B, Smax, Hk, D), dt, 3)
+    rd = 32 if D < 64 else 64
+    cos, sin = _rotary(Smax + 8, rd, dt) if rot else (None, None)
+    causal = softcap == 0.0
+    kc_ref, vc_ref = f64(kc).copy(), f64(vc).copy()
+    out, lse = _fa().flash_attn_with_kvcache(q, kc, vc, k=knew, v=vnew, rotary_cos=cos, rotary_sin=sin,
+                                             cache_seqlens=seqlens.cuda(), block_table=None if bt is None else bt.cuda(),
+                                             causal=causal, softcap=softcap, rotary_interleaved=True, num_splits=nsplit,
+                                             return_softmax_lse=True)
+    o_ref, lse_ref = oracle.kvcache_fwd(f64(q), kc_ref, vc_ref, k=f64(knew), v=f64(vnew),
+                                        rotary_cos=None if cos is None else f64(cos), rotary_sin=None if sin is None else f64(sin),
+                                        cache_seqlens=seqlens.numpy(), block_table=None if bt is None else bt.numpy(),
+                                        causal=causal, softcap=softcap, rotary_interleaved=True, io_dtype=dt)
+    tol = 2.0 ** (-7 if dt == "bf16" else -10)
+    assert np.abs(f64(kc) - kc_ref).max() <= tol * max(1.0, np.abs(kc_ref).max())       # appended (rotated) K rows
+    assert np.array_equal(f64(vc), vc_ref)
+    assert out.shape == q.shape
+    assert_close(f64(out), o_ref, dt, "out", mult=2.0 if rot else 1.0)
+    assert_lse_close(f64(lse), lse_ref, "lse", **(dict(atol=2e-2) if rot else {}))
+
+
 def test_full_size_config4_decode_paged_rotary_fp8():
     """BASELINE config 4 at full size (B128, 32 heads, D128, cache_seqlen 8192, paged KV with a random
     block table, NeoX rotary, fp8-e4m3 KV), checked through size-independent properties:
