@@ -31,7 +31,11 @@ template <int D> struct DecSmem {
     static constexpr int TILE = BN * D * 2;                // one 16-bit K (or V) tile
     static constexpr int WAVE = 4 * TILE;                  // 2 stages x (K + V), private per wave
     static constexpr int MERGE = 2 * 4 * 32 * 4 + 4 * 32 * D * 4;     // the 4 waves' (m, l, O) at the end
-    static constexpr int TOTAL = 4 * WAVE > MERGE ? 4 * WAVE : MERGE;
+    // D = 256: the Q fragments (the same for the four waves: 16 k-steps x 64 lanes x 16 B) live in LDS behind the waves'
+    // tiles instead of 64 registers per lane
+    static constexpr int QOFF = 4 * WAVE;
+    static constexpr int QBYTES = D > 128 ? (D / 16) * 64 * 16 : 0;
+    static constexpr int TOTAL = QOFF + QBYTES > MERGE ? QOFF + QBYTES : MERGE;
 };
 
 struct DecArgs {
@@ -107,7 +111,8 @@ __global__ void __launch_bounds__(DEC_THREADS, 1) fa_decode_kernel(const DecArgs
     // the missing columns are zeros in Q and in the LDS tiles, and are not written
     const int vcols = NARROW ? p.head_dim_v : D;
     // ---- Q fragments (B operand), RoPE applied in registers ----
-    u32x4 qf[KSTEPS];
+    constexpr bool Q_LDS = DecSmem<D>::QBYTES > 0;
+    u32x4 qf[Q_LDS ? 1 : KSTEPS];
     {
         const uint16_t* qrow = reinterpret_cast<const uint16_t*>(p.q) + (int64_t)b * p.q_batch_stride +
                                (int64_t)t_row * p.q_row_stride + (int64_t)h * p.q_head_stride;
@@ -130,9 +135,12 @@ __global__ void __launch_bounds__(DEC_THREADS, 1) fa_decode_kernel(const DecArgs
                     rope_chunk<T>(x, xp, cosp, sinp, d_base, p.rotary_dim, p.rotary_interleaved != 0);
                 }
             }
-            qf[ks] = x;
+            if constexpr (Q_LDS) { if (wave == 0) lds_write_b128(smem + DecSmem<D>::QOFF + (ks * 64 + lane) * 16, x); }
+            else qf[ks] = x;
         }
     }
+    if constexpr (Q_LDS) __syncthreads();
+    (void)qf;
 
     // ---- key-tile range of this split / this wave ----
     int tile_lo = 0;
@@ -158,7 +166,10 @@ __global__ void __launch_bounds__(DEC_THREADS, 1) fa_decode_kernel(const DecArgs
 #ifndef FA_DEC_NS16
 #define FA_DEC_NS16 2
 #endif
-    constexpr int NS = D > 128 ? 1 : (KV8 ? FA_DEC_NS8 : FA_DEC_NS16);     // (D = 256: register budget)
+#ifndef FA_DEC_NS256
+#define FA_DEC_NS256 1                 // D = 256: two sets spill (172-280 bytes of scratch per lane)
+#endif
+    constexpr int NS = D > 128 ? FA_DEC_NS256 : (KV8 ? FA_DEC_NS8 : FA_DEC_NS16);     // (D = 256: register budget)
     u32x4 kS[NS][CH], vS[NS][CH];
     // loop-invariant per-lane byte offsets inside a tile (row * row_stride + 16-byte column)
     uint32_t k_voff[CH], v_voff[CH];
@@ -280,7 +291,8 @@ __global__ void __launch_bounds__(DEC_THREADS, 1) fa_decode_kernel(const DecArgs
 #pragma unroll
         for (int ksx = 0; ksx < KSTEPS; ++ksx) {
             const u32x4 kf = lds_read_b128(ks + swz_row_off<D>(l31, 32 * ksx + 16 * g));
-            s = E::mfma(kf, qf[ksx], s);
+            if constexpr (Q_LDS) s = E::mfma(kf, lds_read_b128(smem + DecSmem<D>::QOFF + (ksx * 64 + lane) * 16), s);
+            else s = E::mfma(kf, qf[ksx], s);
         }
         if (bias) {
 #pragma unroll
