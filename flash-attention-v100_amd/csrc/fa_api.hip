@@ -25,6 +25,7 @@ int launch_kvcache_append(const KArgs& a, hipStream_t stream);
 int launch_decode(const KArgs& a, hipStream_t stream);
 size_t decode_workspace_bytes(const fa_params& p);
 bool decode_applicable(const fa_params& p);
+bool decode_takes(const fa_params& p);
 }  // namespace fa
 
 static thread_local std::string g_last_error;
@@ -134,7 +135,36 @@ const char* fa_build_info(void) {
 }
 
 
-size_t fa_fwd_workspace_bytes(const fa_params*) { return 0; }
+// Decode issued through the varlen op (vLLM-style callers: every sequence brings the same few query tokens, K / V are
+// paged with a block_table, lengths come from seqused_k or cu_seqlens_k): the layout is the kv-cache op's - q [B, T_q, H, D]
+// with batch stride T_q rows, LSE [H, B T_q] - so the decode kernels (GQA packing, split-KV) can serve it instead of
+// fa_fwd_kernel's one workgroup per sequence and head (B 1, H 32/8, 8 k context: 240 -> 32 us; tools/varlen_decode_probe.py).
+// Needs the split-KV workspace: fa_fwd_workspace_bytes() reports it, and without it the general path runs as before.
+static bool varlen_decode_route(const fa_params& p, fa_params& d) {
+    if (!p.block_table || !p.cu_seqlens_q || !p.cu_seqlens_k || p.p_dropout > 0.f || p.dmask) return false;
+    if (p.batch <= 0 || p.seqlen_q <= 0 || p.total_q != (int64_t)p.batch * p.seqlen_q) return false;   // uniform T_q (host-checkable)
+    if (p.kv_dtype != p.dtype || p.page_block_size <= 0 || p.page_block_size % 64 != 0) return false;
+    d = p;
+    d.cache_seqlens = p.seqused_k;                       // NULL: cu_seqlens_k differences (dec_cache_len in fa_decode.hip)
+    d.seqused_k = nullptr;
+    d.cu_seqlens_q = nullptr;
+    d.q_batch_stride = (int64_t)p.seqlen_q * p.q_row_stride;
+    d.o_batch_stride = (int64_t)p.seqlen_q * p.o_row_stride;
+    d.lse_batch_stride = p.seqlen_q;                     // LSE [H, total_q]: head stride as given
+    d.k_new = d.v_new = nullptr; d.seqlen_new = 0;
+    d.rotary_cos = d.rotary_sin = nullptr; d.rotary_dim = 0;
+    d.cache_batch_idx = nullptr; d.cache_leftpad = nullptr;
+    d.num_splits = 0;
+    if (d.seqlen_q == 1 && !d.alibi_slopes) d.is_causal = 0;
+    if (d.is_causal) d.window_right = 0;
+    return fa::decode_takes(d);
+}
+
+size_t fa_fwd_workspace_bytes(const fa_params* p) {
+    fa_params d;
+    if (!p || !varlen_decode_route(*p, d)) return 0;
+    return fa::decode_workspace_bytes(d);
+}
 size_t fa_bwd_workspace_bytes(const fa_params* p) { return p ? fa::bwd_workspace_bytes(*p) : 0; }
 size_t fa_fwd_kvcache_workspace_bytes(const fa_params* p) { return p ? fa::decode_workspace_bytes(*p) : 0; }
 
@@ -168,6 +198,20 @@ int fa_varlen_fwd(const fa_params* pp, void* stream) {
     }
     if (p.p_dropout > 0.f && p.block_table) return fail(FA_ERR_UNSUPPORTED, "dropout with paged K/V is not supported");
     if (p.total_q == 0 || p.seqlen_q == 0) return FA_OK;
+    {
+        fa_params d;
+        if (varlen_decode_route(p, d)) {
+            const size_t need = fa::decode_workspace_bytes(d);
+            if (need == 0 || (d.workspace && d.workspace_bytes >= need)) {
+                fa::KArgs ad = make_args(d, 128);
+                ad.seqlens_k = d.cache_seqlens;
+                ad.kv_mode = 1;
+                rc = fa::launch_decode(ad, static_cast<hipStream_t>(stream));
+                if (rc) return fail(FA_ERR_UNSUPPORTED, "no decode kernel for this varlen configuration");
+                return check_hip("fa_varlen_fwd (decode kernels) launch");
+            }
+        }
+    }
     normalize(p, false);
     fa::KArgs a = make_args(p, 128);
     a.seqlens_k = p.seqused_k;

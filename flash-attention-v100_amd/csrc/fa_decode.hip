@@ -38,6 +38,17 @@ template <int D> struct DecSmem {
     static constexpr int TOTAL = QOFF + QBYTES > MERGE ? QOFF + QBYTES : MERGE;
 };
 
+// keys in the cache of batch entry b: cache_seqlens[b] (kv-cache op), or - decode issued through the varlen op - the
+// cu_seqlens_k difference, clamped by seqused_k when both are given (include/template.h:65-68)
+__device__ __forceinline__ int dec_cache_len(const fa_params& p, int b) {
+    int L = p.cache_seqlens ? p.cache_seqlens[b] : 0;
+    if (p.cu_seqlens_k) {
+        const int d = p.cu_seqlens_k[b + 1] - p.cu_seqlens_k[b];
+        L = p.cache_seqlens ? (L > 0 ? (L < d ? L : d) : 0) : d;
+    }
+    return L;
+}
+
 struct DecArgs {
     KArgs a;
     int n_splits;
@@ -86,7 +97,7 @@ __global__ void __launch_bounds__(DEC_THREADS, 1) fa_decode_kernel(const DecArgs
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     char* wsm = smem + wave * DecSmem<D>::WAVE;
 
-    const int L = p.cache_seqlens ? p.cache_seqlens[b] : 0;
+    const int L = dec_cache_len(p, b);
     const int lp = p.cache_leftpad ? p.cache_leftpad[b] : 0;
     const int cb = p.cache_batch_idx ? p.cache_batch_idx[b] : b;
     const int seqlen_k = L + p.seqlen_new;
@@ -629,7 +640,7 @@ __global__ void __launch_bounds__(GEMV_THREADS) fa_decode_gemv_fp8_kernel(const 
     const int tid = threadIdx.x, lane = tid & 63, grp = lane >> 3, sub = lane & 7;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    const int L = p.cache_seqlens ? p.cache_seqlens[b] : 0;
+    const int L = dec_cache_len(p, b);
     const int lp = p.cache_leftpad ? p.cache_leftpad[b] : 0;
     const int cb = p.cache_batch_idx ? p.cache_batch_idx[b] : b;
     const int seqlen_k = L + p.seqlen_new;
@@ -893,7 +904,7 @@ __global__ void __launch_bounds__(GEMV_THREADS) fa_decode_gemv_tm_kernel(const D
     const int ksub = ksub_n == 1 ? 0 : wave / n_hg;
     const int hg_step = ksub_n == 1 ? 4 : n_hg;                   // (with sub-ranges every head group has its waves: one round)
 
-    const int L = p.cache_seqlens ? p.cache_seqlens[b] : 0;
+    const int L = dec_cache_len(p, b);
     const int lp = p.cache_leftpad ? p.cache_leftpad[b] : 0;
     const int cb = p.cache_batch_idx ? p.cache_batch_idx[b] : b;
     const int seqlen_k = L + p.seqlen_new;

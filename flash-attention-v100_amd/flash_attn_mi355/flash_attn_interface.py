@@ -464,6 +464,11 @@ def _varlen_forward(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqle
     if return_attn_probs and dropout_p > 0.0:
         dmask = torch.zeros((T_Q, H_Q, max_seqlen_k), dtype=q.dtype, device=q.device)
         p.dmask = _ptr(dmask)
+    # (decode issued through this op - the same few query tokens per sequence over paged K / V - runs the decode kernels
+    #  when their split-KV workspace is there: fa_api.hip varlen_decode_route)
+    ws = _workspace(_lib.lib.fa_fwd_workspace_bytes(ctypes.byref(p)), q.device)
+    if ws is not None:
+        p.workspace, p.workspace_bytes = _ptr(ws), ws.numel()
     if q_.numel() > 0:
         with torch.cuda.device(q.device):
             _lib.call("fa_varlen_fwd", p, _stream(q.device))

@@ -88,6 +88,68 @@ def test_varlen_paged_kv(page, D):
     assert_lse_close(f64(lse), lse_ref, "lse")
 
 
+@pytest.mark.parametrize("Tq,Hq,Hk,D,dt,page,use_seqused,causal,window,softcap,alibi", [
+    (1, 32, 8, 128, "bf16", 256, True, True, (-1, -1), 0.0, False),      # the vLLM-style decode step: token-major kernel
+    (1, 8, 8, 128, "fp16", 64, False, True, (-1, -1), 0.0, False),       # lengths from cu_seqlens_k only
+    (4, 16, 2, 128, "fp16", 128, True, True, (-1, -1), 0.0, False),      # 4 speculative tokens, G = 8: one row block
+    (3, 8, 2, 64, "bf16", 64, True, True, (200, 0), 0.0, True),          # window + ALiBi, D = 64, seqused_k clamps cu_seqlens_k
+    (2, 6, 2, 96, "fp16", 128, False, False, (-1, -1), 30.0, False),     # narrow head dim + softcap (varlen allows it without a window)
+    (1, 4, 4, 256, "bf16", 256, True, True, (-1, -1), 0.0, False),       # D = 256
+])
+def test_varlen_decode_runs_the_decode_kernels(Tq, Hq, Hk, D, dt, page, use_seqused, causal, window, softcap, alibi):
+    """Decode issued through the varlen op: every sequence brings the same T_q query tokens (total_q == B * max_seqlen_q), K / V
+    are paged (block_table), lengths come from seqused_k and / or cu_seqlens_k.  With the workspace fa_fwd_workspace_bytes()
+    asks for, fa_varlen_fwd hands the call to the decode kernels (GQA packing, split-KV: 240 -> 32 us at batch 1,
+    tools/varlen_decode_probe.py); semantics are the varlen op's (include/template.h:65-68 for seqused_k, bottom-right causal
+    alignment, LSE [H, T]) - checked against the varlen oracle, and against the general kernel (no workspace: the C ABI's
+    fallback) to the io tolerance."""
+    import ctypes
+    from flash_attn_mi355 import _lib, flash_attn_interface as fi
+    lens_k = [700, 33, 1024, 1, 257]
+    B = len(lens_k)
+    used = [600, 33, 1000, 1, 300] if use_seqused else None      # (last entry: seqused_k > the cu_seqlens_k difference)
+    pps = [(l + page - 1) // page for l in lens_k]
+    nblk = sum(pps) + 2
+    g = torch.Generator().manual_seed(41)
+    perm = iter(torch.randperm(nblk, generator=g).tolist())
+    bt = torch.zeros((B, max(pps)), dtype=torch.int32)
+    for b in range(B):
+        for j in range(pps[b]):
+            bt[b, j] = next(perm)
+    kp = rand16((nblk, page, Hk, D), dt, 11); vp = rand16((nblk, page, Hk, D), dt, 12)
+    q = rand16((B * Tq, Hq, D), dt, 13)
+    cu_q, cu_k = _cu([Tq] * B), _cu(lens_k)
+    su = None if used is None else torch.tensor(used, dtype=torch.int32).cuda()
+    slopes = torch.tensor([0.03 * (i + 1) for i in range(Hq)], dtype=torch.float32, device="cuda") if alibi else None
+    kw = dict(causal=causal, window_size=window, softcap=softcap, alibi_slopes=slopes, block_table=bt.cuda(), seqused_k=su)
+    calls = []
+    orig = _lib.call
+    def spy(name, p, stream):
+        calls.append((name, int(p.workspace_bytes)))
+        return orig(name, p, stream)
+    _lib.call = spy
+    try:
+        out, lse, _ = _fa().flash_attn_varlen_func(q, kp, vp, cu_q, cu_k, Tq, max(lens_k), return_attn_probs=True, **kw)
+    finally:
+        _lib.call = orig
+    assert calls and calls[0][0] == "fa_varlen_fwd"
+    o_ref, lse_ref = oracle.varlen_fwd(f64(q), f64(kp), f64(vp), cu_q.cpu().numpy(), cu_k.cpu().numpy(), Tq, max(lens_k), D ** -0.5,
+                                       causal=causal, window=window, softcap=softcap,
+                                       alibi_slopes=None if slopes is None else f64(slopes),
+                                       seqused_k=None if used is None else np.array(used), block_table=bt.numpy())
+    assert_close(f64(out), o_ref, dt, "out")
+    assert_lse_close(f64(lse), lse_ref, "lse")
+    # the general kernel on the same call (no workspace offered): same rows to the io tolerance
+    orig_ws = fi._workspace
+    fi._workspace = lambda nbytes, device: None
+    try:
+        out2, lse2, _ = _fa().flash_attn_varlen_func(q, kp, vp, cu_q, cu_k, Tq, max(lens_k), return_attn_probs=True, **kw)
+    finally:
+        fi._workspace = orig_ws
+    assert_close(f64(out2), o_ref, dt, "out (general kernel)")
+    assert_lse_close(f64(lse2), lse_ref, "lse (general kernel)")
+
+
 def test_config3_shape_properties():
     """BASELINE config 3: fp16 packed batch 64, seqlens in [64, 2048] (max forced to 2048), H32 D64,
     window (512, 0).  Full size via properties: window (512,0) == causal + window_left 512, and a few
