@@ -248,6 +248,39 @@ def config4(flash_attn, dev, kv_dtype):
             "frac_of_hbm_peak": round(nbytes / ms / 1e6 / PEAK_HBM_GBS, 4)}
 
 
+def serving_steps(flash_attn, dev):
+    """decode-step latencies outside config 4 (evented medians, microseconds): small batch (split-KV + the merge of the partials),
+    speculative tokens (row blocks), softcap, head dim 256, and the same step issued through the varlen op.  H 32/8, paged
+    256-token pages, 8192-token context, bf16 cache unless noted."""
+    out = {}
+    def run(name, B, Tq, Hq, Hk, D, ctx, varlen=False, **kw):
+        page, dt = 256, torch.bfloat16
+        nblk = B * ctx // page
+        kc = torch.randn(nblk, page, Hk, D, device=dev, dtype=dt); vc = torch.randn_like(kc)
+        bt = torch.randperm(nblk, device=dev).to(torch.int32).reshape(B, ctx // page)
+        lens = torch.full((B,), ctx - 64, dtype=torch.int32, device=dev)
+        q = torch.randn(B, Tq, Hq, D, device=dev, dtype=dt)
+        if varlen:
+            qv = q.reshape(B * Tq, Hq, D)
+            cu_q = torch.arange(B + 1, dtype=torch.int32, device=dev) * Tq
+            cu_k = torch.cat([torch.zeros(1, dtype=torch.int32, device=dev), lens.cumsum(0).to(torch.int32)])
+            fn = lambda: flash_attn.flash_attn_varlen_func(qv, kc, vc, cu_q, cu_k, Tq, ctx, causal=True, block_table=bt, seqused_k=lens)
+        else:
+            fn = lambda: flash_attn.flash_attn_with_kvcache(q, kc, vc, cache_seqlens=lens, block_table=bt, causal=kw.get("softcap", 0.0) == 0.0, **kw)
+        ts = event_times_ms(fn, 20, warm=4)
+        out[name] = round(sorted(ts)[len(ts) // 2] * 1e3, 1)
+    run("decode_B1_us", 1, 1, 32, 8, 128, 8192)
+    run("decode_B8_us", 8, 1, 32, 8, 128, 8192)
+    run("decode_B1_ctx32k_us", 1, 1, 32, 8, 128, 32768)
+    run("spec_decode_B8_Tq8_us", 8, 8, 32, 8, 128, 8192)
+    run("spec_decode_B8_Tq16_us", 8, 16, 32, 8, 128, 8192)
+    run("decode_B8_softcap_us", 8, 1, 32, 8, 128, 8192, softcap=50.0)
+    run("decode_B8_D256_us", 8, 1, 16, 8, 256, 8192)
+    run("decode_B8_via_varlen_op_us", 8, 1, 32, 8, 128, 8192, varlen=True)
+    out["workload"] = "decode step latency, H 32/8 (D256: 16/8), paged(256) bf16 cache, context 8192 unless named; medians of 20 evented calls"
+    return out
+
+
 def config5(flash_attn, dev, world, rank, iters=3, warm=2):
     """dense fwd bf16 causal + ALiBi, B64 S8192 D128, 32 heads sharded over `world` ranks (this rank's heads)"""
     from flash_attn_mi355.sharding import shard_alibi, shard_units
@@ -440,6 +473,7 @@ def main():
             oc["config4_fp8_kv"] = config4(flash_attn, dev, torch.float8_e4m3fn)
             torch.cuda.empty_cache()
             oc["config4_fp16_kv"] = config4(flash_attn, dev, torch.float16)
+            oc["serving_steps"] = serving_steps(flash_attn, dev)
             torch.cuda.empty_cache()
             if world == 1:
                 ms, fl, Bs, Hs = config5(flash_attn, dev, 8, 0)
