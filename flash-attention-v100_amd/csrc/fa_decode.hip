@@ -169,10 +169,12 @@ __global__ void __launch_bounds__(DEC_THREADS, 1) fa_decode_kernel(const DecArgs
     const uint8_t* kbase = reinterpret_cast<const uint8_t*>(p.k) + (int64_t)hk * p.k_head_stride * EB;
     const uint8_t* vbase = reinterpret_cast<const uint8_t*>(p.v) + (int64_t)hk * p.v_head_stride * EB;
     const int32_t* btab = PAGED ? p.block_table + (int64_t)b * p.block_table_batch_stride : nullptr;
-    // register sets = tiles in flight per wave.  An fp8 tile is half the bytes of a 16-bit one, and
-    // with two sets the CU had only 64 KiB in flight (3.0 TB/s, latency-bound): fp8 uses four.
+    // register sets = tiles in flight per wave.  Round 1 gave fp8 caches four (an fp8 tile is half the bytes; with two the
+    // kernel of that time ran at 3.0 TB/s); since the one-row-per-head shapes moved to the token-major kernel what runs
+    // here (GQA groups of 8+, multi-token blocks) is bound by its ~540 instructions per tile, not by the bytes in flight:
+    // two sets are 8-15 % faster than four, six change nothing, eight spill (tools/decode_splits_sweep.py, round 3).
 #ifndef FA_DEC_NS8
-#define FA_DEC_NS8 4
+#define FA_DEC_NS8 2
 #endif
 #ifndef FA_DEC_NS16
 #define FA_DEC_NS16 2
