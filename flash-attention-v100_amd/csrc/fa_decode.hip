@@ -116,6 +116,18 @@ __global__ void __launch_bounds__(DEC_THREADS, 1) fa_decode_kernel(const DecArgs
     int lo = 0, hi = seqlen_k - 1;
     if (wr >= 0) { const int h2 = t_row + off + wr; hi = h2 < hi ? h2 : hi; }
     if (wl >= 0) { const int l2 = t_row + off - wl; lo = l2 > lo ? l2 : lo; }
+    // wave-uniform bounds for mask elision: a tile inside [max lo, min hi] of the wave's valid rows needs no per-element
+    // compare / select (64 of the ~540 instructions of a tile step); rows past R see unmasked garbage that is never stored
+    int w_lo_max = row_ok ? lo : 0, w_hi_min = row_ok ? hi : 0x7fffffff;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const int a2 = __shfl_xor(w_lo_max, o), b2 = __shfl_xor(w_hi_min, o);
+        w_lo_max = a2 > w_lo_max ? a2 : w_lo_max;
+        w_hi_min = b2 < w_hi_min ? b2 : w_hi_min;
+    }
+    w_lo_max = __builtin_amdgcn_readfirstlane(w_lo_max);
+    w_hi_min = __builtin_amdgcn_readfirstlane(w_hi_min);
+    const bool any_row = __builtin_amdgcn_readfirstlane((int)(__ballot(row_ok) != 0ull));
     if (!row_ok) { lo = 0x7fffffff; hi = -1; }
 
     // NARROW: rows of head_dim_v (< D, a multiple of 8) valid columns in a D-wide kernel (D = 96 on the 128 width ...):
@@ -316,10 +328,16 @@ __global__ void __launch_bounds__(DEC_THREADS, 1) fa_decode_kernel(const DecArgs
                 s[i] = x * kLog2e;
             }
         }
+        if (n0 < w_lo_max || n0 + BN - 1 > w_hi_min || !any_row) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int j = n0 + (i & 3) + 8 * (i >> 2) + 4 * g;
-            if (j < lo || j > hi || (BN == 16 && i >= 8)) s[i] = -INFINITY;      // (16-key tiles: key rows 16..31 are not there)
+            for (int i = 0; i < 16; ++i) {
+                const int j = n0 + (i & 3) + 8 * (i >> 2) + 4 * g;
+                if (j < lo || j > hi) s[i] = -INFINITY;
+            }
+        }
+        if (BN == 16) {                                     // (16-key tiles: key rows 16..31 are not there)
+#pragma unroll
+            for (int i = 8; i < 16; ++i) s[i] = -INFINITY;
         }
         float mx = s[0];
 #pragma unroll
