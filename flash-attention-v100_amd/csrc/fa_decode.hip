@@ -20,6 +20,17 @@
 
 namespace fa {
 
+#ifdef FA_DEC_NO_SADDR              // A/B switches of the round-3 addressing changes (tools/define_variant.py)
+#define FA_DEC_PIN(o)
+#else
+#define FA_DEC_PIN(o) asm volatile("" : "+v"(o))
+#endif
+#ifdef FA_DEC_NO_SPAGE
+#define FA_DEC_UNIFORM(x) (x)
+#else
+#define FA_DEC_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
+#endif
+
 constexpr int DEC_THREADS = 256;
 constexpr int DEC_BN = 32;                     // keys per wave tile
 constexpr float DEC_RESCALE_THR = 8.0f;        // log2 units
@@ -220,7 +231,9 @@ __global__ void __launch_bounds__(DEC_THREADS, 1) fa_decode_kernel(const DecArgs
         if (PAGED) {
             const int pg = da.page_shift >= 0 ? (pos0 >> da.page_shift) : pos0 / p.page_block_size;
             const int pr = pos0 - pg * p.page_block_size;
-            const int64_t phys = btab[pg];
+            // the page id is the same in every lane: in an SGPR the tile's base is scalar arithmetic and the eight loads
+            // take the base from SGPRs (as a vector value it cost six 32-bit multiplies and a 64-bit add per load and tile)
+            const int64_t phys = FA_DEC_UNIFORM(btab[pg]);
             ko = phys * p.k_batch_stride + (int64_t)pr * p.k_row_stride;
             vo = phys * p.v_batch_stride + (int64_t)pr * p.v_row_stride;
         } else {
@@ -229,10 +242,12 @@ __global__ void __launch_bounds__(DEC_THREADS, 1) fa_decode_kernel(const DecArgs
         }
         const uint8_t* kb = kbase + ko * EB;
         const uint8_t* vb = vbase + vo * EB;
+        // (the empty asm keeps the zero-extension of the 32-bit lane offset next to the load: hoisted out of the loop as a
+        //  64-bit pair it cost a v_lshl_add_u64 per load and 16 registers; here the load takes SGPR base + 32-bit VGPR offset)
 #pragma unroll
-        for (int i = 0; i < CH; ++i) kreg[i] = *reinterpret_cast<const u32x4*>(kb + k_voff[i]);
+        for (int i = 0; i < CH; ++i) { uint32_t o = k_voff[i]; FA_DEC_PIN(o); kreg[i] = *reinterpret_cast<const u32x4*>(kb + o); }
 #pragma unroll
-        for (int i = 0; i < CH; ++i) vreg[i] = *reinterpret_cast<const u32x4*>(vb + v_voff[i]);
+        for (int i = 0; i < CH; ++i) { uint32_t o = v_voff[i]; FA_DEC_PIN(o); vreg[i] = *reinterpret_cast<const u32x4*>(vb + o); }
     };
     (void)cok; (void)zero4;
     auto load_tile = [&](int tile, u32x4 (&kreg)[CH], u32x4 (&vreg)[CH]) {
