@@ -6,9 +6,10 @@
 // so this kernel is organised around bytes, not FLOPs:
 //   * one workgroup per (batch, KV-head, split): the T_q x G query rows that share a kv-head are
 //     packed into ONE 32-row MFMA tile, so the KV stream is read once per kv-head (GQA packing);
-//   * the 4 waves of the workgroup take alternate 32-key tiles of the split's key range (no
-//     barrier in the loop: every wave stages ITS tiles through a private, double-buffered LDS
-//     region with fully coalesced 16-byte loads), then merge (m, l, O) through LDS once;
+//   * the waves of the workgroup - eight, two per SIMD, for head dims up to 128 (one LDS stage and one register set
+//     each, Q fragments shared in LDS); four for D = 256 - take alternate 32-key tiles of the split's key range (no
+//     barrier in the loop: every wave stages ITS tiles through a private LDS region with fully coalesced 16-byte
+//     loads), then merge (m, l, O) through LDS once;
 //   * optional num_splits > 1 writes normalised partial O + LSE; decode_combine_kernel merges;
 //   * paged KV (block_table), cache_batch_idx, cache_leftpad, in-kernel RoPE on Q, causal /
 //     window masks, and fp8-e4m3 K/V (dequantised while staging; k_descale folds into the softmax
@@ -35,17 +36,19 @@ constexpr int DEC_THREADS = 256;
 constexpr int DEC_BN = 32;                     // keys per wave tile
 constexpr float DEC_RESCALE_THR = 8.0f;        // log2 units
 
-template <int D> struct DecSmem {
+template <int D, int NW = 4> struct DecSmem {
     // D = 256: 16-key tiles (the same 8 KiB per tile and the same staging registers as 32 keys at D = 128); the S^T MFMA
     // still spans 32 key rows - the upper 16 are masked - and P V takes one 16-key k-step
     static constexpr int BN = D > 128 ? 16 : DEC_BN;
     static constexpr int TILE = BN * D * 2;                // one 16-bit K (or V) tile
-    static constexpr int WAVE = 4 * TILE;                  // 2 stages x (K + V), private per wave
-    static constexpr int MERGE = 2 * 4 * 32 * 4 + 4 * 32 * D * 4;     // the 4 waves' (m, l, O) at the end
-    // D = 256: the Q fragments (the same for the four waves: 16 k-steps x 64 lanes x 16 B) live in LDS behind the waves'
-    // tiles instead of 64 registers per lane
-    static constexpr int QOFF = 4 * WAVE;
-    static constexpr int QBYTES = D > 128 ? (D / 16) * 64 * 16 : 0;
+    // four waves (one per SIMD): two LDS stages per wave; eight waves (two per SIMD, 256 registers each): one stage
+    static constexpr int STAGES = NW == 8 ? 1 : 2;
+    static constexpr int WAVE = STAGES * 2 * TILE;         // stages x (K + V), private per wave
+    static constexpr int MERGE = 2 * NW * 32 * 4 + NW * 32 * D * 4;   // the waves' (m, l, O) at the end
+    // D = 256 and the eight-wave form: the Q fragments (the same for all waves: D / 16 k-steps x 64 lanes x 16 B) live in
+    // LDS behind the waves' tiles instead of D / 4 registers per lane
+    static constexpr int QOFF = NW * WAVE;
+    static constexpr int QBYTES = (D > 128 || NW == 8) ? (D / 16) * 64 * 16 : 0;
     static constexpr int TOTAL = QOFF + QBYTES > MERGE ? QOFF + QBYTES : MERGE;
 };
 
@@ -75,15 +78,15 @@ struct DecArgs {
     float* lse_partial;        // [n_splits, B, Hq, T_q]
 };
 
-template <typename T, int D, bool KV8, bool PAGED, bool NARROW = false>
-__global__ void __launch_bounds__(DEC_THREADS, 1) fa_decode_kernel(const DecArgs da) {
+template <typename T, int D, bool KV8, bool PAGED, bool NARROW = false, int NW = 4>
+__global__ void __launch_bounds__(64 * NW, 1) fa_decode_kernel(const DecArgs da) {
     using E = Elem<T>;
     constexpr int KSTEPS = D / 16;
     constexpr int DBLKS = D / 32;
-    constexpr int TILE = DecSmem<D>::TILE;
+    constexpr int TILE = DecSmem<D, NW>::TILE;
     constexpr int EB = KV8 ? 1 : 2;                         // bytes per cache element
     constexpr int CPR = D * EB / 16;                        // 16-byte chunks per cache row
-    constexpr int BN = DecSmem<D>::BN;                      // keys per wave tile
+    constexpr int BN = DecSmem<D, NW>::BN;                      // keys per wave tile
     constexpr int CH = BN * CPR / 64;                       // chunks per lane per tile
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -106,7 +109,7 @@ __global__ void __launch_bounds__(DEC_THREADS, 1) fa_decode_kernel(const DecArgs
     const int b = unit / p.nheads_k, hk = unit - b * p.nheads_k;
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, g = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    char* wsm = smem + wave * DecSmem<D>::WAVE;
+    char* wsm = smem + wave * DecSmem<D, NW>::WAVE;
 
     const int L = dec_cache_len(p, b);
     const int lp = p.cache_leftpad ? p.cache_leftpad[b] : 0;
@@ -145,7 +148,7 @@ __global__ void __launch_bounds__(DEC_THREADS, 1) fa_decode_kernel(const DecArgs
     // the missing columns are zeros in Q and in the LDS tiles, and are not written
     const int vcols = NARROW ? p.head_dim_v : D;
     // ---- Q fragments (B operand), RoPE applied in registers ----
-    constexpr bool Q_LDS = DecSmem<D>::QBYTES > 0;
+    constexpr bool Q_LDS = DecSmem<D, NW>::QBYTES > 0;
     u32x4 qf[Q_LDS ? 1 : KSTEPS];
     {
         const uint16_t* qrow = reinterpret_cast<const uint16_t*>(p.q) + (int64_t)b * p.q_batch_stride +
@@ -169,7 +172,7 @@ __global__ void __launch_bounds__(DEC_THREADS, 1) fa_decode_kernel(const DecArgs
                     rope_chunk<T>(x, xp, cosp, sinp, d_base, p.rotary_dim, p.rotary_interleaved != 0);
                 }
             }
-            if constexpr (Q_LDS) { if (wave == 0) lds_write_b128(smem + DecSmem<D>::QOFF + (ks * 64 + lane) * 16, x); }
+            if constexpr (Q_LDS) { if (wave == 0) lds_write_b128(smem + DecSmem<D, NW>::QOFF + (ks * 64 + lane) * 16, x); }
             else qf[ks] = x;
         }
     }
@@ -184,7 +187,7 @@ __global__ void __launch_bounds__(DEC_THREADS, 1) fa_decode_kernel(const DecArgs
     int tile_hi = (seqlen_k + BN - 1) / BN;
     if (wr >= 0) { const int kmax = t_last + off + wr; const int t2 = kmax < 0 ? 0 : kmax / BN + 1; tile_hi = t2 < tile_hi ? t2 : tile_hi; }
     const int n_all = tile_hi > tile_lo ? tile_hi - tile_lo : 0;
-    const int per_split = ((n_all + da.n_splits - 1) / da.n_splits + 3) & ~3;     // multiple of 4 waves
+    const int per_split = ((n_all + da.n_splits - 1) / da.n_splits + NW - 1) / NW * NW;     // multiple of the waves
     const int s_lo = tile_lo + split * per_split;
     int s_hi = s_lo + per_split; s_hi = s_hi < tile_hi ? s_hi : tile_hi;
 
@@ -205,7 +208,8 @@ __global__ void __launch_bounds__(DEC_THREADS, 1) fa_decode_kernel(const DecArgs
 #ifndef FA_DEC_NS256
 #define FA_DEC_NS256 1                 // D = 256: two sets spill (172-280 bytes of scratch per lane)
 #endif
-    constexpr int NS = D > 128 ? FA_DEC_NS256 : (KV8 ? FA_DEC_NS8 : FA_DEC_NS16);     // (D = 256: register budget)
+    constexpr int NS = (D > 128 || NW == 8) ? FA_DEC_NS256 : (KV8 ? FA_DEC_NS8 : FA_DEC_NS16);     // (D = 256, eight waves: register budget)
+    constexpr int STAGES = DecSmem<D, NW>::STAGES;
     u32x4 kS[NS][CH], vS[NS][CH];
     // loop-invariant per-lane byte offsets inside a tile (row * row_stride + 16-byte column)
     uint32_t k_voff[CH], v_voff[CH];
@@ -331,7 +335,7 @@ __global__ void __launch_bounds__(DEC_THREADS, 1) fa_decode_kernel(const DecArgs
 #pragma unroll
         for (int ksx = 0; ksx < KSTEPS; ++ksx) {
             const u32x4 kf = lds_read_b128(ks + swz_row_off<D>(l31, 32 * ksx + 16 * g));
-            if constexpr (Q_LDS) s = E::mfma(kf, lds_read_b128(smem + DecSmem<D>::QOFF + (ksx * 64 + lane) * 16), s);
+            if constexpr (Q_LDS) s = E::mfma(kf, lds_read_b128(smem + DecSmem<D, NW>::QOFF + (ksx * 64 + lane) * 16), s);
             else s = E::mfma(kf, qf[ksx], s);
         }
         if (bias) {
@@ -393,38 +397,72 @@ __global__ void __launch_bounds__(DEC_THREADS, 1) fa_decode_kernel(const DecArgs
         }
     };
 
+    const int t0 = s_lo + wave;
+    const int n_my = t0 < s_hi ? (s_hi - t0 + NW - 1) / NW : 0;
+    if constexpr (STAGES == 1) {
+        // eight waves: one LDS stage per wave.  Step s: the set that holds tile s goes to LDS (waits for its loads), the
+        // set is re-loaded with tile s + NS, tile s is computed - NS tiles in flight while it runs, and the SIMD's other
+        // wave fills the waits
+        const int n_full1 = t0 < s_hi ? ((seqlen_k / BN < s_hi ? seqlen_k / BN : s_hi) - t0 + NW - 1) / NW : 0;
+        int s1 = 0;
+        if (tiles_aligned && NS < n_full1) {
+#pragma unroll
+            for (int j = 0; j < NS; ++j) load_fast(t0 + NW * j, kS[j], vS[j]);
+            for (; s1 + 2 * NS <= n_full1; s1 += NS) {
+#pragma unroll
+                for (int j = 0; j < NS; ++j) {
+                    store_tile(0, kS[j], vS[j]);
+                    load_fast(t0 + NW * (s1 + j + NS), kS[j], vS[j]);
+                    compute_tile(t0 + NW * (s1 + j), 0);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NS; ++j)
+                if (j < n_my) load_tile(t0 + NW * j, kS[j], vS[j]);
+        }
+        for (; s1 < n_my; s1 += NS) {
+#pragma unroll
+            for (int j = 0; j < NS; ++j) {
+                const int ss = s1 + j;
+                if (ss < n_my) {
+                    store_tile(0, kS[j], vS[j]);
+                    if (ss + NS < n_my) load_tile(t0 + NW * (ss + NS), kS[j], vS[j]);
+                    compute_tile(t0 + NW * ss, 0);
+                }
+            }
+        }
+    } else {
     // LDS stage of step s0 + j: a compile-time constant for even NS (s0 is a multiple of NS)
     auto stage_of = [](int s0_, int j_) { return (NS % 2 == 0) ? (j_ & 1) : ((s0_ + j_) & 1); };
     // pipeline over this wave's tiles t0 + 4 s: LDS stage s & 1 holds tile s while the register sets
     // hold tiles s+1 .. s+NS-1 (landed / landing) and the set just stored is re-loaded with s+1+NS.
-    const int t0 = s_lo + wave;
-    const int n_my = t0 < s_hi ? (s_hi - t0 + 3) / 4 : 0;
     // my tiles that lie completely inside [0, seqlen_k): s < n_full
-    const int n_full = t0 < s_hi ? ((seqlen_k / BN < s_hi ? seqlen_k / BN : s_hi) - t0 + 3) / 4 : 0;
+    const int n_full = t0 < s_hi ? ((seqlen_k / BN < s_hi ? seqlen_k / BN : s_hi) - t0 + NW - 1) / NW : 0;
     int s0 = 0;
     if (tiles_aligned && 2 * NS < n_full) {
         // steady state: every store / load is unconditional, so the vmcnt waits in front of the
         // stores are exact counts (NS - 1 tiles stay in flight) instead of conservative drains
 #pragma unroll
-        for (int j = 0; j < NS; ++j) load_fast(t0 + 4 * j, kS[j], vS[j]);
+        for (int j = 0; j < NS; ++j) load_fast(t0 + NW * j, kS[j], vS[j]);
         store_tile(0, kS[0], vS[0]);
-        load_fast(t0 + 4 * NS, kS[0], vS[0]);
+        load_fast(t0 + NW * NS, kS[0], vS[0]);
         for (; s0 + 2 * NS < n_full; s0 += NS) {
 #pragma unroll
             for (int j = 0; j < NS; ++j) {
                 const int nxt = (j + 1) % NS;
                 store_tile(stage_of(s0, j + 1), kS[nxt], vS[nxt]);
-                load_fast(t0 + 4 * (s0 + j + 1 + NS), kS[nxt], vS[nxt]);
-                compute_tile(t0 + 4 * (s0 + j), stage_of(s0, j));
+                load_fast(t0 + NW * (s0 + j + 1 + NS), kS[nxt], vS[nxt]);
+                compute_tile(t0 + NW * (s0 + j), stage_of(s0, j));
             }
         }
     } else {
 #pragma unroll
         for (int j = 0; j < NS; ++j)
-            if (j < n_my) load_tile(t0 + 4 * j, kS[j], vS[j]);
+            if (j < n_my) load_tile(t0 + NW * j, kS[j], vS[j]);
         if (n_my > 0) {
             store_tile(0, kS[0], vS[0]);
-            if (NS < n_my) load_tile(t0 + 4 * NS, kS[0], vS[0]);
+            if (NS < n_my) load_tile(t0 + NW * NS, kS[0], vS[0]);
         }
     }
     // remaining tiles (and short sequences): same schedule with every step guarded
@@ -435,18 +473,20 @@ __global__ void __launch_bounds__(DEC_THREADS, 1) fa_decode_kernel(const DecArgs
             if (ss < n_my) {
                 const int nxt = (j + 1) % NS;              // compile-time after unrolling
                 if (ss + 1 < n_my) store_tile(stage_of(s0, j + 1), kS[nxt], vS[nxt]);
-                if (ss + 1 + NS < n_my) load_tile(t0 + 4 * (ss + 1 + NS), kS[nxt], vS[nxt]);
-                compute_tile(t0 + 4 * ss, stage_of(s0, j));
+                if (ss + 1 + NS < n_my) load_tile(t0 + NW * (ss + 1 + NS), kS[nxt], vS[nxt]);
+                compute_tile(t0 + NW * ss, stage_of(s0, j));
             }
         }
+    }
+
     }
 
     // ---- merge the 4 waves through LDS ----
     __syncthreads();                                        // everyone is done with its tiles
     const float l_w = xhalf_sum(l_run);
     float* red_m = reinterpret_cast<float*>(smem);                       // [4][32]
-    float* red_l = red_m + 4 * 32;                                       // [4][32]
-    float* red_o = red_l + 4 * 32;                                       // [4][32 rows][D]
+    float* red_l = red_m + NW * 32;                                      // [NW][32]
+    float* red_o = red_l + NW * 32;                                      // [NW][32 rows][D]
     if (g == 0) { red_m[wave * 32 + l31] = m_run; red_l[wave * 32 + l31] = l_w; }
 #pragma unroll
     for (int d = 0; d < DBLKS; ++d)
@@ -458,18 +498,20 @@ __global__ void __launch_bounds__(DEC_THREADS, 1) fa_decode_kernel(const DecArgs
     __syncthreads();
     // thread -> (row = tid / 8, 16-column slice)
     {
-        const int row = tid >> 3;                           // 0..31
-        const int cs = (tid & 7) * (D / 8);                 // D/8 columns per thread
+        constexpr int TPR = 2 * NW;                         // threads per row (8 or 16)
+        constexpr int CPT = D / TPR;                        // columns per thread
+        const int row = tid / TPR;                          // 0..31
+        const int cs = (tid % TPR) * CPT;
         const int t3 = (rbase + row) / G, gq3 = (rbase + row) - t3 * G;
         if (rbase + row < R) {
-            float mw[4], lw[4];
+            float mw[NW], lw[NW];
             float m_all = -INFINITY;
 #pragma unroll
-            for (int w2 = 0; w2 < 4; ++w2) { mw[w2] = red_m[w2 * 32 + row]; lw[w2] = red_l[w2 * 32 + row]; m_all = fmaxf(m_all, mw[w2]); }
+            for (int w2 = 0; w2 < NW; ++w2) { mw[w2] = red_m[w2 * 32 + row]; lw[w2] = red_l[w2 * 32 + row]; m_all = fmaxf(m_all, mw[w2]); }
             const float m_s = (m_all == -INFINITY) ? 0.f : m_all;
-            float l_all = 0.f, sc[4];
+            float l_all = 0.f, sc[NW];
 #pragma unroll
-            for (int w2 = 0; w2 < 4; ++w2) { sc[w2] = fast_exp2(mw[w2] - m_s); l_all = fmaf(lw[w2], sc[w2], l_all); }
+            for (int w2 = 0; w2 < NW; ++w2) { sc[w2] = fast_exp2(mw[w2] - m_s); l_all = fmaf(lw[w2], sc[w2], l_all); }
             const float inv = l_all > 0.f ? (KV8 ? p.v_descale : 1.0f) / l_all : 0.f;
             const float lse = l_all > 0.f ? (m_all + fast_log2(l_all)) * kLn2 : -INFINITY;
             const int hq = hk * G + gq3;
@@ -477,29 +519,29 @@ __global__ void __launch_bounds__(DEC_THREADS, 1) fa_decode_kernel(const DecArgs
                 uint16_t* op = reinterpret_cast<uint16_t*>(p.o) + (int64_t)b * p.o_batch_stride + (int64_t)t3 * p.o_row_stride +
                                (int64_t)hq * p.o_head_stride + cs;
 #pragma unroll
-                for (int x = 0; x < D / 8; x += 2) {
+                for (int x = 0; x < CPT; x += 2) {
                     if (NARROW && cs + x >= vcols) break;
                     float v0 = 0.f, v1 = 0.f;
 #pragma unroll
-                    for (int w2 = 0; w2 < 4; ++w2) {
+                    for (int w2 = 0; w2 < NW; ++w2) {
                         v0 = fmaf(red_o[(w2 * 32 + row) * D + cs + x], sc[w2], v0);
                         v1 = fmaf(red_o[(w2 * 32 + row) * D + cs + x + 1], sc[w2], v1);
                     }
                     *reinterpret_cast<uint32_t*>(op + x) = E::pack2(v0 * inv, v1 * inv);
                 }
-                if ((tid & 7) == 0)
+                if (tid % TPR == 0)
                     p.lse[(int64_t)b * p.lse_batch_stride + (int64_t)hq * p.lse_head_stride + t3] = lse;
             } else {
                 const int64_t prow = (((int64_t)split * p.batch + b) * p.nheads_q + hq) * Tq + t3;
                 float* op = da.o_partial + prow * D + cs;
 #pragma unroll
-                for (int x = 0; x < D / 8; ++x) {
+                for (int x = 0; x < CPT; ++x) {
                     float v0 = 0.f;
 #pragma unroll
-                    for (int w2 = 0; w2 < 4; ++w2) v0 = fmaf(red_o[(w2 * 32 + row) * D + cs + x], sc[w2], v0);
+                    for (int w2 = 0; w2 < NW; ++w2) v0 = fmaf(red_o[(w2 * 32 + row) * D + cs + x], sc[w2], v0);
                     op[x] = v0 * inv;
                 }
-                if ((tid & 7) == 0) da.lse_partial[prow] = lse;
+                if (tid % TPR == 0) da.lse_partial[prow] = lse;
             }
         }
     }
@@ -1249,6 +1291,17 @@ size_t decode_split_workspace_bytes(const fa_params& p) {
     return (size_t)s * rows * (p.head_dim + 1) * sizeof(float);
 }
 
+// two waves per SIMD for the MFMA decode kernel?  (FA_DEC_NW = 4 / 8 forces it: A/B in tools/decode_splits_sweep.py)
+static bool decode_eight_waves(const fa_params& p) {
+    const char* e = getenv("FA_DEC_NW");
+    if (e && e[0] == '8') return true;
+    if (e && e[0] == '4') return false;
+    // head dims up to 128: the SIMD's second wave fills the first one's waits (LDS round trips, MFMA chains, loads) - 7-24 %
+    // faster on every shape measured (profiles/r03_decode_features.txt (5)); D = 256 keeps its 128 accumulator registers
+    // and four waves
+    return p.head_dim <= 128;
+}
+
 template <typename T, int D>
 static int launch_decode_td(DecArgs& da, hipStream_t stream) {
     const fa_params& p = da.a.p;
@@ -1258,7 +1311,6 @@ static int launch_decode_td(DecArgs& da, hipStream_t stream) {
     da.grid_splits = da.n_splits;
     dim3 grid(p.batch * p.nheads_k, da.n_splits, 1);
     if (da.n_rb > 1) grid = dim3((unsigned)(((p.batch * p.nheads_k * da.n_splits + 7) / 8) * 8 * da.n_rb), 1, 1);
-    const size_t smem = DecSmem<D>::TOTAL;
     if constexpr (D == 128) {
         // one query position, heads adjacent in the cache rows: the token-major streaming kernel (fp8 and 16-bit caches, GQA)
         if (gemv_tm_applicable(p)) {
@@ -1282,21 +1334,34 @@ static int launch_decode_td(DecArgs& da, hipStream_t stream) {
             return 0;
         }
     }
-#define FA_LAUNCH_DEC(KV8, PAGED, NARROW)                                                                           \
+#define FA_LAUNCH_DEC(KV8, PAGED, NARROW, NW_)                                                                      \
     do {                                                                                                            \
-        auto kern = fa_decode_kernel<T, D, KV8, PAGED, NARROW>;                                                     \
-        FA_SET_LDS_ONCE(kern, smem); \
-        hipLaunchKernelGGL(kern, grid, dim3(DEC_THREADS), smem, stream, da);                                        \
+        auto kern = fa_decode_kernel<T, D, KV8, PAGED, NARROW, NW_>;                                                \
+        const size_t smem_ = DecSmem<D, NW_>::TOTAL;                                                                \
+        FA_SET_LDS_ONCE(kern, smem_);                                                                               \
+        hipLaunchKernelGGL(kern, grid, dim3(64 * NW_), smem_, stream, da);                                          \
     } while (0)
     const bool narrow = p.head_dim_v != 0;
     if constexpr (D <= 128) {
-        if (kv8) { if (paged) FA_LAUNCH_DEC(true, true, false); else FA_LAUNCH_DEC(true, false, false); }
-        else if (!narrow) { if (paged) FA_LAUNCH_DEC(false, true, false); else FA_LAUNCH_DEC(false, false, false); }
+        // eight waves (two per SIMD, one LDS stage and 256 registers each) or four (one per SIMD, two stages)
+        const bool w8 = decode_eight_waves(p);
+        if (kv8) {
+            if (w8) { if (paged) FA_LAUNCH_DEC(true, true, false, 8); else FA_LAUNCH_DEC(true, false, false, 8); }
+            else    { if (paged) FA_LAUNCH_DEC(true, true, false, 4); else FA_LAUNCH_DEC(true, false, false, 4); }
+        } else if (!narrow) {
+            if (w8) { if (paged) FA_LAUNCH_DEC(false, true, false, 8); else FA_LAUNCH_DEC(false, false, false, 8); }
+            else    { if (paged) FA_LAUNCH_DEC(false, true, false, 4); else FA_LAUNCH_DEC(false, false, false, 4); }
+        }
     }
     if (!kv8 && (narrow || D > 128)) {
         // one instantiation serves full-width D = 256 rows and every narrow width (vcols is a run-time count there)
         if (D > 128 && !narrow) da.a.p.head_dim_v = D;
-        if (paged) FA_LAUNCH_DEC(false, true, true); else FA_LAUNCH_DEC(false, false, true);
+        if constexpr (D <= 128) {
+            if (decode_eight_waves(p)) { if (paged) FA_LAUNCH_DEC(false, true, true, 8); else FA_LAUNCH_DEC(false, false, true, 8); }
+            else                       { if (paged) FA_LAUNCH_DEC(false, true, true, 4); else FA_LAUNCH_DEC(false, false, true, 4); }
+        } else {
+            if (paged) FA_LAUNCH_DEC(false, true, true, 4); else FA_LAUNCH_DEC(false, false, true, 4);
+        }
     }
 #undef FA_LAUNCH_DEC
     if (da.n_splits > 1) launch_decode_combine<T>(da, stream);
