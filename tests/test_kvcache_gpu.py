@@ -400,6 +400,19 @@ def test_decode_head_dims_256_and_narrow(B, Tq, Hq, Hk, D, dt, paged, rot, softc
     assert_lse_close(f64(lse), lse_ref, "lse", **(dict(atol=2e-2) if rot else {}))
 
 
+@pytest.mark.parametrize("nw", ["4", "8"])
+def test_decode_kernel_wave_counts(nw, monkeypatch):
+    """FA_DEC_NW selects the MFMA decode kernel's form: eight waves per workgroup (two per SIMD, one LDS stage: the default up
+    to head dim 128) or four (one per SIMD, two stages) - both stay covered: a GQA-8 step, a multi-token fp8 step and a narrow
+    head dim, against the oracle."""
+    monkeypatch.setenv("FA_DEC_NW", nw)
+    test_multi_token_queries_on_decode_row_blocks(3, 5, 64, 8, 128, "bf16", True, True, (-1, -1), True, True)
+    test_multi_token_queries_on_decode_row_blocks(1, 32, 16, 2, 64, "fp16", False, True, (-1, -1), False, False)
+    test_fp8_cache_multi_token_queries(33, 4, 4, 128, True, True, (-1, -1), True)
+    test_decode_head_dims_256_and_narrow(2, 1, 12, 4, 96, "fp16", True, True, 0.0, 0)
+    test_decode_with_softcap_or_alibi(2, 1, 32, 8, 128, "fp16", False, True, 50.0, None, 0)
+
+
 def test_full_size_config4_decode_paged_rotary_fp8():
     """BASELINE config 4 at full size (B128, 32 heads, D128, cache_seqlen 8192, paged KV with a random
     block table, NeoX rotary, fp8-e4m3 KV), checked through size-independent properties:
