@@ -220,7 +220,6 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : FA_FWD_OCC)) fa_fw
     // XOR swizzle places there (the swizzle is an involution).
     // Paged K/V: one page lookup per row -> global_load to registers, ds_write after the MFMAs.
     constexpr int ROWS_PI = 64 / CPR;
-    u32x4 kreg[PAGED ? CHUNKS : 1], vreg[PAGED ? CHUNKS : 1];
     constexpr int CPR8 = D / 16;                                        // 16-byte chunks (16 codes) per fp8 row
     constexpr int CH8 = FWD_BN * CPR8 / FWD_THREADS;                    // fp8 chunks per thread and tile
     u32x4 k8reg[KV8 ? CH8 : 1], v8reg[KV8 ? CH8 : 1];
@@ -228,46 +227,42 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : FA_FWD_OCC)) fa_fw
     int k_lds[CHUNKS], v_lds[CHUNKS];
 #pragma unroll
     for (int i = 0; i < CHUNKS; ++i) {
-        if (PAGED) {
-            const int c = tid + i * FWD_THREADS;
-            const int row = c / CPR, cc = c % CPR;
-            k_voff[i] = 0; v_voff[i] = 0;
-            k_lds[i] = swz_row_off<D>(row, cc * 16);
-            v_lds[i] = TILE + swzt_row_off<D>(row, cc * 16);
-        } else {
-            const int inst = wave * CHUNKS + i;
-            const int row = inst * ROWS_PI + lane / CPR;
-            const int slot = lane % CPR;
-            const int k_cb = swz_row_off<D>(row, slot * 16) - row * D * 2;      // logical byte column
-            const int v_cb = swzt_row_off<D>(row, slot * 16) - row * D * 2;
-            k_voff[i] = k_cb < dv * 2 ? (uint32_t)(row * p.k_row_stride * 2 + k_cb) : kOobVoff;
-            v_voff[i] = v_cb < dv * 2 ? (uint32_t)(row * p.v_row_stride * 2 + v_cb) : kOobVoff;
-            k_lds[i] = inst * 1024;                                             // wave-uniform destination
-            v_lds[i] = TILE + inst * 1024;
-        }
+        // LDS-DMA lane map (contiguous tiles, and paged tiles through a per-tile descriptor): lane-linear destination,
+        // swizzle applied to the source column
+        const int inst = wave * CHUNKS + i;
+        const int row = inst * ROWS_PI + lane / CPR;
+        const int slot = lane % CPR;
+        const int k_cb = swz_row_off<D>(row, slot * 16) - row * D * 2;      // logical byte column
+        const int v_cb = swzt_row_off<D>(row, slot * 16) - row * D * 2;
+        k_voff[i] = k_cb < dv * 2 ? (uint32_t)(row * p.k_row_stride * 2 + k_cb) : kOobVoff;
+        v_voff[i] = v_cb < dv * 2 ? (uint32_t)(row * p.v_row_stride * 2 + v_cb) : kOobVoff;
+        k_lds[i] = inst * 1024;                                             // wave-uniform destination
+        v_lds[i] = TILE + inst * 1024;
     }
     // Paged K/V, aligned case (a 64-key tile never straddles a page: page % 64 == 0 by contract and the left
     // pad is a multiple of 64): the same LDS-DMA as the contiguous path through a per-tile descriptor built
-    // from ONE block-table lookup; otherwise the per-row register path.
+    // from ONE block-table lookup; otherwise the per-row path in store_tile.
     const bool paged_dma = PAGED && !KV8 && (k_row0 % FWD_BN == 0) && (p.page_block_size % FWD_BN == 0);
-    uint32_t pk_voff[PAGED ? CHUNKS : 1], pv_voff[PAGED ? CHUNKS : 1];
-    if (PAGED) {
-#pragma unroll
-        for (int i = 0; i < CHUNKS; ++i) {
-            const int inst = wave * CHUNKS + i;
-            const int row = inst * ROWS_PI + lane / CPR;
-            const int slot = lane % CPR;
-            const int k_cb = swz_row_off<D>(row, slot * 16) - row * D * 2;
-            const int v_cb = swzt_row_off<D>(row, slot * 16) - row * D * 2;
-            pk_voff[i] = k_cb < dv * 2 ? (uint32_t)(row * p.k_row_stride * 2 + k_cb) : kOobVoff;
-            pv_voff[i] = v_cb < dv * 2 ? (uint32_t)(row * p.v_row_stride * 2 + v_cb) : kOobVoff;
-        }
-    }
     const __amdgpu_buffer_rsrc_t k_rsrc = make_rsrc(kp, p.k_row_stride, PAGED ? 0 : seqlen_k, dv);
     const __amdgpu_buffer_rsrc_t v_rsrc = make_rsrc(vp, p.v_row_stride, PAGED ? 0 : seqlen_k, dv);
     const uint32_t k_tile_bytes = (uint32_t)(FWD_BN * p.k_row_stride * 2);
     const uint32_t v_tile_bytes = (uint32_t)(FWD_BN * p.v_row_stride * 2);
 
+    int page_shift = -1;
+    if (PAGED && (p.page_block_size & (p.page_block_size - 1)) == 0) page_shift = __builtin_ctz(p.page_block_size);
+    // paged_dma: block-table entry of the next tile to load, requested one tile ahead through the CONSTANT address space:
+    // a uniform constant load is a scalar load (s_load_dword) whose wait the compiler places at the first use.  As a plain
+    // C++ load it became a vector load + v_readfirstlane with an `s_waitcnt vmcnt(0)` right behind it - i.e. behind the
+    // eight LDS-DMA loads just issued, so every tile's compute started only after the next tile had landed (chunked
+    // prefill over a paged cache at 0.65 x a contiguous one, tools/chunked_prefill_probe.py).  The kernel never writes
+    // the block table.
+    typedef const int32_t __attribute__((address_space(4))) * const_i32_ptr;
+    const const_i32_ptr btab_c = (const_i32_ptr)(uintptr_t)btab;
+    int pf_phys = 0;
+    auto pf_request = [&](int nb1) {
+        const int pos1 = nb1 * FWD_BN + (int)k_row0;
+        pf_phys = btab_c[page_shift >= 0 ? (pos1 >> page_shift) : pos1 / p.page_block_size];
+    };
     // issue the loads of tile nb; for the DMA path they land directly in LDS stage `stage`
     auto load_tile = [&](int nb, auto stage_c) {
         constexpr int stage = decltype(stage_c)::value;
@@ -299,36 +294,24 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : FA_FWD_OCC)) fa_fw
         if (PAGED && paged_dma) {
             const int n0 = nb * FWD_BN;
             const int pos0 = n0 + (int)k_row0;
-            const int pg = pos0 / p.page_block_size;
+            const int pg = page_shift >= 0 ? (pos0 >> page_shift) : pos0 / p.page_block_size;
             const int pr = pos0 - pg * p.page_block_size;
-            const int64_t phys = btab[pg];
+            // the block-table entry of THIS tile was looked up one tile ago (pf_phys): with the lookup at the top of the
+            // step its round trip sat in front of every tile's DMA issue (chunked prefill over a paged cache ran 12-33 %
+            // behind a contiguous one: tools/chunked_prefill_probe.py); the entry of the next tile is requested below
+            const int64_t phys = pf_phys;
             int rows = seqlen_k - n0;
             rows = rows < 0 ? 0 : (rows > FWD_BN ? FWD_BN : rows);
             const __amdgpu_buffer_rsrc_t kr = make_rsrc(kp + phys * p.k_batch_stride + (int64_t)pr * p.k_row_stride, p.k_row_stride, rows, dv);
             const __amdgpu_buffer_rsrc_t vr = make_rsrc(vp + phys * p.v_batch_stride + (int64_t)pr * p.v_row_stride, p.v_row_stride, rows, dv);
             char* base = smem + stage * STAGE;
 #pragma unroll
-            for (int i = 0; i < CHUNKS; ++i) buf_load_lds_b128(kr, base + (wave * CHUNKS + i) * 1024, pk_voff[i], 0);
+            for (int i = 0; i < CHUNKS; ++i) buf_load_lds_b128(kr, base + k_lds[i], k_voff[i], 0);
 #pragma unroll
-            for (int i = 0; i < CHUNKS; ++i) buf_load_lds_b128(vr, base + TILE + (wave * CHUNKS + i) * 1024, pv_voff[i], 0);
+            for (int i = 0; i < CHUNKS; ++i) buf_load_lds_b128(vr, base + v_lds[i], v_voff[i], 0);
+            pf_request(nb + 1 < n_max ? nb + 1 : nb);                         // (the tiles of a pass are walked upwards)
         } else if (PAGED) {
-            const int n0 = nb * FWD_BN;
-#pragma unroll
-            for (int i = 0; i < CHUNKS; ++i) {
-                const int c = tid + i * FWD_THREADS;
-                const int row = c / CPR, cc = c % CPR;
-                const int j = n0 + row;
-                u32x4 z = {0, 0, 0, 0};
-                kreg[i] = z; vreg[i] = z;
-                if (j < seqlen_k && cc * 8 < dv) {
-                    const int pos = j + (int)k_row0;
-                    const int pg = pos / p.page_block_size;
-                    const int pr = pos - pg * p.page_block_size;
-                    const int64_t phys = btab[pg];
-                    kreg[i] = *reinterpret_cast<const u32x4*>(kp + phys * p.k_batch_stride + (int64_t)pr * p.k_row_stride + cc * 8);
-                    vreg[i] = *reinterpret_cast<const u32x4*>(vp + phys * p.v_batch_stride + (int64_t)pr * p.v_row_stride + cc * 8);
-                }
-            }
+            // unaligned paged tiles (a left pad that is not a multiple of the tile): fetched row by row in store_tile
         } else {
             char* base = smem + stage * STAGE;
             const uint32_t ks_off = (uint32_t)nb * k_tile_bytes;
@@ -339,7 +322,7 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : FA_FWD_OCC)) fa_fw
             for (int i = 0; i < CHUNKS; ++i) buf_load_lds_b128(v_rsrc, base + v_lds[i], v_voff[i], vs_off);
         }
     };
-    auto store_tile = [&](auto stage_c) {
+    auto store_tile = [&](auto stage_c, int nb) {
         constexpr int stage = decltype(stage_c)::value;
         if constexpr (KV8) {
             char* base = smem + stage * STAGE;
@@ -358,11 +341,27 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : FA_FWD_OCC)) fa_fw
             return;
         }
         if (PAGED && !paged_dma) {
+            // rare (a tile may straddle pages): per-row lookup, load and LDS write back to back - nothing stays in
+            // registers across the tile's compute (as loop-carried register arrays these 64 registers spilled the
+            // ALIGNED path's loop: 60 scratch instructions, chunked prefill over a paged cache at 2/3 of a contiguous one)
             char* base = smem + stage * STAGE;
+            const int n0 = nb * FWD_BN;
 #pragma unroll
             for (int i = 0; i < CHUNKS; ++i) {
-                lds_write_b128(base + k_lds[i], kreg[i]);
-                lds_write_b128(base + v_lds[i], vreg[i]);
+                const int c = tid + i * FWD_THREADS;
+                const int row = c / CPR, cc = c % CPR;
+                const int j = n0 + row;
+                u32x4 kx = {0, 0, 0, 0}, vx = {0, 0, 0, 0};
+                if (j < seqlen_k && cc * 8 < dv) {
+                    const int pos = j + (int)k_row0;
+                    const int pg = pos / p.page_block_size;
+                    const int pr = pos - pg * p.page_block_size;
+                    const int64_t phys = btab[pg];
+                    kx = *reinterpret_cast<const u32x4*>(kp + phys * p.k_batch_stride + (int64_t)pr * p.k_row_stride + cc * 8);
+                    vx = *reinterpret_cast<const u32x4*>(vp + phys * p.v_batch_stride + (int64_t)pr * p.v_row_stride + cc * 8);
+                }
+                lds_write_b128(base + swz_row_off<D>(row, cc * 16), kx);
+                lds_write_b128(base + TILE + swzt_row_off<D>(row, cc * 16), vx);
             }
         }
     };
@@ -649,13 +648,14 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : FA_FWD_OCC)) fa_fw
 #ifndef FA_FWD_KO_COMPUTE        // timing knock-out: loads and barriers only
         if (wave_active) compute_tile(stage_c, nb);
 #endif
-        if (has_next) store_tile(std::integral_constant<int, stage ^ 1>{});
+        if (has_next) store_tile(std::integral_constant<int, stage ^ 1>{}, nb + 1);
         __syncthreads();
     };
 
     if (n_min < n_max) {
+        if (PAGED && paged_dma) pf_request(n_min);
         load_tile(n_min, std::integral_constant<int, 0>{});
-        store_tile(std::integral_constant<int, 0>{});
+        store_tile(std::integral_constant<int, 0>{}, n_min);
     }
     __syncthreads();
 
