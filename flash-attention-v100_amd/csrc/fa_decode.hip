@@ -26,11 +26,7 @@ namespace fa {
 #else
 #define FA_DEC_PIN(o) asm volatile("" : "+v"(o))
 #endif
-#ifdef FA_DEC_NO_SPAGE
 #define FA_DEC_UNIFORM(x) (x)
-#else
-#define FA_DEC_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
-#endif
 
 constexpr int DEC_THREADS = 256;
 constexpr int DEC_BN = 32;                     // keys per wave tile
@@ -195,6 +191,10 @@ __global__ void __launch_bounds__(64 * NW, 1) fa_decode_kernel(const DecArgs da)
     const uint8_t* kbase = reinterpret_cast<const uint8_t*>(p.k) + (int64_t)hk * p.k_head_stride * EB;
     const uint8_t* vbase = reinterpret_cast<const uint8_t*>(p.v) + (int64_t)hk * p.v_head_stride * EB;
     const int32_t* btab = PAGED ? p.block_table + (int64_t)b * p.block_table_batch_stride : nullptr;
+    // the same table through the constant address space: a uniform load from it is a scalar load (s_load_dword, waited for
+    // with lgkmcnt at its use); a plain load was a vector load whose `s_waitcnt vmcnt(0)` drained the tiles in flight
+    typedef const int32_t __attribute__((address_space(4))) * const_i32_ptr;
+    const const_i32_ptr btab_c = (const_i32_ptr)(uintptr_t)btab;
     // register sets = tiles in flight per wave.  Round 1 gave fp8 caches four (an fp8 tile is half the bytes; with two the
     // kernel of that time ran at 3.0 TB/s); since the one-row-per-head shapes moved to the token-major kernel what runs
     // here (GQA groups of 8+, multi-token blocks) is bound by its ~540 instructions per tile, not by the bytes in flight:
@@ -237,7 +237,7 @@ __global__ void __launch_bounds__(64 * NW, 1) fa_decode_kernel(const DecArgs da)
             const int pr = pos0 - pg * p.page_block_size;
             // the page id is the same in every lane: in an SGPR the tile's base is scalar arithmetic and the eight loads
             // take the base from SGPRs (as a vector value it cost six 32-bit multiplies and a 64-bit add per load and tile)
-            const int64_t phys = FA_DEC_UNIFORM(btab[pg]);
+            const int64_t phys = FA_DEC_UNIFORM(btab_c[pg]);
             ko = phys * p.k_batch_stride + (int64_t)pr * p.k_row_stride;
             vo = phys * p.v_batch_stride + (int64_t)pr * p.v_row_stride;
         } else {
