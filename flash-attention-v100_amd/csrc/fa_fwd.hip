@@ -242,7 +242,8 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : FA_FWD_OCC)) fa_fw
     // Paged K/V, aligned case (a 64-key tile never straddles a page: page % 64 == 0 by contract and the left
     // pad is a multiple of 64): the same LDS-DMA as the contiguous path through a per-tile descriptor built
     // from ONE block-table lookup; otherwise the per-row path in store_tile.
-    const bool paged_dma = PAGED && !KV8 && (k_row0 % FWD_BN == 0) && (p.page_block_size % FWD_BN == 0);
+    const bool paged_aligned = PAGED && (k_row0 % FWD_BN == 0) && (p.page_block_size % FWD_BN == 0);
+    const bool paged_dma = paged_aligned && !KV8;
     const __amdgpu_buffer_rsrc_t k_rsrc = make_rsrc(kp, p.k_row_stride, PAGED ? 0 : seqlen_k, dv);
     const __amdgpu_buffer_rsrc_t v_rsrc = make_rsrc(vp, p.v_row_stride, PAGED ? 0 : seqlen_k, dv);
     const uint32_t k_tile_bytes = (uint32_t)(FWD_BN * p.k_row_stride * 2);
@@ -268,6 +269,28 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : FA_FWD_OCC)) fa_fw
         constexpr int stage = decltype(stage_c)::value;
         if constexpr (KV8) {
             const int n0 = nb * FWD_BN;
+            if (PAGED && paged_aligned) {
+                // aligned tiles lie inside one page: ONE entry, requested one tile ago (scalar), no per-lane lookups in
+                // front of the loads
+                const int pos0 = n0 + (int)k_row0;
+                const int pg0 = page_shift >= 0 ? (pos0 >> page_shift) : pos0 / p.page_block_size;
+                const int64_t phys = pf_phys;
+                const uint8_t* kpg = kp8 + phys * p.k_batch_stride + (int64_t)(pos0 - pg0 * p.page_block_size) * p.k_row_stride;
+                const uint8_t* vpg = vp8 + phys * p.v_batch_stride + (int64_t)(pos0 - pg0 * p.page_block_size) * p.v_row_stride;
+#pragma unroll
+                for (int i = 0; i < CH8; ++i) {
+                    const int c8 = tid + i * FWD_THREADS;
+                    const int row = c8 / CPR8, cc8 = c8 % CPR8;
+                    u32x4 z = {0, 0, 0, 0};
+                    k8reg[i] = z; v8reg[i] = z;
+                    if (n0 + row < seqlen_k && cc8 * 16 < dv) {
+                        k8reg[i] = *reinterpret_cast<const u32x4*>(kpg + (int64_t)row * p.k_row_stride + cc8 * 16);
+                        v8reg[i] = *reinterpret_cast<const u32x4*>(vpg + (int64_t)row * p.v_row_stride + cc8 * 16);
+                    }
+                }
+                pf_request(nb + 1 < n_max ? nb + 1 : nb);
+                return;
+            }
 #pragma unroll
             for (int i = 0; i < CH8; ++i) {
                 const int c8 = tid + i * FWD_THREADS;
@@ -278,7 +301,7 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : FA_FWD_OCC)) fa_fw
                 if (j < seqlen_k && cc8 * 16 < dv) {
                     if (PAGED) {
                         const int pos = j + (int)k_row0;
-                        const int pg = pos / p.page_block_size;
+                        const int pg = page_shift >= 0 ? (pos >> page_shift) : pos / p.page_block_size;
                         const int pr = pos - pg * p.page_block_size;
                         const int64_t phys = btab[pg];
                         k8reg[i] = *reinterpret_cast<const u32x4*>(kp8 + phys * p.k_batch_stride + (int64_t)pr * p.k_row_stride + cc8 * 16);
@@ -653,7 +676,7 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : FA_FWD_OCC)) fa_fw
     };
 
     if (n_min < n_max) {
-        if (PAGED && paged_dma) pf_request(n_min);
+        if (PAGED && paged_aligned) pf_request(n_min);
         load_tile(n_min, std::integral_constant<int, 0>{});
         store_tile(std::integral_constant<int, 0>{}, n_min);
     }
