@@ -267,7 +267,7 @@ def serving_steps(flash_attn, dev):
             fn = lambda: flash_attn.flash_attn_varlen_func(qv, kc, vc, cu_q, cu_k, Tq, ctx, causal=True, block_table=bt, seqused_k=lens)
         else:
             fn = lambda: flash_attn.flash_attn_with_kvcache(q, kc, vc, cache_seqlens=lens, block_table=bt, causal=kw.get("softcap", 0.0) == 0.0, **kw)
-        ts = event_times_ms(fn, 20, warm=4)
+        ts = event_times_ms(fn, 20, warm=12)
         out[name] = round(sorted(ts)[len(ts) // 2] * 1e3, 1)
     run("decode_B1_us", 1, 1, 32, 8, 128, 8192)
     run("decode_B8_us", 8, 1, 32, 8, 128, 8192)
