@@ -160,10 +160,40 @@ static bool varlen_decode_route(const fa_params& p, fa_params& d) {
     return fa::decode_takes(d);
 }
 
+// A MIXED batch through the varlen op (vLLM-style unified step: many sequences with one - or a few - query tokens next to a
+// prefill chunk, paged K / V): the host cannot see the lengths, but it can see that most sequences must be short
+// ((total_q - max_seqlen_q) / (batch - 1) small).  Then the decode kernels run over ALL sequences in varlen-q mode and keep
+// the ones with 1 .. T query rows (DecArgs::cu_q; the others' workgroups leave at once), and fa_fwd_kernel runs with
+// KArgs::skip_short_q = T for the rest: 32 decode sequences + a 512-token chunk over 8 k contexts 792 -> ~350 us
+// (tools/mixed_batch_probe.py).  T = 32 / G query rows (at most 8): one 32-row block per kv-head.
+static bool varlen_mixed_route(const fa_params& p, fa_params& d) {
+    if (!p.block_table || !p.cu_seqlens_q || !p.cu_seqlens_k || p.p_dropout > 0.f || p.dmask) return false;
+    if (p.kv_dtype != p.dtype || p.page_block_size <= 0 || p.page_block_size % 64 != 0) return false;
+    if (p.batch < 4 || p.nheads_k <= 0 || p.total_q >= (int64_t)p.batch * p.seqlen_q) return false;    // uniform batches: above
+    const int G = p.nheads_q / p.nheads_k;
+    int T = 32 / (G > 0 ? G : 1);
+    T = T < 1 ? 1 : (T > 8 ? 8 : T);
+    if (p.seqlen_q <= T) return false;                                           // everything is short: the uniform route or the general kernel
+    if ((p.total_q - p.seqlen_q) > (int64_t)(p.batch - 1) * 16) return false;    // the other sequences average more than 16 rows
+    d = p;
+    d.cache_seqlens = p.seqused_k;                       // NULL: cu_seqlens_k differences
+    d.seqused_k = nullptr;
+    d.seqlen_q = T;                                      // the class bound; rows per sequence come from cu_seqlens_q (kept)
+    d.q_batch_stride = 0; d.o_batch_stride = 0; d.lse_batch_stride = 0;
+    d.k_new = d.v_new = nullptr; d.seqlen_new = 0;
+    d.rotary_cos = d.rotary_sin = nullptr; d.rotary_dim = 0;
+    d.cache_batch_idx = nullptr; d.cache_leftpad = nullptr;
+    d.num_splits = 0;
+    if (d.is_causal) d.window_right = 0;
+    return fa::decode_takes(d);
+}
+
 size_t fa_fwd_workspace_bytes(const fa_params* p) {
     fa_params d;
-    if (!p || !varlen_decode_route(*p, d)) return 0;
-    return fa::decode_workspace_bytes(d);
+    if (!p) return 0;
+    if (varlen_decode_route(*p, d)) return fa::decode_workspace_bytes(d);
+    if (varlen_mixed_route(*p, d)) return fa::decode_workspace_bytes(d);
+    return 0;
 }
 size_t fa_bwd_workspace_bytes(const fa_params* p) { return p ? fa::bwd_workspace_bytes(*p) : 0; }
 size_t fa_fwd_kvcache_workspace_bytes(const fa_params* p) { return p ? fa::decode_workspace_bytes(*p) : 0; }
@@ -212,9 +242,25 @@ int fa_varlen_fwd(const fa_params* pp, void* stream) {
             }
         }
     }
+    int skip_short = 0;
+    {
+        fa_params d;
+        if (varlen_mixed_route(p, d)) {
+            const size_t need = fa::decode_workspace_bytes(d);
+            if (need == 0 || (d.workspace && d.workspace_bytes >= need)) {
+                fa::KArgs ad = make_args(d, 128);
+                ad.seqlens_k = d.cache_seqlens;
+                ad.kv_mode = 1;
+                rc = fa::launch_decode(ad, static_cast<hipStream_t>(stream));
+                if (rc) return fail(FA_ERR_UNSUPPORTED, "no decode kernel for the short sequences of this varlen batch");
+                skip_short = d.seqlen_q;             // the general kernel below leaves those sequences out
+            }
+        }
+    }
     normalize(p, false);
     fa::KArgs a = make_args(p, 128);
     a.seqlens_k = p.seqused_k;
+    a.skip_short_q = skip_short;
     if (p.total_q > 0 && !varlen_grid_env()) {     // flat work list (fa_common.h: decode_work_flat)
         a.flat_blocks = p.total_q / 128 + p.batch;
         a.pair_qblocks = 0;

@@ -396,6 +396,8 @@ struct KArgs {
     int ds_nqb, ds_nkb;            // ceil(seqlen_q / 32), ceil(seqlen_k / 32)
     // backward, asm dK/dV kernel (fa_bwd_asm.hip): row statistics written by the preprocess kernel, or NULL
     float* stats_ws;               // [2][B][Hq][Sq]: plane 0 = LSE log2(e) (+inf where LSE = -inf), plane 1 = -D
+    int skip_short_q;              // varlen forward of a mixed batch: sequences with 1 .. skip_short_q query rows are served by the
+                                   // decode kernels (fa_api.hip: varlen_mixed_route) - fa_fwd_kernel leaves them out
     int rope_q;                    // kv-cache general path: fa_fwd_kernel rotates its Q fragments in registers (rotary_cos / sin at
                                    // position cache_seqlens[b] + leftpad (+ row under a causal / local mask), include/rotary.h:176-202)
     int fuse_pre;                  // the dQ kernel computes D = rowsum(dO o O) itself, runs first and writes softmax_d + stats_ws

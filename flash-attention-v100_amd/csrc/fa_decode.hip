@@ -65,6 +65,8 @@ struct DecArgs {
     int rows;                  // T_q * G; a workgroup takes 32 of them (row block)
     int n_rb;                  // row blocks
     int bias;                  // ALiBi slopes or softcap: per-element score path in fa_decode_kernel
+    const int32_t* cu_q;       // varlen-q mode (mixed batch through the varlen op): sequence b brings cu_q[b+1] - cu_q[b] query rows at
+                               // packed row cu_q[b]; sequences with 0 or more than p.seqlen_q (= the class bound) rows are not ours
     int grid_splits;           // fa_decode_kernel: key splits of the grid (= n_splits there)
     int group;                 // G
     int local;                 // RoPE position advances with the query row (causal / window)
@@ -111,7 +113,16 @@ __global__ void __launch_bounds__(64 * NW, 1) fa_decode_kernel(const DecArgs da)
     const int lp = p.cache_leftpad ? p.cache_leftpad[b] : 0;
     const int cb = p.cache_batch_idx ? p.cache_batch_idx[b] : b;
     const int seqlen_k = L + p.seqlen_new;
-    const int Tq = p.seqlen_q, G = da.group, R = da.rows;
+    int Tq = p.seqlen_q, q_row0 = 0;
+    const int G = da.group;
+    if (da.cu_q) {
+        q_row0 = da.cu_q[b];
+        const int ql = da.cu_q[b + 1] - q_row0;
+        if (ql < 1 || ql > p.seqlen_q) return;              // (uniform per workgroup: before any barrier)
+        Tq = ql;
+    }
+    const int R = da.cu_q ? Tq * G : da.rows;
+    if (32 * (da.n_rb > 1 ? rb : 0) >= R) return;           // a row block past this sequence's rows
     const int off = seqlen_k - Tq;
     const int wl = p.window_left;
     const int wr = p.is_causal ? 0 : p.window_right;
@@ -148,7 +159,7 @@ __global__ void __launch_bounds__(64 * NW, 1) fa_decode_kernel(const DecArgs da)
     u32x4 qf[Q_LDS ? 1 : KSTEPS];
     {
         const uint16_t* qrow = reinterpret_cast<const uint16_t*>(p.q) + (int64_t)b * p.q_batch_stride +
-                               (int64_t)t_row * p.q_row_stride + (int64_t)h * p.q_head_stride;
+                               (int64_t)(q_row0 + t_row) * p.q_row_stride + (int64_t)h * p.q_head_stride;
         const int half = p.rotary_dim >> 1;
         const int pos = L + lp + (da.local ? t_row : 0);
         const uint16_t* cosp = reinterpret_cast<const uint16_t*>(p.rotary_cos) + (int64_t)pos * half;
@@ -516,7 +527,7 @@ __global__ void __launch_bounds__(64 * NW, 1) fa_decode_kernel(const DecArgs da)
             const float lse = l_all > 0.f ? (m_all + fast_log2(l_all)) * kLn2 : -INFINITY;
             const int hq = hk * G + gq3;
             if (da.n_splits == 1) {
-                uint16_t* op = reinterpret_cast<uint16_t*>(p.o) + (int64_t)b * p.o_batch_stride + (int64_t)t3 * p.o_row_stride +
+                uint16_t* op = reinterpret_cast<uint16_t*>(p.o) + (int64_t)b * p.o_batch_stride + (int64_t)(q_row0 + t3) * p.o_row_stride +
                                (int64_t)hq * p.o_head_stride + cs;
 #pragma unroll
                 for (int x = 0; x < CPT; x += 2) {
@@ -530,9 +541,9 @@ __global__ void __launch_bounds__(64 * NW, 1) fa_decode_kernel(const DecArgs da)
                     *reinterpret_cast<uint32_t*>(op + x) = E::pack2(v0 * inv, v1 * inv);
                 }
                 if (tid % TPR == 0)
-                    p.lse[(int64_t)b * p.lse_batch_stride + (int64_t)hq * p.lse_head_stride + t3] = lse;
+                    p.lse[(int64_t)b * p.lse_batch_stride + (int64_t)hq * p.lse_head_stride + q_row0 + t3] = lse;
             } else {
-                const int64_t prow = (((int64_t)split * p.batch + b) * p.nheads_q + hq) * Tq + t3;
+                const int64_t prow = (((int64_t)split * p.batch + b) * p.nheads_q + hq) * p.seqlen_q + t3;
                 float* op = da.o_partial + prow * D + cs;
 #pragma unroll
                 for (int x = 0; x < CPT; ++x) {
@@ -571,10 +582,15 @@ __global__ void __launch_bounds__(256) decode_combine_kernel(const DecArgs da) {
 #pragma unroll
         for (int x = 0; x < 8; ++x) acc[x] = fmaf(op[x], wgt, acc[x]);
     }
-    const int t = row % p.seqlen_q;
+    int t = row % p.seqlen_q;
     const int64_t bh = row / p.seqlen_q;
     const int hq = bh % p.nheads_q;
     const int64_t b = bh / p.nheads_q;
+    if (da.cu_q) {                                          // varlen-q mode: rows of other classes / past the sequence
+        const int q0 = da.cu_q[b], ql = da.cu_q[b + 1] - q0;
+        if (ql < 1 || ql > p.seqlen_q || t >= ql) return;
+        t += q0;
+    }
     uint16_t* out = reinterpret_cast<uint16_t*>(p.o) + b * p.o_batch_stride + (int64_t)t * p.o_row_stride +
                     (int64_t)hq * p.o_head_stride + cc * 8;
     u32x4 o4;
@@ -600,6 +616,15 @@ __global__ void __launch_bounds__(256) decode_combine_wide_kernel(const DecArgs 
     const int64_t row = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = da.n_splits;
+    int t_out = row % p.seqlen_q;
+    const int64_t bh_ = row / p.seqlen_q;
+    const int hq_ = bh_ % p.nheads_q;
+    const int64_t b_ = bh_ / p.nheads_q;
+    if (da.cu_q) {                                          // varlen-q mode: rows of other classes / past the sequence
+        const int q0 = da.cu_q[b_], ql = da.cu_q[b_ + 1] - q0;
+        if (ql < 1 || ql > p.seqlen_q || t_out >= ql) return;          // (uniform per workgroup: before the barriers)
+        t_out += q0;
+    }
     __shared__ float s_w[256];
     __shared__ float s_red[8];
     __shared__ f32x4 s_acc[256];
@@ -654,10 +679,8 @@ __global__ void __launch_bounds__(256) decode_combine_wide_kernel(const DecArgs 
 #pragma unroll
             for (int x = 0; x < 4; ++x) acc[x] += y[x];
         }
-        const int t = row % p.seqlen_q;
-        const int64_t bh = row / p.seqlen_q;
-        const int hq = bh % p.nheads_q;
-        const int64_t b = bh / p.nheads_q;
+        const int t = t_out, hq = hq_;
+        const int64_t b = b_;
         uint16_t* out = reinterpret_cast<uint16_t*>(p.o) + b * p.o_batch_stride + (int64_t)t * p.o_row_stride +
                         (int64_t)hq * p.o_head_stride + tid * 4;
         u32x2 o2 = {E::pack2(acc[0], acc[1]), E::pack2(acc[2], acc[3])};
@@ -934,7 +957,7 @@ __host__ __device__ inline int gemv_tm_ksub(const fa_params& p) {
 __host__ __device__ inline bool gemv_tm_applicable(const fa_params& p) {
     const bool kv8 = p.kv_dtype == FA_FP8_E4M3;
     if (!kv8 && p.kv_dtype != p.dtype) return false;
-    if (p.head_dim != 128 || p.head_dim_v != 0 || p.seqlen_q != 1 || p.alibi_slopes || p.softcap > 0.f) return false;
+    if (p.head_dim != 128 || p.head_dim_v != 0 || p.seqlen_q != 1 || p.alibi_slopes || p.softcap > 0.f || p.cu_seqlens_q) return false;
     if (p.nheads_k < 1 || p.nheads_q % p.nheads_k) return false;
     const int G = p.nheads_q / p.nheads_k;
     // (GQA groups up to 4: VALU-bound - H 32/8: fp8 4.0 vs 3.7 TB/s on the MFMA kernel, fp16 5.6 vs 5.4)
@@ -1327,7 +1350,7 @@ static int launch_decode_td(DecArgs& da, hipStream_t stream) {
             return 0;
         }
         // fp8 cache, one query row per kv-head, a head layout the token-major kernel does not take: one workgroup per head
-        if (kv8 && da.rows == 1 && da.group == 1 && !da.bias) {
+        if (kv8 && da.rows == 1 && da.group == 1 && !da.bias && !da.cu_q) {
             if (paged) hipLaunchKernelGGL((fa_decode_gemv_fp8_kernel<T, true>), grid, dim3(GEMV_THREADS), 0, stream, da);
             else       hipLaunchKernelGGL((fa_decode_gemv_fp8_kernel<T, false>), grid, dim3(GEMV_THREADS), 0, stream, da);
             if (da.n_splits > 1) launch_decode_combine<T>(da, stream);
@@ -1377,6 +1400,7 @@ int launch_decode_splitkv(const KArgs& a, void* ws, hipStream_t stream) {
     da.rows = p.seqlen_q * da.group;
     da.local = (p.is_causal || p.window_left >= 0 || p.window_right >= 0) ? 1 : 0;
     da.bias = (p.alibi_slopes != nullptr || p.softcap > 0.f) ? 1 : 0;
+    da.cu_q = p.cu_seqlens_q;                         // (NULL except for the mixed-batch route of the varlen op)
     da.n_splits = decode_num_partials(p);             // (token-major kernel: grid splits x key sub-ranges; else the grid's y)
     da.ksub = gemv_tm_applicable(p) ? gemv_tm_ksub(p) : 1;
     da.page_shift = -1;

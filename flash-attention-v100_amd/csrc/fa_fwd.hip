@@ -82,6 +82,7 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : FA_FWD_OCC)) fa_fw
     if (p.cu_seqlens_q) {
         q_row0 = p.cu_seqlens_q[w.b];
         seqlen_q = p.cu_seqlens_q[w.b + 1] - (int)q_row0;
+        if (a.skip_short_q > 0 && seqlen_q <= a.skip_short_q) return;      // (mixed batch: the decode kernels own this sequence)
     }
     if (p.cu_seqlens_k) {
         const int k0 = p.cu_seqlens_k[w.b];

@@ -155,7 +155,8 @@ const char* fa_build_info(void);           /* arch, compiler, kernel variants */
 
 /* Workspace queries (bytes; 0 = none needed).  fa_fwd_workspace_bytes covers fa_fwd (always 0) and fa_varlen_fwd: non-zero
  * when the call is a decode step issued through the varlen op (every sequence brings the same <= 32 query tokens, paged
- * K / V) - with the workspace the split-KV decode kernels serve it, without it the general kernel does (same results). */
+ * K / V) or a mixed batch whose sequences are mostly short (decode sequences next to a prefill chunk) - with the workspace
+ * the split-KV decode kernels serve the short sequences, without it the general kernel serves everything (same results). */
 size_t fa_fwd_workspace_bytes(const fa_params* p);
 size_t fa_bwd_workspace_bytes(const fa_params* p);
 size_t fa_fwd_kvcache_workspace_bytes(const fa_params* p);

@@ -150,6 +150,59 @@ def test_varlen_decode_runs_the_decode_kernels(Tq, Hq, Hk, D, dt, page, use_sequ
     assert_lse_close(f64(lse2), lse_ref, "lse (general kernel)")
 
 
+@pytest.mark.parametrize("qlens,Hq,Hk,D,dt,page,causal,window,softcap,alibi", [
+    ([1] * 12 + [300], 32, 8, 128, "bf16", 256, True, (-1, -1), 0.0, False),              # 12 decode sequences + one prefill chunk
+    ([1, 1, 700, 1, 2, 1, 4, 1, 1, 3], 16, 4, 128, "fp16", 128, True, (-1, -1), 0.0, False),   # chunk in the middle, 1-4 speculative tokens (T = 8)
+    ([1, 5, 1, 1, 1, 1, 200, 1], 16, 2, 64, "bf16", 64, True, (-1, -1), 0.0, True),       # G = 8 -> T = 4: the 5-row sequence stays with the general kernel; ALiBi
+    ([1] * 6 + [150, 1, 1], 8, 8, 128, "fp16", 256, False, (-1, -1), 30.0, False),        # MHA, non-causal + softcap
+    ([2, 1, 1, 1, 90, 1, 1], 8, 2, 96, "bf16", 128, True, (300, 0), 0.0, False),          # narrow head dim + sliding window
+])
+def test_varlen_mixed_batch_splits_between_the_kernels(qlens, Hq, Hk, D, dt, page, causal, window, softcap, alibi):
+    """A mixed serving batch through ONE varlen call: sequences with 1 .. T query rows (T = min(8, 32 / G)) are served by the
+    decode kernels in varlen-q mode, the others by fa_fwd_kernel with those left out (fa_api.hip varlen_mixed_route; 792 ->
+    ~350 us for 32 decode sequences + a 512-token chunk, tools/mixed_batch_probe.py).  Every row of the packed output must be
+    written exactly once: out / lse start as NaN.  Checked against the varlen oracle, and against the general kernel alone
+    (no workspace offered)."""
+    from flash_attn_mi355 import flash_attn_interface as fi
+    B = len(qlens)
+    g = torch.Generator().manual_seed(43)
+    lens_k = [int(x) for x in torch.randint(40, 900, (B,), generator=g)]
+    lens_k = [max(lk, ql) for lk, ql in zip(lens_k, qlens)]
+    used = [lk - (i % 3) for i, lk in enumerate(lens_k)]
+    pps = [(l + page - 1) // page for l in lens_k]
+    nblk = sum(pps) + 2
+    perm = iter(torch.randperm(nblk, generator=g).tolist())
+    bt = torch.zeros((B, max(pps)), dtype=torch.int32)
+    for b in range(B):
+        for j in range(pps[b]):
+            bt[b, j] = next(perm)
+    kp = rand16((nblk, page, Hk, D), dt, 11); vp = rand16((nblk, page, Hk, D), dt, 12)
+    q = rand16((sum(qlens), Hq, D), dt, 13)
+    cu_q, cu_k = _cu(qlens), _cu(lens_k)
+    su = torch.tensor(used, dtype=torch.int32).cuda()
+    slopes = torch.tensor([0.02 * (i + 1) for i in range(Hq)], dtype=torch.float32, device="cuda") if alibi else None
+    kw = dict(causal=causal, window_size=window, softcap=softcap, alibi_slopes=slopes, block_table=bt.cuda(), seqused_k=su)
+    o_ref, lse_ref = oracle.varlen_fwd(f64(q), f64(kp), f64(vp), cu_q.cpu().numpy(), cu_k.cpu().numpy(), max(qlens), max(lens_k), D ** -0.5,
+                                       causal=causal, window=window, softcap=softcap,
+                                       alibi_slopes=None if slopes is None else f64(slopes),
+                                       seqused_k=np.array(used), block_table=bt.numpy())
+    # poison the allocator's next blocks so that an unwritten output row shows
+    junk = [torch.full((sum(qlens), Hq, D), float("nan"), dtype=q.dtype, device="cuda"), torch.full((Hq, sum(qlens)), float("nan"), device="cuda")]
+    del junk
+    out, lse, _ = _fa().flash_attn_varlen_func(q, kp, vp, cu_q, cu_k, max(qlens), max(lens_k), return_attn_probs=True, **kw)
+    assert torch.isfinite(out.float()).all(), "an output row was not written"
+    assert_close(f64(out), o_ref, dt, "out")
+    assert_lse_close(f64(lse), lse_ref, "lse")
+    orig_ws = fi._workspace
+    fi._workspace = lambda nbytes, device: None
+    try:
+        out2, lse2, _ = _fa().flash_attn_varlen_func(q, kp, vp, cu_q, cu_k, max(qlens), max(lens_k), return_attn_probs=True, **kw)
+    finally:
+        fi._workspace = orig_ws
+    assert_close(f64(out2), o_ref, dt, "out (general kernel)")
+    assert_lse_close(f64(lse2), lse_ref, "lse (general kernel)")
+
+
 def test_config3_shape_properties():
     """BASELINE config 3: fp16 packed batch 64, seqlens in [64, 2048] (max forced to 2048), H32 D64,
     window (512, 0).  Full size via properties: window (512,0) == causal + window_left 512, and a few
