@@ -162,7 +162,7 @@ static bool varlen_decode_route(const fa_params& p, fa_params& d) {
 
 // A MIXED batch through the varlen op (vLLM-style unified step: many sequences with one - or a few - query tokens next to a
 // prefill chunk, paged K / V): the host cannot see the lengths, but it can see that most sequences must be short
-// ((total_q - max_seqlen_q) / (batch - 1) small).  Then the decode kernels run over ALL sequences in varlen-q mode and keep
+// ((total_q - max_seqlen_q) / (batch - 1) <= 64).  Then the decode kernels run over ALL sequences in varlen-q mode and keep
 // the ones with 1 .. T query rows (DecArgs::cu_q; the others' workgroups leave at once), and fa_fwd_kernel runs with
 // KArgs::skip_short_q = T for the rest: 32 decode sequences + a 512-token chunk over 8 k contexts 792 -> ~350 us
 // (tools/mixed_batch_probe.py).  T = 32 / G query rows (at most 8): one 32-row block per kv-head.
@@ -174,7 +174,9 @@ static bool varlen_mixed_route(const fa_params& p, fa_params& d) {
     int T = 32 / (G > 0 ? G : 1);
     T = T < 1 ? 1 : (T > 8 ? 8 : T);
     if (p.seqlen_q <= T) return false;                                           // everything is short: the uniform route or the general kernel
-    if ((p.total_q - p.seqlen_q) > (int64_t)(p.batch - 1) * 16) return false;    // the other sequences average more than 16 rows
+    // (the other sequences average more than 64 rows: few of them can be decode steps.  A wrong yes costs one launch of
+    //  workgroups that leave at once, ~10 us; a wrong no costs the decode sequences a 128-row tile and a full stream each)
+    if ((p.total_q - p.seqlen_q) > (int64_t)(p.batch - 1) * 64) return false;
     d = p;
     d.cache_seqlens = p.seqused_k;                       // NULL: cu_seqlens_k differences
     d.seqused_k = nullptr;

@@ -12,9 +12,9 @@ def t_us(f, n=10):
     torch.cuda.synchronize()
     return sorted(s.elapsed_time(e) for s, e in evs)[n // 2] * 1e3
 Hq, Hk, D, page, ctx = 32, 8, 128, 256, 8192
-for (ndec, chunk) in ((32, 512), (64, 2048), (8, 512), (128, 0), (0, 2048)):
-    B = ndec + (1 if chunk else 0)
-    qlens = [1] * ndec + ([chunk] if chunk else [])
+for (ndec, chunks) in ((32, [512]), (64, [2048]), (64, [512] * 4), (8, [512]), (128, []), (0, [2048])):
+    B = ndec + len(chunks)
+    qlens = [1] * ndec + chunks
     nblk = B * ctx // page
     kc = torch.randn(nblk, page, Hk, D, device="cuda", dtype=torch.bfloat16); vc = torch.randn_like(kc)
     bt = torch.randperm(nblk, device="cuda").to(torch.int32).reshape(B, ctx // page)
@@ -27,7 +27,7 @@ for (ndec, chunk) in ((32, 512), (64, 2048), (8, 512), (128, 0), (0, 2048)):
     if ndec:
         qd = q[:ndec].reshape(ndec, 1, Hq, D)
         parts += t_us(lambda: fa.flash_attn_with_kvcache(qd, kc, vc, cache_seqlens=lens[:ndec], block_table=bt[:ndec], causal=True))
-    if chunk:
-        qp = q[ndec:].reshape(1, chunk, Hq, D)
+    if chunks:
+        qp = q[ndec:].reshape(len(chunks), chunks[0], Hq, D)
         parts += t_us(lambda: fa.flash_attn_with_kvcache(qp, kc, vc, cache_seqlens=lens[ndec:], block_table=bt[ndec:], causal=True))
-    print(f"{ndec:3d} decode seqs + prefill chunk {chunk:4d} (ctx {ctx}, H {Hq}/{Hk}): one varlen call {mixed:8.1f} us | decode call + prefill call {parts:8.1f} us", flush=True)
+    print(f"{ndec:3d} decode seqs + {len(chunks)} prefill chunk(s) of {chunks[0] if chunks else 0:4d} (ctx {ctx}, H {Hq}/{Hk}): one varlen call {mixed:8.1f} us | decode call + prefill call {parts:8.1f} us", flush=True)
