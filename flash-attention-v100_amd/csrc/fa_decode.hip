@@ -1231,7 +1231,7 @@ static int device_cu_count();
 // both (tools/spec_decode_sweep.py: ~150 us per row block vs 156 us per head pass at B 64, H 64/8, 4 k fp8), so the
 // decode kernel runs while it needs no more passes - i.e. up to 32 query positions whatever the group size (16-bit
 // caches stopped at 32 packed ROWS before: T_q 9 at G = 4 fell onto the general path at 6 x the time).  When the general
-// path cannot fill the chip (batch x heads x 128-row blocks < 2 x CUs) the decode kernel's split-KV is worth up to
+// path cannot fill the chip (batch x heads x 128-row blocks <= CUs) the decode kernel's split-KV is worth up to
 // 8 x the passes (B 1, H 32/8, T_q 128 over 8 k: 72 us against 240).  fp8 caches with two row blocks stay here too.
 bool decode_takes(const fa_params& p) {
     if (!decode_applicable(p)) return false;
@@ -1240,8 +1240,11 @@ bool decode_takes(const fa_params& p) {
     const int fwd_blocks = (p.seqlen_q + 127) / 128;
     const int fwd_passes = G * fwd_blocks;
     const int64_t fwd_wgs = (int64_t)p.batch * p.nheads_q * fwd_blocks;
-    int64_t factor = 2 * device_cu_count() / (fwd_wgs > 0 ? fwd_wgs : 1);
-    factor = factor < 1 ? 1 : (factor > 8 ? 8 : factor);
+    // (chunked_prefill_probe.py with FA_DEC_FACTOR: at one general-path workgroup per CU or fewer the row blocks win even at
+    //  4 x the passes - B 1, T_q 512, H 64/8 over 32 k: 0.92 ms against 1.34 -; at two per CU the general path wins)
+    const int cus = device_cu_count();
+    int64_t factor = fwd_wgs <= cus ? 8 : (fwd_wgs < 2 * cus ? 2 : 1);
+    if (const char* e = getenv("FA_DEC_FACTOR")) factor = atoi(e);          // (experiments: tools/chunked_prefill_probe.py)
     if (row_blocks <= factor * fwd_passes) return true;
     return p.kv_dtype == FA_FP8_E4M3 && row_blocks <= 2;
 }
