@@ -143,7 +143,7 @@ const char* fa_build_info(void) {
 static bool varlen_decode_route(const fa_params& p, fa_params& d) {
     if (!p.block_table || !p.cu_seqlens_q || !p.cu_seqlens_k || p.p_dropout > 0.f || p.dmask) return false;
     if (p.batch <= 0 || p.seqlen_q <= 0 || p.total_q != (int64_t)p.batch * p.seqlen_q) return false;   // uniform T_q (host-checkable)
-    if (p.kv_dtype != p.dtype || p.page_block_size <= 0 || p.page_block_size % 64 != 0) return false;
+    if ((p.kv_dtype != p.dtype && p.kv_dtype != FA_FP8_E4M3) || p.page_block_size <= 0 || p.page_block_size % 64 != 0) return false;
     d = p;
     d.cache_seqlens = p.seqused_k;                       // NULL: cu_seqlens_k differences (dec_cache_len in fa_decode.hip)
     d.seqused_k = nullptr;
@@ -168,7 +168,7 @@ static bool varlen_decode_route(const fa_params& p, fa_params& d) {
 // (tools/mixed_batch_probe.py).  T = 32 / G query rows (at most 8): one 32-row block per kv-head.
 static bool varlen_mixed_route(const fa_params& p, fa_params& d) {
     if (!p.block_table || !p.cu_seqlens_q || !p.cu_seqlens_k || p.p_dropout > 0.f || p.dmask) return false;
-    if (p.kv_dtype != p.dtype || p.page_block_size <= 0 || p.page_block_size % 64 != 0) return false;
+    if ((p.kv_dtype != p.dtype && p.kv_dtype != FA_FP8_E4M3) || p.page_block_size <= 0 || p.page_block_size % 64 != 0) return false;
     if (p.batch < 4 || p.nheads_k <= 0 || p.total_q >= (int64_t)p.batch * p.seqlen_q) return false;    // uniform batches: above
     const int G = p.nheads_q / p.nheads_k;
     int T = 32 / (G > 0 ? G : 1);
@@ -222,7 +222,14 @@ int fa_varlen_fwd(const fa_params* pp, void* stream) {
     fa_params p = *pp;
     int rc = check_common(p, true);
     if (rc) return rc;
-    FA_CHECK(p.kv_dtype == p.dtype, "k/v must have the same dtype as q");
+    // fp8-e4m3 K / V (this build's extension, as in fa_fwd_kvcache): paged caches, forward only, head dim 64 / 128
+    if (p.kv_dtype == FA_FP8_E4M3) {
+        FA_CHECK(p.block_table, "fp8 K/V through the varlen op: paged K/V (block_table) only");
+        FA_CHECK((p.head_dim == 64 || p.head_dim == 128) && p.head_dim_v == 0, "fp8 K/V: head dimension 64 or 128");
+        FA_CHECK(p.p_dropout == 0.f && !p.dmask, "fp8 K/V: no dropout");
+    } else {
+        FA_CHECK(p.kv_dtype == p.dtype, "k/v must have the same dtype as q (or fp8-e4m3 for paged K/V)");
+    }
     FA_CHECK(p.cu_seqlens_q && p.cu_seqlens_k, "cu_seqlens_q and cu_seqlens_k are required");
     if (p.block_table) {
         FA_CHECK(p.page_block_size > 0, "page_block_size must be positive");

@@ -386,7 +386,8 @@ def flash_attn_func(q, k, v, dropout_p: float = 0.0, softmax_scale: float = None
 # ======================================================================================
 def _varlen_forward(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, dropout_p,
                     softmax_scale, causal, window_size, softcap, alibi_slopes, return_attn_probs,
-                    block_table, seqused_k=None, leftpad_k=None, zero_tensors=False, out=None):
+                    block_table, seqused_k=None, leftpad_k=None, zero_tensors=False, out=None,
+                    k_descale=None, v_descale=None):
     """One fa_varlen_fwd call on [T, H, D] tensors (K/V optionally paged [nblk, page, Hk, D]).
     seqused_k clamps the keys of each sequence (include/template.h:65-68); zero_tensors pre-fills out / lse / dmask
     (fused_mha_forward_varlen.cu:538-542); leftpad_k is validated and, like in the reference kernel (the pointer is a
@@ -394,7 +395,14 @@ def _varlen_forward(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqle
     _check_device(q, k, v, cu_seqlens_q, cu_seqlens_k, seqused_k, leftpad_k)
     if q.dtype not in _DTYPES:
         raise RuntimeError("q must be fp16 or bf16")
-    if k.dtype != q.dtype or v.dtype != q.dtype:
+    fp8 = k.dtype == torch.float8_e4m3fn
+    if fp8:
+        # this build's extension (as in flash_attn_with_kvcache): a paged fp8-e4m3 cache, value = code * descale; forward only
+        if v.dtype != k.dtype or block_table is None:
+            raise RuntimeError("fp8 k/v through the varlen op: paged k and v (block_table), both float8_e4m3fn")
+        if q.shape[-1] not in (64, 128) or dropout_p > 0.0:
+            raise RuntimeError("fp8 k/v: head dimension 64 or 128, no dropout")
+    elif k.dtype != q.dtype or v.dtype != q.dtype:
         raise RuntimeError("k/v must have the same dtype as q")
     if q.dim() != 3:
         raise RuntimeError("q must be (total_q, nheads, headdim)")
@@ -442,6 +450,10 @@ def _varlen_forward(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqle
         out_.zero_()
         lse.fill_(float("-inf"))
     p = _base_params(q_, q.dtype, softmax_scale, causal, window_size, softcap)
+    if fp8:
+        p.kv_dtype = _lib.FA_FP8_E4M3
+        p.k_descale = 1.0 if k_descale is None else float(k_descale)
+        p.v_descale = 1.0 if v_descale is None else float(v_descale)
     p.q, p.k, p.v, p.o, p.lse = _ptr(q_), _ptr(k_), _ptr(v_), _ptr(out_), _ptr(lse)
     p.seqused_k = _ptr(seqused_k)
     _set3(p, "q", q_, "thd"); _set3(p, "o", out_, "thd")
@@ -566,17 +578,21 @@ def flash_attn_varlen_func(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q: in
                            softcap: float = 0.0, alibi_slopes: Optional[torch.Tensor] = None,
                            deterministic: bool = False, return_attn_probs: bool = False,
                            block_table: Optional[torch.Tensor] = None, *,
-                           seqused_k: Optional[torch.Tensor] = None):
+                           seqused_k: Optional[torch.Tensor] = None,
+                           k_descale: Optional[float] = None, v_descale: Optional[float] = None):
     """Varlen Flash Attention (T, H, D).  seqused_k ([B] int32, forward only): use only the first seqused_k[b] keys
-    of sequence b (the op-level argument of the reference, include/mha.h:116-139)."""
+    of sequence b (the op-level argument of the reference, include/mha.h:116-139).  Paged k / v may be float8_e4m3fn
+    (value = code * k_descale / v_descale; forward only) - this build's extension, as in flash_attn_with_kvcache."""
     deterministic = _warn_deterministic(deterministic)
     try:
-        if seqused_k is not None:
+        fp8 = k.dtype == torch.float8_e4m3fn
+        if seqused_k is not None or fp8:
             if torch.is_grad_enabled() and any(x.requires_grad for x in (q, k, v)):
-                raise RuntimeError("seqused_k is a forward-only argument (the reference's backward op has none)")
+                raise RuntimeError("seqused_k / fp8 k, v are forward-only (the reference's backward op has neither)")
             out, lse, dmask, _, _, _ = _varlen_forward(
                 q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, dropout_p, softmax_scale, causal,
-                window_size, softcap, alibi_slopes, return_attn_probs, block_table, seqused_k=seqused_k)
+                window_size, softcap, alibi_slopes, return_attn_probs, block_table, seqused_k=seqused_k,
+                k_descale=k_descale, v_descale=v_descale)
             return (out, lse, dmask) if return_attn_probs else out
         return FlashAttnVarlenFunc.apply(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q,
                                          max_seqlen_k, dropout_p, softmax_scale, causal,

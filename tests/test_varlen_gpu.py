@@ -203,6 +203,48 @@ def test_varlen_mixed_batch_splits_between_the_kernels(qlens, Hq, Hk, D, dt, pag
     assert_lse_close(f64(lse2), lse_ref, "lse (general kernel)")
 
 
+@pytest.mark.parametrize("qlens,Hq,Hk,D,page,causal", [
+    ([70, 1, 300, 129], 8, 2, 128, 128, True),              # ragged prefill: fa_fwd_kernel<..., KV8> on the flat work list
+    ([1] * 6, 32, 8, 128, 256, True),                       # uniform decode through the varlen op: decode kernels
+    ([1] * 9 + [260, 1, 2], 16, 4, 128, 256, True),         # mixed batch: both
+    ([40, 200, 1], 4, 4, 64, 64, False),                    # D = 64, non-causal
+])
+def test_varlen_paged_fp8_kv(qlens, Hq, Hk, D, page, causal):
+    """Paged fp8-e4m3 K / V through the varlen op (this build's extension, as in flash_attn_with_kvcache: value = code x
+    descale, forward only): the general kernel dequantises a tile once per 128 query rows, the decode routes serve uniform
+    and mixed batches.  The oracle sees the dequantised cache; tolerance: 1.5 x the io dtype's, LSE 3e-2 (the fp8 cases')."""
+    dt = "bf16"
+    B = len(qlens)
+    g = torch.Generator().manual_seed(47)
+    lens_k = [max(int(x), ql) for x, ql in zip(torch.randint(30, 700, (B,), generator=g), qlens)]
+    pps = [(l + page - 1) // page for l in lens_k]
+    nblk = sum(pps) + 1
+    perm = iter(torch.randperm(nblk, generator=g).tolist())
+    bt = torch.zeros((B, max(pps)), dtype=torch.int32)
+    for b in range(B):
+        for j in range(pps[b]):
+            bt[b, j] = next(perm)
+    kd, vd = 0.0625, 0.03125
+    kp = (rand16((nblk, page, Hk, D), dt, 11, scale=1.5).float() / kd).to(torch.float8_e4m3fn)
+    vp = (rand16((nblk, page, Hk, D), dt, 12, scale=1.5).float() / vd).to(torch.float8_e4m3fn)
+    q = rand16((sum(qlens), Hq, D), dt, 13)
+    cu_q, cu_k = _cu(qlens), _cu(lens_k)
+    su = torch.tensor(lens_k, dtype=torch.int32).cuda()
+    out, lse, _ = _fa().flash_attn_varlen_func(q, kp, vp, cu_q, cu_k, max(qlens), max(lens_k), causal=causal, return_attn_probs=True,
+                                               block_table=bt.cuda(), seqused_k=su, k_descale=kd, v_descale=vd)
+    o_ref, lse_ref = oracle.varlen_fwd(f64(q), kp.float().double().cpu().numpy() * kd, vp.float().double().cpu().numpy() * vd,
+                                       cu_q.cpu().numpy(), cu_k.cpu().numpy(), max(qlens), max(lens_k), D ** -0.5, causal=causal,
+                                       seqused_k=np.array(lens_k), block_table=bt.numpy())
+    assert_close(f64(out), o_ref, dt, "out", mult=1.5)
+    assert_lse_close(f64(lse), lse_ref, "lse", atol=3e-2)
+    with pytest.raises(RuntimeError):                       # forward only
+        qg = q.clone().requires_grad_()
+        _fa().flash_attn_varlen_func(qg, kp, vp, cu_q, cu_k, max(qlens), max(lens_k), causal=causal, block_table=bt.cuda())
+    with pytest.raises(RuntimeError):                       # packed (unpaged) fp8 k / v are not taken
+        _fa().flash_attn_varlen_func(q, kp.reshape(-1, Hk, D)[: sum(lens_k)], vp.reshape(-1, Hk, D)[: sum(lens_k)], cu_q, cu_k,
+                                     max(qlens), max(lens_k), causal=causal)
+
+
 def test_config3_shape_properties():
     """BASELINE config 3: fp16 packed batch 64, seqlens in [64, 2048] (max forced to 2048), H32 D64,
     window (512, 0).  Full size via properties: window (512,0) == causal + window_left 512, and a few
