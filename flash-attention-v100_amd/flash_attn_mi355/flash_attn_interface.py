@@ -392,6 +392,11 @@ def _varlen_forward(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqle
     seqused_k clamps the keys of each sequence (include/template.h:65-68); zero_tensors pre-fills out / lse / dmask
     (fused_mha_forward_varlen.cu:538-542); leftpad_k is validated and, like in the reference kernel (the pointer is a
     parameter that is never read, fused_mha_forward_varlen.cu:37), not applied."""
+    if cu_seqlens_k is None:
+        # paged callers that carry lengths only (seqused_k, as vLLM-style wrappers do): the prefix sums the op wants
+        if block_table is None or seqused_k is None:
+            raise RuntimeError("cu_seqlens_k may be omitted only for paged k / v with seqused_k")
+        cu_seqlens_k = torch.nn.functional.pad(seqused_k.cumsum(0, dtype=torch.int32), (1, 0))
     _check_device(q, k, v, cu_seqlens_q, cu_seqlens_k, seqused_k, leftpad_k)
     if q.dtype not in _DTYPES:
         raise RuntimeError("q must be fp16 or bf16")

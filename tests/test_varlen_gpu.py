@@ -237,6 +237,10 @@ def test_varlen_paged_fp8_kv(qlens, Hq, Hk, D, page, causal):
                                        seqused_k=np.array(lens_k), block_table=bt.numpy())
     assert_close(f64(out), o_ref, dt, "out", mult=1.5)
     assert_lse_close(f64(lse), lse_ref, "lse", atol=3e-2)
+    # lengths only (cu_seqlens_k = None with seqused_k, as vLLM-style wrappers call it): the same rows
+    out_n = _fa().flash_attn_varlen_func(q, kp, vp, cu_q, None, max(qlens), max(lens_k), causal=causal,
+                                         block_table=bt.cuda(), seqused_k=su, k_descale=kd, v_descale=vd)
+    assert torch.equal(out_n, out)
     with pytest.raises(RuntimeError):                       # forward only
         qg = q.clone().requires_grad_()
         _fa().flash_attn_varlen_func(qg, kp, vp, cu_q, cu_k, max(qlens), max(lens_k), causal=causal, block_table=bt.cuda())
