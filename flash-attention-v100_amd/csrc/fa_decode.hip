@@ -960,8 +960,11 @@ __host__ __device__ inline bool gemv_tm_applicable(const fa_params& p) {
     if (p.head_dim != 128 || p.head_dim_v != 0 || p.seqlen_q != 1 || p.alibi_slopes || p.softcap > 0.f || p.cu_seqlens_q) return false;
     if (p.nheads_k < 1 || p.nheads_q % p.nheads_k) return false;
     const int G = p.nheads_q / p.nheads_k;
-    // (GQA groups up to 4: VALU-bound - H 32/8: fp8 4.0 vs 3.7 TB/s on the MFMA kernel, fp16 5.6 vs 5.4)
+    // (GQA groups up to 4: VALU-bound - H 32/8, round 2: fp8 4.0 vs 3.7 TB/s on the MFMA kernel, fp16 5.6 vs 5.4)
     if (!(G == 1 || G == 2 || G == 4)) return false;
+    // fp8 caches at G = 4 are VALU-bound here (4.0-4.4 TB/s): since the MFMA decode kernel runs two waves per SIMD it is
+    // 3-43 % faster on them (H 32/8: B 64 285 -> 223 us, B 8 55 -> 38, B 1 over 32 k 52 -> 30); 16-bit caches and G <= 2 stay
+    if (kv8 && G == 4) return false;
     return p.nheads_k % gemv_tm_hpw(p) == 0 && p.k_head_stride == 128 && p.v_head_stride == 128;
 }
 
