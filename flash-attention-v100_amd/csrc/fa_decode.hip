@@ -965,6 +965,9 @@ __host__ __device__ inline bool gemv_tm_applicable(const fa_params& p) {
     // fp8 caches at G = 4 are VALU-bound here (4.0-4.4 TB/s): since the MFMA decode kernel runs two waves per SIMD it is
     // 3-43 % faster on them (H 32/8: B 64 285 -> 223 us, B 8 55 -> 38, B 1 over 32 k 52 -> 30); 16-bit caches and G <= 2 stay
     if (kv8 && G == 4) return false;
+#ifdef FA_EXP_TM16_MAXG                 // experiment builds (tools/define_variant.py): 16-bit caches above this group size -> MFMA kernel
+    if (!kv8 && G > FA_EXP_TM16_MAXG) return false;
+#endif
     return p.nheads_k % gemv_tm_hpw(p) == 0 && p.k_head_stride == 128 && p.v_head_stride == 128;
 }
 
