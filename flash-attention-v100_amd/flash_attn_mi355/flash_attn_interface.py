@@ -101,8 +101,38 @@ def _usable_out(out, dpad, head_size_og):
             all(st % 8 == 0 for st in out.stride()[:-1]))
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream(device) -> int:
+    """raw handle of torch's current stream on `device` (the stream the reference launches on: fused_mha_forward.cu:416)"""
+    if _raw_stream is not None:
+        idx = device.index
+        return _raw_stream(torch.cuda.current_device() if idx is None else idx)
     return torch.cuda.current_stream(device).cuda_stream
+
+
+class _on_device:
+    """`with _on_device(dev)` that costs nothing when `dev` is already current (the usual case; the context manager
+    itself was ~3 us of the ~25 us a call spends on the host: tools/host_overhead.py)"""
+    __slots__ = ("idx", "prev")
+
+    def __init__(self, device):
+        self.idx = device.index
+        self.prev = None
+
+    def __enter__(self):
+        if self.idx is not None:
+            cur = torch.cuda.current_device()
+            if cur != self.idx:
+                self.prev = cur
+                torch.cuda.set_device(self.idx)
+        return self
+
+    def __exit__(self, *exc):
+        if self.prev is not None:
+            torch.cuda.set_device(self.prev)
+        return False
 
 
 def _ptr(t):
@@ -207,7 +237,7 @@ def _dense_forward(q, k, v, dropout_p, softmax_scale, causal, window_size, softc
         dmask = torch.zeros((B, H_Q, M, N), dtype=q.dtype, device=q.device)
         p.dmask = _ptr(dmask)
     if q_.numel() > 0:                                   # (an empty query block is a no-op)
-        with torch.cuda.device(q.device):
+        with _on_device(q.device):
             _lib.call("fa_fwd", p, _stream(q.device))
     if out is not None and out_ is not out:              # caller-allocated out the kernel could not write directly
         out.copy_(out_[..., :head_size_og])
@@ -247,7 +277,7 @@ def _dense_backward(dout, q_, k_, v_, out_, lse, alibi_slopes, dropout_p, softma
     ws = _workspace(_lib.lib.fa_bwd_workspace_bytes(ctypes.byref(p)), q_.device)
     if ws is not None:
         p.workspace, p.workspace_bytes = _ptr(ws), ws.numel()
-    with torch.cuda.device(q_.device):
+    with _on_device(q_.device):
         _lib.call("fa_bwd", p, _stream(q_.device))
     return softmax_d
 
@@ -487,7 +517,7 @@ def _varlen_forward(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqle
     if ws is not None:
         p.workspace, p.workspace_bytes = _ptr(ws), ws.numel()
     if q_.numel() > 0:
-        with torch.cuda.device(q.device):
+        with _on_device(q.device):
             _lib.call("fa_varlen_fwd", p, _stream(q.device))
     if out is not None and out_ is not out:
         out.copy_(out_[..., :head_size_og])
@@ -529,7 +559,7 @@ def _varlen_backward(dout, q_, k_, v_, out_, lse, cu_seqlens_q, cu_seqlens_k, al
     ws = _workspace(_lib.lib.fa_bwd_workspace_bytes(ctypes.byref(p)), q_.device)
     if ws is not None:
         p.workspace, p.workspace_bytes = _ptr(ws), ws.numel()
-    with torch.cuda.device(q_.device):
+    with _on_device(q_.device):
         _lib.call("fa_varlen_bwd", p, _stream(q_.device))
     return softmax_d
 
@@ -727,7 +757,7 @@ def flash_attn_with_kvcache(q, k_cache, v_cache, k=None, v=None, rotary_cos=None
     ws = _workspace(_lib.lib.fa_fwd_kvcache_workspace_bytes(ctypes.byref(p)), q.device)
     if ws is not None:
         p.workspace, p.workspace_bytes = _ptr(ws), ws.numel()
-    with torch.cuda.device(q.device):
+    with _on_device(q.device):
         _lib.call("fa_fwd_kvcache", p, _stream(q.device))
     if return_softmax_lse:
         return out, lse

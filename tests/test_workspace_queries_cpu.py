@@ -77,7 +77,9 @@ def test_decode_partials_workspace(lib):
     assert n % per_part(128, 32) == 0 and 1 <= n // per_part(128, 32) <= 8
     # explicit splits are honoured; fewer head groups than waves multiply the partial rows (8 kv-heads, fp8: 1 group -> x4)
     assert q(ctypes.byref(_decode(lib, 16, 32, 32, 4096, True, num_splits=3))) == 3 * per_part(16, 32)
-    assert q(ctypes.byref(_decode(lib, 16, 32, 8, 4096, True, num_splits=3))) == 3 * 4 * per_part(16, 32)
+    assert q(ctypes.byref(_decode(lib, 16, 16, 8, 4096, True, num_splits=3))) == 3 * 4 * per_part(16, 16)    # G = 2, fp8
+    # fp8 caches with groups of 4 run the MFMA decode kernel (round 3: two waves per SIMD beat the VALU-bound form): splits only
+    assert q(ctypes.byref(_decode(lib, 16, 32, 8, 4096, True, num_splits=3))) == 3 * per_part(16, 32)
     assert q(ctypes.byref(_decode(lib, 16, 16, 8, 4096, False, num_splits=2))) == 2 * 2 * per_part(16, 16)   # 16 bit: 4 heads per wave step
     assert q(ctypes.byref(_decode(lib, 16, 32, 32, 4096, False, num_splits=1))) == 0                         # one partial = written in place
     # four kv-heads with fp8: the head-major kernel, splits only
