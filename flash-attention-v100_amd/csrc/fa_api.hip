@@ -143,7 +143,7 @@ const char* fa_build_info(void) {
 static bool varlen_decode_route(const fa_params& p, fa_params& d) {
     if (!p.block_table || !p.cu_seqlens_q || !p.cu_seqlens_k || p.p_dropout > 0.f || p.dmask) return false;
     if (p.batch <= 0 || p.seqlen_q <= 0 || p.total_q != (int64_t)p.batch * p.seqlen_q) return false;   // uniform T_q (host-checkable)
-    if ((p.kv_dtype != p.dtype && p.kv_dtype != FA_FP8_E4M3) || p.page_block_size <= 0 || p.page_block_size % 64 != 0) return false;
+    if ((p.kv_dtype != p.dtype && p.kv_dtype != FA_FP8_E4M3) || p.page_block_size <= 0 || p.page_block_size % 16 != 0) return false;
     d = p;
     d.cache_seqlens = p.seqused_k;                       // NULL: cu_seqlens_k differences (dec_cache_len in fa_decode.hip)
     d.seqused_k = nullptr;
@@ -168,7 +168,7 @@ static bool varlen_decode_route(const fa_params& p, fa_params& d) {
 // (tools/mixed_batch_probe.py).  T = 32 / G query rows (at most 8): one 32-row block per kv-head.
 static bool varlen_mixed_route(const fa_params& p, fa_params& d) {
     if (!p.block_table || !p.cu_seqlens_q || !p.cu_seqlens_k || p.p_dropout > 0.f || p.dmask) return false;
-    if ((p.kv_dtype != p.dtype && p.kv_dtype != FA_FP8_E4M3) || p.page_block_size <= 0 || p.page_block_size % 64 != 0) return false;
+    if ((p.kv_dtype != p.dtype && p.kv_dtype != FA_FP8_E4M3) || p.page_block_size <= 0 || p.page_block_size % 16 != 0) return false;
     if (p.batch < 4 || p.nheads_k <= 0 || p.total_q >= (int64_t)p.batch * p.seqlen_q) return false;    // uniform batches: above
     const int G = p.nheads_q / p.nheads_k;
     int T = 32 / (G > 0 ? G : 1);
@@ -233,7 +233,7 @@ int fa_varlen_fwd(const fa_params* pp, void* stream) {
     FA_CHECK(p.cu_seqlens_q && p.cu_seqlens_k, "cu_seqlens_q and cu_seqlens_k are required");
     if (p.block_table) {
         FA_CHECK(p.page_block_size > 0, "page_block_size must be positive");
-        FA_CHECK(p.page_block_size % 64 == 0, "Paged KV cache block size must be divisible by 64");
+        FA_CHECK(p.page_block_size % 16 == 0, "Paged KV cache block size must be divisible by 16");
     }
     if (p.p_dropout > 0.f && p.block_table) return fail(FA_ERR_UNSUPPORTED, "dropout with paged K/V is not supported");
     if (p.total_q == 0 || p.seqlen_q == 0) return FA_OK;
@@ -291,8 +291,10 @@ int fa_fwd_kvcache(const fa_params* pp, void* stream) {
     const bool paged = p.block_table != nullptr;
     if (paged) {
         FA_CHECK(!p.cache_batch_idx, "Paged KVcache does not support cache_batch_idx");
-        FA_CHECK(p.page_block_size > 0 && p.page_block_size % 64 == 0,
-                 "Paged KV cache block size must be divisible by 64");
+        // (the reference wants multiples of 256, fused_mha_forward_kvcache.cu:488; here any multiple of 16 works - pages of
+        //  64 tokens and more take the aligned fast paths, smaller ones the per-row lookups)
+        FA_CHECK(p.page_block_size > 0 && p.page_block_size % 16 == 0,
+                 "Paged KV cache block size must be divisible by 16");
     }
     if (p.k_new || p.v_new) {
         FA_CHECK(p.k_new && p.v_new, "If key is supplied, value must also be passed in");

@@ -236,13 +236,18 @@ __global__ void __launch_bounds__(64 * NW, 1) fa_decode_kernel(const DecArgs da)
         v_voff[i] = (uint32_t)(row * p.v_row_stride * EB + ccl * 16);
     }
     const u32x4 zero4 = {0, 0, 0, 0};
-    // a 32-key tile lies inside one page when the left pad keeps tiles 32-aligned (page % 64 == 0)
-    const bool tiles_aligned = !PAGED || ((lp & (BN - 1)) == 0);
+    // a 16-row half of a tile lies inside one page when the left pad and the page size are multiples of 16
+    // (pages of 16 tokens - vLLM's default block - hold half a 32-key tile: the tile's two 16-row halves take their own
+    //  page; a lane's chunk i lies in one half as a whole because 64 / CPR rows per load step divide 16)
+    const bool tiles_aligned = !PAGED || (((lp & 15) == 0) && (p.page_block_size % 16) == 0);
+    constexpr int RPS = 64 / CPR;                           // rows per load step
+    static_assert(16 % RPS == 0 || RPS > 16, "a load step stays inside a 16-row half");
     // a full, page-aligned tile: ONE scalar base per tile, no predication, no branch (so that the
     // compiler can count the loads in flight: see the steady-state loop below)
     auto load_fast = [&](int tile, u32x4 (&kreg)[CH], u32x4 (&vreg)[CH]) {
         const int pos0 = lp + tile * BN;
         int64_t ko, vo;
+        int64_t ko2 = 0, vo2 = 0;                              // second 16-row half of a 32-key tile (its own page when pages are 16 tokens)
         if (PAGED) {
             const int pg = da.page_shift >= 0 ? (pos0 >> da.page_shift) : pos0 / p.page_block_size;
             const int pr = pos0 - pg * p.page_block_size;
@@ -251,18 +256,28 @@ __global__ void __launch_bounds__(64 * NW, 1) fa_decode_kernel(const DecArgs da)
             const int64_t phys = FA_DEC_UNIFORM(btab_c[pg]);
             ko = phys * p.k_batch_stride + (int64_t)pr * p.k_row_stride;
             vo = phys * p.v_batch_stride + (int64_t)pr * p.v_row_stride;
+            if (BN > 16) {
+                const int pos1 = pos0 + 16;
+                const int pg1 = da.page_shift >= 0 ? (pos1 >> da.page_shift) : pos1 / p.page_block_size;
+                const int64_t phys1 = FA_DEC_UNIFORM(btab_c[pg1]);
+                // (base of the half minus its 16 rows: the lane offsets count rows from the tile's first row)
+                ko2 = phys1 * p.k_batch_stride + (int64_t)(pos1 - pg1 * p.page_block_size - 16) * p.k_row_stride;
+                vo2 = phys1 * p.v_batch_stride + (int64_t)(pos1 - pg1 * p.page_block_size - 16) * p.v_row_stride;
+            }
         } else {
             ko = (int64_t)cb * p.k_batch_stride + (int64_t)pos0 * p.k_row_stride;
             vo = (int64_t)cb * p.v_batch_stride + (int64_t)pos0 * p.v_row_stride;
         }
         const uint8_t* kb = kbase + ko * EB;
         const uint8_t* vb = vbase + vo * EB;
+        const uint8_t* kb2 = PAGED && BN > 16 ? kbase + ko2 * EB : kb;
+        const uint8_t* vb2 = PAGED && BN > 16 ? vbase + vo2 * EB : vb;
         // (the empty asm keeps the zero-extension of the 32-bit lane offset next to the load: hoisted out of the loop as a
         //  64-bit pair it cost a v_lshl_add_u64 per load and 16 registers; here the load takes SGPR base + 32-bit VGPR offset)
 #pragma unroll
-        for (int i = 0; i < CH; ++i) { uint32_t o = k_voff[i]; FA_DEC_PIN(o); kreg[i] = *reinterpret_cast<const u32x4*>(kb + o); }
+        for (int i = 0; i < CH; ++i) { uint32_t o = k_voff[i]; FA_DEC_PIN(o); kreg[i] = *reinterpret_cast<const u32x4*>((i * RPS >= 16 ? kb2 : kb) + o); }
 #pragma unroll
-        for (int i = 0; i < CH; ++i) { uint32_t o = v_voff[i]; FA_DEC_PIN(o); vreg[i] = *reinterpret_cast<const u32x4*>(vb + o); }
+        for (int i = 0; i < CH; ++i) { uint32_t o = v_voff[i]; FA_DEC_PIN(o); vreg[i] = *reinterpret_cast<const u32x4*>((i * RPS >= 16 ? vb2 : vb) + o); }
     };
     (void)cok; (void)zero4;
     auto load_tile = [&](int tile, u32x4 (&kreg)[CH], u32x4 (&vreg)[CH]) {

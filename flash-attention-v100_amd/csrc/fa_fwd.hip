@@ -243,8 +243,13 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : FA_FWD_OCC)) fa_fw
     // Paged K/V, aligned case (a 64-key tile never straddles a page: page % 64 == 0 by contract and the left
     // pad is a multiple of 64): the same LDS-DMA as the contiguous path through a per-tile descriptor built
     // from ONE block-table lookup; otherwise the per-row path in store_tile.
-    const bool paged_aligned = PAGED && (k_row0 % FWD_BN == 0) && (p.page_block_size % FWD_BN == 0);
-    const bool paged_dma = paged_aligned && !KV8;
+    const bool paged_aligned = PAGED && (k_row0 % FWD_BN == 0) && (p.page_block_size % FWD_BN == 0);      // (fp8 path)
+    // 16-bit path: a wave's LDS-DMA instructions cover rows 16 w .. 16 w + 15 of the tile (at every head dim), so pages of
+    // 16 tokens and more work with ONE block-table entry per wave and tile: each wave builds its own descriptor
+    const bool paged_dma = PAGED && !KV8 && (k_row0 % 16 == 0) && (p.page_block_size % 16 == 0);
+    static_assert(FWD_BN != 64 || (CHUNKS * (64 / (D / 8))) == 16, "a wave's DMA instructions span one 16-row quarter of a 64-key tile");
+    // this wave's first row in a tile - or 0 when a whole tile lies in one page (one descriptor for the four waves, as before)
+    const int pf_row = (PAGED && !KV8 && FWD_BN == 64 && (p.page_block_size % FWD_BN != 0 || k_row0 % FWD_BN != 0)) ? 16 * wave : 0;
     const __amdgpu_buffer_rsrc_t k_rsrc = make_rsrc(kp, p.k_row_stride, PAGED ? 0 : seqlen_k, dv);
     const __amdgpu_buffer_rsrc_t v_rsrc = make_rsrc(vp, p.v_row_stride, PAGED ? 0 : seqlen_k, dv);
     const uint32_t k_tile_bytes = (uint32_t)(FWD_BN * p.k_row_stride * 2);
@@ -262,7 +267,8 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : FA_FWD_OCC)) fa_fw
     const const_i32_ptr btab_c = (const_i32_ptr)(uintptr_t)btab;
     int pf_phys = 0;
     auto pf_request = [&](int nb1) {
-        const int pos1 = nb1 * FWD_BN + (int)k_row0;
+        int pos1 = nb1 * FWD_BN + pf_row;
+        pos1 = (pos1 < seqlen_k ? pos1 : (seqlen_k > 0 ? seqlen_k - 1 : 0)) + (int)k_row0;      // (a quarter past the sequence: any valid entry - its rows are out of range)
         pf_phys = btab_c[page_shift >= 0 ? (pos1 >> page_shift) : pos1 / p.page_block_size];
     };
     // issue the loads of tile nb; for the DMA path they land directly in LDS stage `stage`
@@ -317,9 +323,9 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : FA_FWD_OCC)) fa_fw
         }
         if (PAGED && paged_dma) {
             const int n0 = nb * FWD_BN;
-            const int pos0 = n0 + (int)k_row0;
+            const int pos0 = n0 + (int)k_row0 + pf_row;                       // this wave's quarter of the tile
             const int pg = page_shift >= 0 ? (pos0 >> page_shift) : pos0 / p.page_block_size;
-            const int pr = pos0 - pg * p.page_block_size;
+            const int pr = pos0 - pg * p.page_block_size - pf_row;            // (the lane offsets count rows from the tile's first row)
             // the block-table entry of THIS tile was looked up one tile ago (pf_phys): with the lookup at the top of the
             // step its round trip sat in front of every tile's DMA issue (chunked prefill over a paged cache ran 12-33 %
             // behind a contiguous one: tools/chunked_prefill_probe.py); the entry of the next tile is requested below
@@ -677,7 +683,7 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : FA_FWD_OCC)) fa_fw
     };
 
     if (n_min < n_max) {
-        if (PAGED && paged_aligned) pf_request(n_min);
+        if (PAGED && (paged_aligned || paged_dma)) pf_request(n_min);
         load_tile(n_min, std::integral_constant<int, 0>{});
         store_tile(std::integral_constant<int, 0>{}, n_min);
     }

@@ -211,7 +211,7 @@ def varlen_case(rng, idx, long=False):
         extra["seqused_k"] = torch.tensor(used, dtype=torch.int32, device="cuda")
         kw["seqused_k"] = np.asarray(used, dtype=np.int32)
     if paged:
-        page = int(rng.choice([64, 128, 256]))
+        page = int(rng.choice([16, 32, 64, 128, 256]))
         per = [(l + page - 1) // page for l in lens_k]
         total = sum(per) + 2
         perm = torch.randperm(total, generator=torch.Generator().manual_seed(s)).tolist()
@@ -266,7 +266,7 @@ def kvcache_case(rng, idx):
     Tq = int(rng.choice([1, 1, 1, 2, 5, 33, 70, 130]))
     Tn = Tq if rng.random() < 0.7 else 0
     paged = rng.random() < 0.4
-    page = int(rng.choice([64, 128, 256]))
+    page = int(rng.choice([16, 32, 64, 128, 256]))
     Smax = int(rng.choice([256, 512, 768, 1024]))
     if Smax < Tn + 64:
         Smax = 512

@@ -72,10 +72,10 @@ def test_kvcache_vs_oracle(case):
     assert_lse_close(f64(lse), lse_ref, "lse", atol=2e-2 if rd else 2e-3)
 
 
-@pytest.mark.parametrize("page", [64, 256])
+@pytest.mark.parametrize("page", [64, 256, 16, 32, 80])
 def test_kvcache_paged_with_rotary(page):
     B, Hq, Hk, D, dt = 4, 8, 2, 128, "fp16"
-    pages_per_seq = 1024 // page
+    pages_per_seq = -(-1024 // page)
     nblk = B * pages_per_seq + 5
     kc = rand16((nblk, page, Hk, D), dt, 2)
     vc = rand16((nblk, page, Hk, D), dt, 3)

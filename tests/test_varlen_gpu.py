@@ -61,7 +61,7 @@ def test_varlen_fwd_bwd_vs_oracle(case):
     assert_close(f64(dv), dv_r, dt, "dv", mult=2.0)
 
 
-@pytest.mark.parametrize("page,D", [(64, 128), (256, 128), (128, 96), (64, 64)])
+@pytest.mark.parametrize("page,D", [(64, 128), (256, 128), (128, 96), (64, 64), (16, 128), (32, 64), (48, 128)])
 def test_varlen_paged_kv(page, D):
     lens_q, lens_k = [70, 1, 300], [200, 513, 300]
     Hq, Hk, dt = 4, 2, "fp16"
