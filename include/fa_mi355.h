@@ -116,7 +116,7 @@ typedef struct fa_params {
     /* ---- paged KV ---- */
     const int32_t* block_table;     /* [B, max_blocks] or NULL */
     int64_t        block_table_batch_stride;
-    int32_t        page_block_size;
+    int32_t        page_block_size;   /* tokens per page: any multiple of 16 */
     int32_t        head_dim_v;      /* valid columns of every row (multiple of 8, <= head_dim); 0 = head_dim.
                                        Columns [head_dim_v, head_dim) are read as zero and never written: odd
                                        head dims (40, 80, 96, 192 ...) run on the next kernel width without
