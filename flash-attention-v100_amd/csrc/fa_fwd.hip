@@ -271,6 +271,17 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : FA_FWD_OCC)) fa_fw
         pos1 = (pos1 < seqlen_k ? pos1 : (seqlen_k > 0 ? seqlen_k - 1 : 0)) + (int)k_row0;      // (a quarter past the sequence: any valid entry - its rows are out of range)
         pf_phys = btab_c[page_shift >= 0 ? (pos1 >> page_shift) : pos1 / p.page_block_size];
     };
+    // fp8 path with small pages: one entry per (wave, chunk step)
+    const bool paged_q16 = PAGED && KV8 && !paged_aligned && (k_row0 % 16 == 0) && (p.page_block_size % 16 == 0);
+    int pf8[KV8 ? CH8 : 1] = {};
+    auto pf8_request = [&](int nb1) {
+#pragma unroll
+        for (int i = 0; i < (KV8 ? CH8 : 1); ++i) {
+            int pos1 = nb1 * FWD_BN + (((64 * wave + i * FWD_THREADS) / CPR8) & ~15);
+            pos1 = (pos1 < seqlen_k ? pos1 : (seqlen_k > 0 ? seqlen_k - 1 : 0)) + (int)k_row0;
+            pf8[i] = btab_c[page_shift >= 0 ? (pos1 >> page_shift) : pos1 / p.page_block_size];
+        }
+    };
     // issue the loads of tile nb; for the DMA path they land directly in LDS stage `stage`
     auto load_tile = [&](int nb, auto stage_c) {
         constexpr int stage = decltype(stage_c)::value;
@@ -296,6 +307,29 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : FA_FWD_OCC)) fa_fw
                     }
                 }
                 pf_request(nb + 1 < n_max ? nb + 1 : nb);
+                return;
+            }
+            if (PAGED && paged_q16) {
+                // pages of 16 tokens and more (not a multiple of the tile): the rows a wave fetches with its chunk i lie in one
+                // 16-row quarter of the tile - ONE entry per (wave, i), requested one tile ago (scalars)
+#pragma unroll
+                for (int i = 0; i < CH8; ++i) {
+                    const int c8 = tid + i * FWD_THREADS;
+                    const int row = c8 / CPR8, cc8 = c8 % CPR8;
+                    const int q16 = ((64 * wave + i * FWD_THREADS) / CPR8) & ~15;       // wave-uniform
+                    const int pos = n0 + (int)k_row0 + q16;
+                    const int pg = page_shift >= 0 ? (pos >> page_shift) : pos / p.page_block_size;
+                    const int64_t phys = pf8[i];
+                    const uint8_t* kpg = kp8 + phys * p.k_batch_stride + (int64_t)(pos - pg * p.page_block_size - q16) * p.k_row_stride;
+                    const uint8_t* vpg = vp8 + phys * p.v_batch_stride + (int64_t)(pos - pg * p.page_block_size - q16) * p.v_row_stride;
+                    u32x4 z = {0, 0, 0, 0};
+                    k8reg[i] = z; v8reg[i] = z;
+                    if (n0 + row < seqlen_k && cc8 * 16 < dv) {
+                        k8reg[i] = *reinterpret_cast<const u32x4*>(kpg + (int64_t)row * p.k_row_stride + cc8 * 16);
+                        v8reg[i] = *reinterpret_cast<const u32x4*>(vpg + (int64_t)row * p.v_row_stride + cc8 * 16);
+                    }
+                }
+                pf8_request(nb + 1 < n_max ? nb + 1 : nb);
                 return;
             }
 #pragma unroll
@@ -684,6 +718,7 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : FA_FWD_OCC)) fa_fw
 
     if (n_min < n_max) {
         if (PAGED && (paged_aligned || paged_dma)) pf_request(n_min);
+        if (PAGED && paged_q16) pf8_request(n_min);
         load_tile(n_min, std::integral_constant<int, 0>{});
         store_tile(std::integral_constant<int, 0>{}, n_min);
     }

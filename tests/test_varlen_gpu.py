@@ -208,6 +208,8 @@ def test_varlen_mixed_batch_splits_between_the_kernels(qlens, Hq, Hk, D, dt, pag
     ([1] * 6, 32, 8, 128, 256, True),                       # uniform decode through the varlen op: decode kernels
     ([1] * 9 + [260, 1, 2], 16, 4, 128, 256, True),         # mixed batch: both
     ([40, 200, 1], 4, 4, 64, 64, False),                    # D = 64, non-causal
+    ([70, 1, 300, 129], 8, 2, 128, 16, True),               # 16-token pages: one entry per (wave, chunk step)
+    ([150, 33], 4, 4, 64, 32, True),                        # D = 64, 32-token pages
 ])
 def test_varlen_paged_fp8_kv(qlens, Hq, Hk, D, page, causal):
     """Paged fp8-e4m3 K / V through the varlen op (this build's extension, as in flash_attn_with_kvcache: value = code x
