@@ -976,10 +976,11 @@ __host__ __device__ inline bool gemv_tm_applicable(const fa_params& p) {
     if (p.nheads_k < 1 || p.nheads_q % p.nheads_k) return false;
     const int G = p.nheads_q / p.nheads_k;
     // (GQA groups up to 4: VALU-bound - H 32/8, round 2: fp8 4.0 vs 3.7 TB/s on the MFMA kernel, fp16 5.6 vs 5.4)
-    if (!(G == 1 || G == 2 || G == 4)) return false;
-    // fp8 caches at G = 4 are VALU-bound here (4.0-4.4 TB/s): since the MFMA decode kernel runs two waves per SIMD it is
-    // 3-43 % faster on them (H 32/8: B 64 285 -> 223 us, B 8 55 -> 38, B 1 over 32 k 52 -> 30); 16-bit caches and G <= 2 stay
-    if (kv8 && G == 4) return false;
+    // Groups of 1 and 2.  Groups of 4 were VALU-bound here (fp8 4.0-4.4 TB/s, 16 bit 5.5): since the MFMA decode kernel runs
+    // two waves per SIMD it is 3-43 % faster on fp8 caches (H 32/8: B 64 285 -> 223 us, B 8 55 -> 38, B 1 over 32 k 52 -> 30)
+    // and 4-9 % on 16-bit ones (B 1 33.0 -> 30.0, B 8 61.4 -> 57.4, B 64 389 -> 372; B 32 196 vs 200), and pages of 16
+    // tokens cost it nothing (this kernel restarts its pipeline per page: + 12 %)
+    if (!(G == 1 || G == 2)) return false;
 #ifdef FA_EXP_TM16_MAXG                 // experiment builds (tools/define_variant.py): 16-bit caches above this group size -> MFMA kernel
     if (!kv8 && G > FA_EXP_TM16_MAXG) return false;
 #endif
@@ -1367,8 +1368,8 @@ static int launch_decode_td(DecArgs& da, hipStream_t stream) {
                 if (paged) hipLaunchKernelGGL((fa_decode_gemv_tm_kernel<T, true, KV8_, G_>), grid_tm, dim3(GEMV_THREADS), 0, stream, da);  \
                 else       hipLaunchKernelGGL((fa_decode_gemv_tm_kernel<T, false, KV8_, G_>), grid_tm, dim3(GEMV_THREADS), 0, stream, da); \
             } while (0)
-            if (kv8) { if (da.group == 1) FA_LAUNCH_TM(true, 1); else if (da.group == 2) FA_LAUNCH_TM(true, 2); else FA_LAUNCH_TM(true, 4); }
-            else { if (da.group == 1) FA_LAUNCH_TM(false, 1); else if (da.group == 2) FA_LAUNCH_TM(false, 2); else FA_LAUNCH_TM(false, 4); }
+            if (kv8) { if (da.group == 1) FA_LAUNCH_TM(true, 1); else FA_LAUNCH_TM(true, 2); }
+            else { if (da.group == 1) FA_LAUNCH_TM(false, 1); else FA_LAUNCH_TM(false, 2); }
 #undef FA_LAUNCH_TM
             if (da.n_splits > 1) launch_decode_combine<T>(da, stream);
             return 0;
