@@ -84,3 +84,57 @@ def test_decode_partials_workspace(lib):
     assert q(ctypes.byref(_decode(lib, 16, 32, 32, 4096, False, num_splits=1))) == 0                         # one partial = written in place
     # four kv-heads with fp8: the head-major kernel, splits only
     assert q(ctypes.byref(_decode(lib, 16, 4, 4, 4096, True, num_splits=5))) == 5 * per_part(16, 4)
+
+
+def _varlen_paged(lib, B, total_q, max_q, H, Hk, D=128, page=256, max_k=8192, kv8=False):
+    p = lib.FaParams()
+    p.dtype = lib.FA_BF16
+    p.kv_dtype = lib.FA_FP8_E4M3 if kv8 else lib.FA_BF16
+    p.batch, p.nheads_q, p.nheads_k, p.seqlen_q, p.seqlen_k, p.head_dim = B, H, Hk, max_q, max_k, D
+    p.total_q = total_q
+    p.q_row_stride, p.q_head_stride = H * D, D
+    p.o_row_stride, p.o_head_stride = H * D, D
+    p.k_batch_stride = p.v_batch_stride = page * Hk * D
+    p.k_row_stride = p.v_row_stride = Hk * D
+    p.k_head_stride = p.v_head_stride = D
+    p.lse_head_stride = total_q
+    p.page_block_size = page
+    p.block_table_batch_stride = max_k // page
+    dummy = (ctypes.c_int32 * 8)()
+    p.cu_seqlens_q = p.cu_seqlens_k = p.block_table = ctypes.addressof(dummy)     # (host logic only tests for NULL)
+    p._keep = dummy
+    p.is_causal = 1
+    p.window_left = p.window_right = -1
+    p.softmax_scale = D ** -0.5
+    p.k_descale = p.v_descale = 1.0
+    return p
+
+
+def test_varlen_forward_workspace_marks_the_decode_routes(lib):
+    """fa_fwd_workspace_bytes is how a caller learns that fa_varlen_fwd can hand a call (or its short sequences) to the decode
+    kernels (fa_api.hip: varlen_decode_route, varlen_mixed_route) - pure host logic on sizes the host can see."""
+    q = lib.lib.fa_fwd_workspace_bytes
+    per_part = lambda rows: rows * (128 + 1) * 4
+    # dense calls never ask
+    assert q(ctypes.byref(_dense(lib, 8, 4096, 16, 16, 128))) == 0
+    # uniform decode through the varlen op: batch 2, one token each, H 32/8 over 8 k -> split until the chip is full
+    n = q(ctypes.byref(_varlen_paged(lib, 2, 2, 1, 32, 8)))
+    assert n > 0 and n % per_part(2 * 32 * 1) == 0
+    # uniform 4 speculative tokens
+    n = q(ctypes.byref(_varlen_paged(lib, 2, 8, 4, 32, 8)))
+    assert n > 0 and n % per_part(2 * 32 * 4) == 0
+    # a big uniform decode batch: one partial, written in place
+    assert q(ctypes.byref(_varlen_paged(lib, 512, 512, 1, 32, 8))) == 0
+    # ragged prefill (8 prompts averaging 1000 rows): the general kernel alone
+    assert q(ctypes.byref(_varlen_paged(lib, 8, 8000, 2048, 32, 8))) == 0
+    # mixed: 12 decode sequences + one 300-token chunk -> partial rows for T = min(8, 32 / G) = 8 positions per sequence
+    n = q(ctypes.byref(_varlen_paged(lib, 13, 312, 300, 32, 8)))
+    assert n > 0 and n % per_part(13 * 32 * 8) == 0
+    # G = 8 -> T = 4
+    n = q(ctypes.byref(_varlen_paged(lib, 13, 312, 300, 64, 8)))
+    assert n > 0 and n % per_part(13 * 64 * 4) == 0
+    # too few sequences for the mixed route, and unpaged K / V, ask for nothing
+    assert q(ctypes.byref(_varlen_paged(lib, 3, 302, 300, 32, 8))) == 0
+    p = _varlen_paged(lib, 13, 312, 300, 32, 8)
+    p.block_table = None
+    assert q(ctypes.byref(p)) == 0
