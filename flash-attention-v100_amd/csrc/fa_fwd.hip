@@ -98,6 +98,15 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : FA_FWD_OCC)) fa_fw
     }
     if (a.kv_batch_idx) kv_b = a.kv_batch_idx[w.b];
     if (a.leftpad_k) k_row0 += a.leftpad_k[w.b];
+    // workgroup-uniform by construction (everything above hangs off w.b) - said explicitly, so that the per-tile address and
+    // descriptor arithmetic of the paged path stays on the scalar unit: without it ~100 VALU instructions and five
+    // v_readfirstlane sat between the barrier and every tile's DMA issue (paged prefill 15 % behind a contiguous cache
+    // even with ONE page per sequence, tools: page = whole cache)
+    seqlen_k = __builtin_amdgcn_readfirstlane(seqlen_k);
+    seqlen_q = __builtin_amdgcn_readfirstlane(seqlen_q);
+    kv_b = __builtin_amdgcn_readfirstlane(kv_b);
+    k_row0 = (int64_t)__builtin_amdgcn_readfirstlane((int)k_row0);
+    q_row0 = (int64_t)__builtin_amdgcn_readfirstlane((int)q_row0);
 
     const int off = seqlen_k - seqlen_q;               // bottom-right alignment
     const int wl = p.window_left;
@@ -243,11 +252,23 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : FA_FWD_OCC)) fa_fw
     // Paged K/V, aligned case (a 64-key tile never straddles a page: page % 64 == 0 by contract and the left
     // pad is a multiple of 64): the same LDS-DMA as the contiguous path through a per-tile descriptor built
     // from ONE block-table lookup; otherwise the per-row path in store_tile.
+    int page_shift = -1;
+    if (PAGED && (p.page_block_size & (p.page_block_size - 1)) == 0) page_shift = __builtin_ctz(p.page_block_size);
     const bool paged_aligned = PAGED && (k_row0 % FWD_BN == 0) && (p.page_block_size % FWD_BN == 0);      // (fp8 path)
     // 16-bit path: a wave's LDS-DMA instructions cover rows 16 w .. 16 w + 15 of the tile (at every head dim), so pages of
     // 16 tokens and more work with ONE block-table entry per wave and tile: each wave builds its own descriptor
-    const bool paged_dma = PAGED && !KV8 && (k_row0 % 16 == 0) && (p.page_block_size % 16 == 0);
+    // (power-of-two pages: the page index is a shift and the row in the page a mask - an inline integer division costs ~30
+    //  scalar instructions per tile; other page sizes take the per-row path)
+    const bool paged_dma = PAGED && !KV8 && (k_row0 % 16 == 0) && page_shift >= 4;
     static_assert(FWD_BN != 64 || (CHUNKS * (64 / (D / 8))) == 16, "a wave's DMA instructions span one 16-row quarter of a 64-key tile");
+    // uniform (SGPR) copies of the K / V base pointers of this (batch, kv-head) for the per-tile descriptors
+    auto uniform_ptr = [](const void* ptr) {
+        const uint64_t b = reinterpret_cast<uint64_t>(ptr);
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)b);          // (the builtin returns int: no sign extension)
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
+        return ((uint64_t)hi << 32) | lo;
+    };
+    const uint64_t kp_u = uniform_ptr(kp), vp_u = uniform_ptr(vp);
     // this wave's first row in a tile - or 0 when a whole tile lies in one page (one descriptor for the four waves, as before)
     const int pf_row = (PAGED && !KV8 && FWD_BN == 64 && (p.page_block_size % FWD_BN != 0 || k_row0 % FWD_BN != 0)) ? 16 * wave : 0;
     const __amdgpu_buffer_rsrc_t k_rsrc = make_rsrc(kp, p.k_row_stride, PAGED ? 0 : seqlen_k, dv);
@@ -255,8 +276,6 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : FA_FWD_OCC)) fa_fw
     const uint32_t k_tile_bytes = (uint32_t)(FWD_BN * p.k_row_stride * 2);
     const uint32_t v_tile_bytes = (uint32_t)(FWD_BN * p.v_row_stride * 2);
 
-    int page_shift = -1;
-    if (PAGED && (p.page_block_size & (p.page_block_size - 1)) == 0) page_shift = __builtin_ctz(p.page_block_size);
     // paged_dma: block-table entry of the next tile to load, requested one tile ahead through the CONSTANT address space:
     // a uniform constant load is a scalar load (s_load_dword) whose wait the compiler places at the first use.  As a plain
     // C++ load it became a vector load + v_readfirstlane with an `s_waitcnt vmcnt(0)` right behind it - i.e. behind the
@@ -358,16 +377,19 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : FA_FWD_OCC)) fa_fw
         if (PAGED && paged_dma) {
             const int n0 = nb * FWD_BN;
             const int pos0 = n0 + (int)k_row0 + pf_row;                       // this wave's quarter of the tile
-            const int pg = page_shift >= 0 ? (pos0 >> page_shift) : pos0 / p.page_block_size;
-            const int pr = pos0 - pg * p.page_block_size - pf_row;            // (the lane offsets count rows from the tile's first row)
+            const int pr = (pos0 & (p.page_block_size - 1)) - pf_row;         // row in the page (the lane offsets count rows from the tile's first row)
             // the block-table entry of THIS tile was looked up one tile ago (pf_phys): with the lookup at the top of the
             // step its round trip sat in front of every tile's DMA issue (chunked prefill over a paged cache ran 12-33 %
             // behind a contiguous one: tools/chunked_prefill_probe.py); the entry of the next tile is requested below
             const int64_t phys = pf_phys;
             int rows = seqlen_k - n0;
             rows = rows < 0 ? 0 : (rows > FWD_BN ? FWD_BN : rows);
-            const __amdgpu_buffer_rsrc_t kr = make_rsrc(kp + phys * p.k_batch_stride + (int64_t)pr * p.k_row_stride, p.k_row_stride, rows, dv);
-            const __amdgpu_buffer_rsrc_t vr = make_rsrc(vp + phys * p.v_batch_stride + (int64_t)pr * p.v_row_stride, p.v_row_stride, rows, dv);
+            // descriptors on the scalar unit: uniform base pointers (hoisted), one 64-bit multiply-add per tensor, 32-bit extent
+            const uint64_t ka = kp_u + (uint64_t)((phys * p.k_batch_stride + (int64_t)pr * p.k_row_stride) * 2);
+            const uint64_t va = vp_u + (uint64_t)((phys * p.v_batch_stride + (int64_t)pr * p.v_row_stride) * 2);
+            const int kext = ((rows - 1) * (int)p.k_row_stride + dv) * 2, vext = ((rows - 1) * (int)p.v_row_stride + dv) * 2;
+            const __amdgpu_buffer_rsrc_t kr = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(ka), 0, rows > 0 ? kext : 0, 0x00020000);
+            const __amdgpu_buffer_rsrc_t vr = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(va), 0, rows > 0 ? vext : 0, 0x00020000);
             char* base = smem + stage * STAGE;
 #pragma unroll
             for (int i = 0; i < CHUNKS; ++i) buf_load_lds_b128(kr, base + k_lds[i], k_voff[i], 0);
