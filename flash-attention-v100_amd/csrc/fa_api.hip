@@ -96,12 +96,16 @@ static int check_common(const fa_params& p, bool need_out) {
     return FA_OK;
 }
 
-// Flag normalisation (reference: fused_mha_forward.cu:343-352).
+// Flag normalisation (reference: fused_mha_forward.cu:343-352).  A window is dropped only where dropping it cannot
+// change a result: a left window of >= seqlen_k keys never hides one (the smallest j' is seqlen_q - seqlen_k, the largest
+// row seqlen_q - 1), a right window hides key j' > i + wr, i.e. something while wr < seqlen_q - 1.  The reference tests
+// `>= seqlen_k` only, which is the same thing for seqlen_q <= seqlen_k and silently un-masks rows when seqlen_q is larger
+// (divergence 8; what a context-parallel shard looks like: all queries over a slice of the keys).
 static void normalize(fa_params& p, bool kvcache) {
     if (p.seqlen_q == 1 && !p.alibi_slopes) p.is_causal = 0;
     if (kvcache && p.is_causal) p.window_right = 0;
     if (p.window_left >= p.seqlen_k) p.window_left = -1;
-    if (p.window_right >= p.seqlen_k) p.window_right = -1;
+    if (p.window_right >= p.seqlen_k && p.window_right >= p.seqlen_q - 1) p.window_right = -1;
 }
 
 static fa::KArgs make_args(const fa_params& p, int block_m) {
@@ -147,10 +151,11 @@ static bool varlen_decode_route(const fa_params& p, fa_params& d) {
     d = p;
     d.cache_seqlens = p.seqused_k;                       // NULL: cu_seqlens_k differences (dec_cache_len in fa_decode.hip)
     d.seqused_k = nullptr;
-    d.cu_seqlens_q = nullptr;
-    d.q_batch_stride = (int64_t)p.seqlen_q * p.q_row_stride;
-    d.o_batch_stride = (int64_t)p.seqlen_q * p.o_row_stride;
-    d.lse_batch_stride = p.seqlen_q;                     // LSE [H, total_q]: head stride as given
+    // cu_seqlens_q stays: the kernels run in varlen-q mode (DecArgs::cu_q, class bound T = seqlen_q) and take every
+    // sequence's rows and row count from the device.  total_q == batch x max_seqlen_q does NOT prove cu_seqlens_q[-1] ==
+    // total_q - q may carry padding rows behind the last sequence (graph-captured serving steps), and then sequence b is
+    // not at row b T (round-3 advisor finding)
+    d.q_batch_stride = 0; d.o_batch_stride = 0; d.lse_batch_stride = 0;
     d.k_new = d.v_new = nullptr; d.seqlen_new = 0;
     d.rotary_cos = d.rotary_sin = nullptr; d.rotary_dim = 0;
     d.cache_batch_idx = nullptr; d.cache_leftpad = nullptr;
@@ -198,7 +203,12 @@ size_t fa_fwd_workspace_bytes(const fa_params* p) {
     return 0;
 }
 size_t fa_bwd_workspace_bytes(const fa_params* p) { return p ? fa::bwd_workspace_bytes(*p) : 0; }
-size_t fa_fwd_kvcache_workspace_bytes(const fa_params* p) { return p ? fa::decode_workspace_bytes(*p) : 0; }
+size_t fa_fwd_kvcache_workspace_bytes(const fa_params* pp) {
+    if (!pp) return 0;
+    fa_params p = *pp;                                   // what fa_fwd_kvcache launches with (the decode code reads these fields)
+    p.cu_seqlens_q = p.cu_seqlens_k = p.seqused_k = nullptr;
+    return fa::decode_workspace_bytes(p);
+}
 
 int fa_fwd(const fa_params* pp, void* stream) {
     if (!pp) return fail(FA_ERR_INVALID_ARGUMENT, "params is NULL");

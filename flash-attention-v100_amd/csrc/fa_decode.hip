@@ -16,6 +16,7 @@
 //     scale, v_descale into the final normalisation).
 // ALiBi / softcap: per-element score path of fa_decode_kernel (the token-major kernels step aside).
 // Head dims: widths 64 / 128 / 256 (256: 16-key tiles), narrower rows through the NARROW instantiations.
+#include <atomic>
 #include "fa_common.h"
 #include "fa_rope.h"
 
@@ -755,6 +756,13 @@ __global__ void __launch_bounds__(GEMV_THREADS) fa_decode_gemv_fp8_kernel(const 
     const int tid = threadIdx.x, lane = tid & 63, grp = lane >> 3, sub = lane & 7;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
+    // varlen-q mode (decode through the varlen op): the sequence's ONE row sits at packed row cu_q[b]; sequences that bring
+    // no row (a padded q: cu_q[-1] < total_q) are not ours - uniform per workgroup, before any barrier
+    int64_t q_row0 = 0;
+    if (da.cu_q) {
+        q_row0 = da.cu_q[b];
+        if (da.cu_q[b + 1] - (int)q_row0 != 1) return;
+    }
     const int L = dec_cache_len(p, b);
     const int lp = p.cache_leftpad ? p.cache_leftpad[b] : 0;
     const int cb = p.cache_batch_idx ? p.cache_batch_idx[b] : b;
@@ -770,7 +778,8 @@ __global__ void __launch_bounds__(GEMV_THREADS) fa_decode_gemv_fp8_kernel(const 
     float qs[16];
     {
         const int h = hk;                                   // G == 1
-        const uint16_t* qrow = reinterpret_cast<const uint16_t*>(p.q) + (int64_t)b * p.q_batch_stride + (int64_t)h * p.q_head_stride;
+        const uint16_t* qrow = reinterpret_cast<const uint16_t*>(p.q) + (int64_t)b * p.q_batch_stride + q_row0 * p.q_row_stride +
+                               (int64_t)h * p.q_head_stride;
         const int half = p.rotary_dim >> 1;
         const int pos = L + lp;
         const uint16_t* cosp = reinterpret_cast<const uint16_t*>(p.rotary_cos) + (int64_t)pos * half;
@@ -940,11 +949,12 @@ __global__ void __launch_bounds__(GEMV_THREADS) fa_decode_gemv_fp8_kernel(const 
         const float lse = l_all > 0.f ? (m_all + fast_log2(l_all)) * kLn2 : -INFINITY;
         const int hq = hk;
         if (da.n_splits == 1) {
-            uint16_t* op = reinterpret_cast<uint16_t*>(p.o) + (int64_t)b * p.o_batch_stride + (int64_t)hq * p.o_head_stride;
+            uint16_t* op = reinterpret_cast<uint16_t*>(p.o) + (int64_t)b * p.o_batch_stride + q_row0 * p.o_row_stride +
+                           (int64_t)hq * p.o_head_stride;
             const float val = acc * inv;
             const float other = __shfl_xor(val, 1);
             if ((tid & 1) == 0) *reinterpret_cast<uint32_t*>(op + tid) = E::pack2(val, other);
-            if (tid == 0) p.lse[(int64_t)b * p.lse_batch_stride + (int64_t)hq * p.lse_head_stride] = lse;
+            if (tid == 0) p.lse[(int64_t)b * p.lse_batch_stride + (int64_t)hq * p.lse_head_stride + q_row0] = lse;
         } else {
             const int64_t prow = ((int64_t)split * p.batch + b) * p.nheads_q + hq;
             da.o_partial[prow * D + tid] = acc * inv;
@@ -972,7 +982,7 @@ __host__ __device__ inline int gemv_tm_ksub(const fa_params& p) {
 __host__ __device__ inline bool gemv_tm_applicable(const fa_params& p) {
     const bool kv8 = p.kv_dtype == FA_FP8_E4M3;
     if (!kv8 && p.kv_dtype != p.dtype) return false;
-    if (p.head_dim != 128 || p.head_dim_v != 0 || p.seqlen_q != 1 || p.alibi_slopes || p.softcap > 0.f || p.cu_seqlens_q) return false;
+    if (p.head_dim != 128 || p.head_dim_v != 0 || p.seqlen_q != 1 || p.alibi_slopes || p.softcap > 0.f) return false;
     if (p.nheads_k < 1 || p.nheads_q % p.nheads_k) return false;
     const int G = p.nheads_q / p.nheads_k;
     // (GQA groups up to 4: VALU-bound - H 32/8, round 2: fp8 4.0 vs 3.7 TB/s on the MFMA kernel, fp16 5.6 vs 5.4)
@@ -1026,6 +1036,11 @@ __global__ void __launch_bounds__(GEMV_THREADS) fa_decode_gemv_tm_kernel(const D
     const int ksub = ksub_n == 1 ? 0 : wave / n_hg;
     const int hg_step = ksub_n == 1 ? 4 : n_hg;                   // (with sub-ranges every head group has its waves: one round)
 
+    int64_t q_row0 = 0;                                           // varlen-q mode: as in fa_decode_gemv_fp8_kernel
+    if (da.cu_q) {
+        q_row0 = da.cu_q[b];
+        if (da.cu_q[b + 1] - (int)q_row0 != 1) return;
+    }
     const int L = dec_cache_len(p, b);
     const int lp = p.cache_leftpad ? p.cache_leftpad[b] : 0;
     const int cb = p.cache_batch_idx ? p.cache_batch_idx[b] : b;
@@ -1058,7 +1073,8 @@ __global__ void __launch_bounds__(GEMV_THREADS) fa_decode_gemv_tm_kernel(const D
         uint32_t qh[G][4];                                        // 16-bit caches: the row's packed pairs (v_dot2), scaled after the sum
 #pragma unroll
         for (int gi = 0; gi < G; ++gi) {
-            const uint16_t* qrow = reinterpret_cast<const uint16_t*>(p.q) + (int64_t)b * p.q_batch_stride + (int64_t)(h * G + gi) * p.q_head_stride;
+            const uint16_t* qrow = reinterpret_cast<const uint16_t*>(p.q) + (int64_t)b * p.q_batch_stride + q_row0 * p.q_row_stride +
+                                   (int64_t)(h * G + gi) * p.q_head_stride;
 #pragma unroll
             for (int cpart = 0; cpart < CPL / 8; ++cpart) {
                 const int d_base = CPL * sub + 8 * cpart;
@@ -1213,7 +1229,8 @@ __global__ void __launch_bounds__(GEMV_THREADS) fa_decode_gemv_tm_kernel(const D
             const float inv = l_run[gi] > 0.f ? p.v_descale / l_run[gi] : 0.f;
             const float lse = l_run[gi] > 0.f ? (m_run[gi] + fast_log2(l_run[gi])) * kLn2 : -INFINITY;
             if (da.n_splits == 1) {
-                uint16_t* op = reinterpret_cast<uint16_t*>(p.o) + (int64_t)b * p.o_batch_stride + (int64_t)hq * p.o_head_stride + CPL * sub;
+                uint16_t* op = reinterpret_cast<uint16_t*>(p.o) + (int64_t)b * p.o_batch_stride + q_row0 * p.o_row_stride +
+                               (int64_t)hq * p.o_head_stride + CPL * sub;
 #pragma unroll
                 for (int c8 = 0; c8 < CPL / 8; ++c8) {
                     u32x4 w0;
@@ -1221,7 +1238,7 @@ __global__ void __launch_bounds__(GEMV_THREADS) fa_decode_gemv_tm_kernel(const D
                     for (int x = 0; x < 4; ++x) w0[x] = E::pack2(o[gi][8 * c8 + 2 * x] * inv, o[gi][8 * c8 + 2 * x + 1] * inv);
                     *reinterpret_cast<u32x4*>(op + 8 * c8) = w0;
                 }
-                if (sub == 0) p.lse[(int64_t)b * p.lse_batch_stride + (int64_t)hq * p.lse_head_stride] = lse;
+                if (sub == 0) p.lse[(int64_t)b * p.lse_batch_stride + (int64_t)hq * p.lse_head_stride + q_row0] = lse;
             } else {
                 const int64_t prow = ((int64_t)part * p.batch + b) * p.nheads_q + hq;
                 float* dst = da.o_partial + prow * D + CPL * sub;
@@ -1266,18 +1283,24 @@ bool decode_takes(const fa_params& p) {
     //  4 x the passes - B 1, T_q 512, H 64/8 over 32 k: 0.92 ms against 1.34 -; at two per CU the general path wins)
     const int cus = device_cu_count();
     int64_t factor = fwd_wgs <= cus ? 8 : (fwd_wgs < 2 * cus ? 2 : 1);
-    if (const char* e = getenv("FA_DEC_FACTOR")) factor = atoi(e);          // (experiments: tools/chunked_prefill_probe.py)
+#ifdef FA_EXP_DEC_FACTOR                 // experiment builds only (tools/define_variant.py, tools/chunked_prefill_probe.py)
+    factor = FA_EXP_DEC_FACTOR;
+#endif
     if (row_blocks <= factor * fwd_passes) return true;
     return p.kv_dtype == FA_FP8_E4M3 && row_blocks <= 2;
 }
 
 static int device_cu_count() {
-    static const int n = [] {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
-        return v;
-    }();
-    return n;
+    // per device ordinal: one process may drive several GPUs (cf. FA_SET_LDS_ONCE in fa_common.h)
+    constexpr int MAXDEV = 64;
+    static std::atomic<int> cache[MAXDEV];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) return 256;
+    int v = cache[dev].load(std::memory_order_relaxed);
+    if (v > 0) return v;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+    cache[dev].store(v, std::memory_order_relaxed);
+    return v;
 }
 
 // grid splits of the key range (x up to 4 key sub-ranges per workgroup in the token-major kernel: <= 1024 partial rows per
@@ -1375,7 +1398,7 @@ static int launch_decode_td(DecArgs& da, hipStream_t stream) {
             return 0;
         }
         // fp8 cache, one query row per kv-head, a head layout the token-major kernel does not take: one workgroup per head
-        if (kv8 && da.rows == 1 && da.group == 1 && !da.bias && !da.cu_q) {
+        if (kv8 && da.rows == 1 && da.group == 1 && !da.bias) {
             if (paged) hipLaunchKernelGGL((fa_decode_gemv_fp8_kernel<T, true>), grid, dim3(GEMV_THREADS), 0, stream, da);
             else       hipLaunchKernelGGL((fa_decode_gemv_fp8_kernel<T, false>), grid, dim3(GEMV_THREADS), 0, stream, da);
             if (da.n_splits > 1) launch_decode_combine<T>(da, stream);
@@ -1425,7 +1448,7 @@ int launch_decode_splitkv(const KArgs& a, void* ws, hipStream_t stream) {
     da.rows = p.seqlen_q * da.group;
     da.local = (p.is_causal || p.window_left >= 0 || p.window_right >= 0) ? 1 : 0;
     da.bias = (p.alibi_slopes != nullptr || p.softcap > 0.f) ? 1 : 0;
-    da.cu_q = p.cu_seqlens_q;                         // (NULL except for the mixed-batch route of the varlen op)
+    da.cu_q = p.cu_seqlens_q;                         // (NULL except for the routes of the varlen op)
     da.n_splits = decode_num_partials(p);             // (token-major kernel: grid splits x key sub-ranges; else the grid's y)
     da.ksub = gemv_tm_applicable(p) ? gemv_tm_ksub(p) : 1;
     da.page_shift = -1;

@@ -257,9 +257,9 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : FA_FWD_OCC)) fa_fw
     const bool paged_aligned = PAGED && (k_row0 % FWD_BN == 0) && (p.page_block_size % FWD_BN == 0);      // (fp8 path)
     // 16-bit path: a wave's LDS-DMA instructions cover rows 16 w .. 16 w + 15 of the tile (at every head dim), so pages of
     // 16 tokens and more work with ONE block-table entry per wave and tile: each wave builds its own descriptor
-    // (power-of-two pages: the page index is a shift and the row in the page a mask - an inline integer division costs ~30
-    //  scalar instructions per tile; other page sizes take the per-row path)
-    const bool paged_dma = PAGED && !KV8 && (k_row0 % 16 == 0) && page_shift >= 4;
+    // (power-of-two pages: the page index is a shift and the row in the page a mask; other page sizes - 48, 192, 320 ... - pay
+    //  an inline integer division, ~30 scalar instructions per tile, on the same path)
+    const bool paged_dma = PAGED && !KV8 && (k_row0 % 16 == 0) && (p.page_block_size % 16 == 0);
     static_assert(FWD_BN != 64 || (CHUNKS * (64 / (D / 8))) == 16, "a wave's DMA instructions span one 16-row quarter of a 64-key tile");
     // uniform (SGPR) copies of the K / V base pointers of this (batch, kv-head) for the per-tile descriptors
     auto uniform_ptr = [](const void* ptr) {
@@ -377,7 +377,9 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : FA_FWD_OCC)) fa_fw
         if (PAGED && paged_dma) {
             const int n0 = nb * FWD_BN;
             const int pos0 = n0 + (int)k_row0 + pf_row;                       // this wave's quarter of the tile
-            const int pr = (pos0 & (p.page_block_size - 1)) - pf_row;         // row in the page (the lane offsets count rows from the tile's first row)
+            // row in the page (the lane offsets count rows from the tile's first row); pages that are not a power of two
+            // (192, 320 ...) pay an integer division per tile here and in pf_request - still one descriptor per wave and tile
+            const int pr = (page_shift >= 0 ? (pos0 & (p.page_block_size - 1)) : pos0 % p.page_block_size) - pf_row;
             // the block-table entry of THIS tile was looked up one tile ago (pf_phys): with the lookup at the top of the
             // step its round trip sat in front of every tile's DMA issue (chunked prefill over a paged cache ran 12-33 %
             // behind a contiguous one: tools/chunked_prefill_probe.py); the entry of the next tile is requested below

@@ -54,7 +54,10 @@ def normalize_flags(seqlen_q, seqlen_k, causal, window_left, window_right, has_a
         window_right = 0
     if window_left >= seqlen_k:
         window_left = -1
-    if window_right >= seqlen_k:
+    # the reference drops a right window of >= seqlen_k keys; that is a no-op only while seqlen_q <= seqlen_k
+    # (key j' > i + wr is hidden, j' reaches seqlen_q - 1).  For seqlen_q > seqlen_k the reference un-masks rows the
+    # caller asked to mask; this restatement (and the product) keeps the window there - DESIGN section 5, divergence 8.
+    if window_right >= seqlen_k and window_right >= seqlen_q - 1:
         window_right = -1
     return causal, window_left, window_right
 

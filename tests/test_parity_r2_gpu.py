@@ -511,14 +511,20 @@ def test_rope_append_and_paged_gather_independent_pins(interleaved):
 
 
 # ------------------------------------------------------------------------------------------------ context parallel
+# Sq == Sk / N is the one shape where dropping a shard's right window (>= its local seqlen_k) is harmless; self-attention
+# (Sq == Sk, what training shards) and N = 4 need the window kept (round-3 advisor finding: ranks 0 .. N-2 saw the future)
+_CP_SHAPES = [(512, 1024, 2), (1024, 1024, 2), (768, 1024, 4), (1024, 1024, 4)]
+
+
+@pytest.mark.parametrize("Sq,Sk,N", _CP_SHAPES)
 @pytest.mark.parametrize("causal", [False, True])
-def test_context_parallel_two_shards_on_one_gpu(causal):
+def test_context_parallel_two_shards_on_one_gpu(causal, Sq, Sk, N):
     """the per-rank calls of context_parallel_attention (local attention over a key shard with the shifted causal
-    window) + merge_attention_shards, both shards on one GPU: equals attention over all keys"""
+    window) + merge_attention_shards, all shards on one GPU: equals attention over all keys"""
     from flash_attn_mi355.sharding import merge_attention_shards
     fa = _fa()
     dt = "bf16"
-    B, Sq, Sk, H, Hk, D, N = 2, 512, 1024, 4, 2, 128, 2
+    B, H, Hk, D = 2, 4, 2, 128
     q = rand16((B, Sq, H, D), dt, 1); k = rand16((B, Sk, Hk, D), dt, 2); v = rand16((B, Sk, Hk, D), dt, 3)
     skl = Sk // N
     outs, lses = [], []
@@ -534,14 +540,15 @@ def test_context_parallel_two_shards_on_one_gpu(causal):
     assert_lse_close(f64(lse), lse_ref, "lse", atol=1e-4)
 
 
+@pytest.mark.parametrize("Sq,Sk,N", _CP_SHAPES)
 @pytest.mark.parametrize("causal", [False, True])
-def test_context_parallel_backward_two_shards_on_one_gpu(causal):
-    """the per-rank backward of context_parallel_attention on the HIP path, both shards on one GPU: fa_bwd over each key
-    shard with the MERGED out / lse gives that shard's dk / dv complete, and the two partial dq add up to the full dq
+def test_context_parallel_backward_two_shards_on_one_gpu(causal, Sq, Sk, N):
+    """the per-rank backward of context_parallel_attention on the HIP path, all shards on one GPU: fa_bwd over each key
+    shard with the MERGED out / lse gives that shard's dk / dv complete, and the partial dq add up to the full dq
     (oracle: the unsharded problem)."""
     from flash_attn_mi355 import sharding
     dt = "bf16"
-    B, Sq, Sk, H, Hk, D, N = 2, 512, 1024, 4, 2, 128, 2
+    B, H, Hk, D = 2, 4, 2, 128
     q = rand16((B, Sq, H, D), dt, 1); k = rand16((B, Sk, Hk, D), dt, 2); v = rand16((B, Sk, Hk, D), dt, 3)
     do = rand16((B, Sq, H, D), dt, 4)
     skl = Sk // N
@@ -565,6 +572,32 @@ def test_context_parallel_backward_two_shards_on_one_gpu(causal):
     o1.backward(do)
     assert_close(t(q1.grad), g_ref[0], dt, "dq (autograd)", mult=2.0)
     assert_close(t(k1.grad), g_ref[1], dt, "dk (autograd)", mult=2.0)
+
+
+@pytest.mark.parametrize("Sq,Sk,wr", [(1024, 256, 256), (1024, 256, 700), (1024, 256, 1022), (1024, 256, 1023),
+                                       (300, 64, 64), (300, 64, 298)])
+def test_right_window_longer_than_the_key_side_is_kept(Sq, Sk, wr):
+    """seqlen_q > seqlen_k: a right window of seqlen_k <= wr < seqlen_q - 1 keys still hides keys from the first rows
+    (j - (Sk - Sq) > i + wr).  The reference drops every window >= seqlen_k (fused_mha_forward.cu:343-352) - DESIGN
+    section 5, divergence 8; forward and backward against the oracle, which keeps it."""
+    fa = _fa()
+    dt = "fp16"
+    B, H, D = 1, 2, 128
+    q = rand16((B, Sq, H, D), dt, 1).requires_grad_(True); k = rand16((B, Sk, H, D), dt, 2).requires_grad_(True)
+    v = rand16((B, Sk, H, D), dt, 3).requires_grad_(True); do = rand16((B, Sq, H, D), dt, 4)
+    o, lse, _ = fa.flash_attn_func(q, k, v, window_size=(-1, wr), return_attn_probs=True)
+    o.backward(do)
+    t = lambda x: f64(x.detach()).transpose(0, 2, 1, 3)
+    o_ref, lse_ref, _ = oracle.attn_fwd(t(q), t(k), t(v), D ** -0.5, window=(-1, wr))
+    if wr < Sq - 1:                                                # the window really hides something: row 0 sees
+        n_vis0 = max(0, min(Sk, wr + 1 - (Sq - Sk)))               # keys j <= wr - (Sq - Sk)
+        assert n_vis0 < Sk
+    g_ref = oracle.attn_bwd(t(do), t(q), t(k), t(v), oracle.round_to(o_ref, dt), lse_ref.astype(np.float64), D ** -0.5,
+                            window=(-1, wr))
+    assert_close(t(o), o_ref, dt, "out")
+    assert_close(t(q.grad), g_ref[0], dt, "dq", mult=2.0)
+    assert_close(t(k.grad), g_ref[1], dt, "dk", mult=2.0)
+    assert_close(t(v.grad), g_ref[2], dt, "dv", mult=2.0)
 
 
 # ------------------------------------------------------------------------------------------------ fp8 matrix-vector decode

@@ -61,7 +61,8 @@ def test_varlen_fwd_bwd_vs_oracle(case):
     assert_close(f64(dv), dv_r, dt, "dv", mult=2.0)
 
 
-@pytest.mark.parametrize("page,D", [(64, 128), (256, 128), (128, 96), (64, 64), (16, 128), (32, 64), (48, 128)])
+@pytest.mark.parametrize("page,D", [(64, 128), (256, 128), (128, 96), (64, 64), (16, 128), (32, 64), (48, 128), (192, 128),
+                                     (320, 64)])
 def test_varlen_paged_kv(page, D):
     lens_q, lens_k = [70, 1, 300], [200, 513, 300]
     Hq, Hk, dt = 4, 2, "fp16"
@@ -148,6 +149,55 @@ def test_varlen_decode_runs_the_decode_kernels(Tq, Hq, Hk, D, dt, page, use_sequ
         fi._workspace = orig_ws
     assert_close(f64(out2), o_ref, dt, "out (general kernel)")
     assert_lse_close(f64(lse2), lse_ref, "lse (general kernel)")
+
+
+@pytest.mark.parametrize("Tq,qlens,Hq,Hk,dt,fp8", [
+    (2, [2, 2, 1, 1], 8, 2, "bf16", False),          # the advisor's case: T 8 rows of q, B 4, max 2, cu = [0, 2, 4, 5, 6]
+    (1, [1, 1, 0, 1, 1], 8, 8, "fp16", False),       # token-major kernel, a sequence without a row, one padding row
+    (1, [1, 0, 1, 1], 4, 4, "bf16", True),           # fp8 head-major matrix-vector kernel
+    (1, [1, 1, 1, 0], 32, 16, "bf16", True),         # fp8 token-major, G = 2
+    (4, [4, 1, 3, 4], 16, 2, "fp16", False),         # MFMA decode kernel, G = 8
+])
+def test_varlen_decode_with_padding_rows_in_q(Tq, qlens, Hq, Hk, dt, fp8):
+    """total_q == batch x max_seqlen_q does not prove that sequence b sits at row b T: q may carry padding rows behind
+    cu_seqlens_q[-1] (graph-captured serving steps pad the token dimension) - the reference takes every row offset from
+    cu_seqlens_q on the device (include/template.h:55-69).  The decode route keeps cu_seqlens_q (varlen-q mode); rows past
+    cu_seqlens_q[-1] are never written (NaN canary)."""
+    D, page = 128, 64
+    lens_k = [700, 33, 300, 129, 64][:len(qlens)]
+    B = len(qlens)
+    total_q = B * Tq
+    assert sum(qlens) < total_q and max(qlens) == Tq
+    pps = [(l + page - 1) // page for l in lens_k]
+    nblk = sum(pps) + 1
+    g = torch.Generator().manual_seed(43)
+    perm = iter(torch.randperm(nblk, generator=g).tolist())
+    bt = torch.zeros((B, max(pps)), dtype=torch.int32)
+    for b in range(B):
+        for j in range(pps[b]):
+            bt[b, j] = next(perm)
+    kp = rand16((nblk, page, Hk, D), dt, 11); vp = rand16((nblk, page, Hk, D), dt, 12)
+    kw = {}
+    kp_ref, vp_ref = f64(kp), f64(vp)
+    if fp8:
+        kd, vd = 0.05, 0.04
+        kp8 = (kp.float() / kd).to(torch.float8_e4m3fn); vp8 = (vp.float() / vd).to(torch.float8_e4m3fn)
+        kp_ref, vp_ref = kp8.float().double().cpu().numpy() * kd, vp8.float().double().cpu().numpy() * vd
+        kp, vp = kp8, vp8
+        kw = dict(k_descale=kd, v_descale=vd)
+    q = rand16((total_q, Hq, D), dt, 13)
+    cu_q, cu_k = _cu(qlens), _cu(lens_k)
+    out = torch.full((total_q, Hq, D), float("nan"), dtype=q.dtype, device="cuda")
+    from flash_attn_mi355 import flash_attn_interface as fi
+    o, lse = fi._varlen_forward(q, kp, vp, cu_q, cu_k, Tq, max(lens_k), 0.0, None, True, (-1, -1), 0.0, None, True,
+                                bt.cuda(), out=out, **kw)[:2]
+    assert o.data_ptr() == out.data_ptr()
+    n = sum(qlens)
+    o_ref, lse_ref = oracle.varlen_fwd(f64(q)[:n], kp_ref, vp_ref, cu_q.cpu().numpy(), cu_k.cpu().numpy(), Tq, max(lens_k),
+                                       D ** -0.5, causal=True, block_table=bt.numpy())
+    assert_close(f64(o)[:n], o_ref, dt, "out", mult=3.0 if fp8 else 1.0)
+    assert_lse_close(f64(lse)[:, :n], lse_ref, "lse", atol=3e-2 if fp8 else 2e-3)
+    assert torch.isnan(o[n:]).all(), "padding rows of q were written"
 
 
 @pytest.mark.parametrize("qlens,Hq,Hk,D,dt,page,causal,window,softcap,alibi", [
