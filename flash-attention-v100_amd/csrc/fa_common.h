@@ -135,6 +135,12 @@ __device__ __forceinline__ float select_bits(float x, uint32_t m, uint32_t other
     return __builtin_bit_cast(float, __builtin_amdgcn_bitop3_b32(__builtin_bit_cast(uint32_t, x), m, other, 0xE2));
 }
 
+// max(a, b, c) in one VALU instruction (IEEE maxNum semantics; not volatile: the optimiser may still move / drop it)
+__device__ __forceinline__ float max3_f32(float a, float b, float c) {
+    float d;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ float fast_log2(float x) { return __builtin_amdgcn_logf(x); }
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
@@ -401,6 +407,8 @@ struct KArgs {
     int rope_q;                    // kv-cache general path: fa_fwd_kernel rotates its Q fragments in registers (rotary_cos / sin at
                                    // position cache_seqlens[b] + leftpad (+ row under a causal / local mask), include/rotary.h:176-202)
     int fuse_pre;                  // the dQ kernel computes D = rowsum(dO o O) itself, runs first and writes softmax_d + stats_ws
+    int walk;                      // forward: a workgroup walks `walk` consecutive 128-row blocks of one (sequence, head) (fa_fwd.hip);
+                                   // with it n_qblocks / flat_blocks count RUNS of that many blocks
 };
 
 // ---- ALiBi through the matrix pipe (causal-like masks: every visible key is at or left of the diagonal) ----
