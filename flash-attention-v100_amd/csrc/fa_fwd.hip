@@ -884,6 +884,10 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : ((WALK && D <= 64 
         const long long sb0 = clock64();
         __syncthreads();
         st_bar += clock64() - sb0;
+#elif defined(FA_FWD_KO_BAR)        // timing knock-out: the tile's own loads are waited for, the other waves are not (garbage results)
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#elif defined(FA_FWD_KO_VMWAIT)     // timing knock-out: barrier without waiting for the loads (garbage results)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #else
         __syncthreads();
 #endif
