@@ -217,9 +217,9 @@ def config3(flash_attn, dev):
             "fwd_bwd_ms": round(t_fb, 4), "fwd_bwd_tflops": round(3.5 * flops / t_fb / 1e9, 1)}
 
 
-def config4(flash_attn, dev, kv_dtype):
+def config4(flash_attn, dev, kv_dtype, Hk=32):
     """decode B128 H32 D128 cache 8192 paged(256) + rotary; K+V bytes read once / time"""
-    B, H, Hk, D, L, page = 128, 32, 32, 128, 8192, 256
+    B, H, D, L, page = 128, 32, 128, 8192, 256       # (Hk = 8: SURVEY 8(d)'s GQA variant - the MFMA decode kernel, 4 query heads per kv-head)
     dt = torch.float16
     g = torch.Generator().manual_seed(421)
     pps = (L + 1 + page - 1) // page
@@ -243,7 +243,7 @@ def config4(flash_attn, dev, kv_dtype):
                                                     rotary_interleaved=False, **kw)
     ms = event_time_ms(fn, 10, warm=3)
     nbytes = 2.0 * B * (L + 1) * Hk * D * kc.element_size()
-    return {"workload": f"decode B128 H32 D128 cache 8192 paged(256)+rotary, KV {'fp8-e4m3' if kc.element_size() == 1 else 'fp16'}",
+    return {"workload": f"decode B128 H32{'' if Hk == 32 else '/%d' % Hk} D128 cache 8192 paged(256)+rotary, KV {'fp8-e4m3' if kc.element_size() == 1 else 'fp16'}",
             "ms": round(ms, 4), "kv_bytes": int(nbytes), "achieved_gbs": round(nbytes / ms / 1e6, 1),
             "frac_of_hbm_peak": round(nbytes / ms / 1e6 / PEAK_HBM_GBS, 4)}
 
@@ -473,6 +473,9 @@ def main():
             oc["config4_fp8_kv"] = config4(flash_attn, dev, torch.float8_e4m3fn)
             torch.cuda.empty_cache()
             oc["config4_fp16_kv"] = config4(flash_attn, dev, torch.float16)
+            torch.cuda.empty_cache()
+            oc["config4_hk8_fp8_kv"] = config4(flash_attn, dev, torch.float8_e4m3fn, Hk=8)
+            oc["config4_hk8_fp16_kv"] = config4(flash_attn, dev, torch.float16, Hk=8)
             oc["serving_steps"] = serving_steps(flash_attn, dev)
             torch.cuda.empty_cache()
             if world == 1:

@@ -329,6 +329,32 @@ __device__ __forceinline__ uint32_t fp8x2_to_16bit<bf16_tag>(uint32_t w, bool hi
                          : __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w, 1.0f, false);
     return __builtin_bit_cast(uint32_t, r);
 }
+// Eight values as a SUM of NT e4m3 fragments (byte j of every fragment belongs to value j): each fragment is the round-
+// to-nearest code of what the previous ones left over, so two carry ~2^-8 of the value (bf16's resolution), three ~2^-12
+// (fp16's) - the remainders have their own exponents.  |a| must stay below the format's 448.
+typedef int i32x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+template <int NT>
+__device__ __forceinline__ void fp8_terms8(const float (&a)[8], u32x2 (&out)[NT]) {
+    float r[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = a[j];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        int w0 = 0, w1 = 0;
+        w0 = __builtin_amdgcn_cvt_pk_fp8_f32(r[0], r[1], w0, false);
+        w0 = __builtin_amdgcn_cvt_pk_fp8_f32(r[2], r[3], w0, true);
+        w1 = __builtin_amdgcn_cvt_pk_fp8_f32(r[4], r[5], w1, false);
+        w1 = __builtin_amdgcn_cvt_pk_fp8_f32(r[6], r[7], w1, true);
+        out[t] = u32x2{(uint32_t)w0, (uint32_t)w1};
+        if (t + 1 < NT) {
+            const f32x2_t b0 = __builtin_amdgcn_cvt_pk_f32_fp8(w0, false), b1 = __builtin_amdgcn_cvt_pk_f32_fp8(w0, true);
+            const f32x2_t b2 = __builtin_amdgcn_cvt_pk_f32_fp8(w1, false), b3 = __builtin_amdgcn_cvt_pk_f32_fp8(w1, true);
+            r[0] -= b0[0]; r[1] -= b0[1]; r[2] -= b1[0]; r[3] -= b1[1];
+            r[4] -= b2[0]; r[5] -= b2[1]; r[6] -= b3[0]; r[7] -= b3[1];
+        }
+    }
+}
 template <typename T>
 __device__ __forceinline__ void fp8x16_to_16bit(const u32x4& in, u32x4& lo, u32x4& hi) {
 #pragma unroll

@@ -29,6 +29,9 @@ namespace fa {
 #endif
 #define FA_DEC_UNIFORM(x) (x)
 
+#ifndef FA_DEC_F8M
+#define FA_DEC_F8M 1                           // fp8 caches at D = 128 on the fp8-operand MFMA (0: dequantise to 16 bit while staging)
+#endif
 constexpr int DEC_THREADS = 256;
 constexpr int DEC_BN = 32;                     // keys per wave tile
 constexpr float DEC_RESCALE_THR = 8.0f;        // log2 units
@@ -77,9 +80,18 @@ struct DecArgs {
     float* lse_partial;        // [n_splits, B, Hq, T_q]
 };
 
-template <typename T, int D, bool KV8, bool PAGED, bool NARROW = false, int NW = 4>
+// F8M (fp8 cache, D = 128, eight waves): the cache bytes feed the matrix pipe AS STORED - v_mfma_f32_32x32x16_fp8_fp8 for both
+// GEMMs - instead of being dequantised to 16 bit on their way into LDS (~480 VALU instructions per 8 KiB tile: the kernel
+// was instruction-bound at 5.1 TB/s where the 16-bit cache streams at 5.9).  The 16-bit side of each product travels as an
+// fp8 PAIR so that nothing is lost against the 16-bit path: Q rows are scaled to the e4m3 range per row (the factor joins
+// k_descale in the softmax scale, a lane owns one query row) and split into head + remainder (two fp8 fragments, 3 + 3
+// mantissa bits and the remainder's own exponent: ~2^-8 relative, bf16's resolution), P likewise (its values are <= 2^8
+// under the deferred rescale).  Two MFMAs per k-step instead of one - the matrix pipe idles in decode - and V^T comes out of
+// LDS through ds_read_b64_tr_b8 (tools/probes/probe_fp8_mfma.hip: operand and transpose layouts).
+template <typename T, int D, bool KV8, bool PAGED, bool NARROW = false, int NW = 4, bool F8M = false>
 __global__ void __launch_bounds__(64 * NW, 1) fa_decode_kernel(const DecArgs da) {
     using E = Elem<T>;
+    static_assert(!F8M || (KV8 && D == 128 && NW == 8 && !NARROW), "fp8 MFMA form: fp8 cache, D = 128, eight waves");
     constexpr int KSTEPS = D / 16;
     constexpr int DBLKS = D / 32;
     constexpr int TILE = DecSmem<D, NW>::TILE;
@@ -158,6 +170,17 @@ __global__ void __launch_bounds__(64 * NW, 1) fa_decode_kernel(const DecArgs da)
     // ---- Q fragments (B operand), RoPE applied in registers ----
     constexpr bool Q_LDS = DecSmem<D, NW>::QBYTES > 0;
     u32x4 qf[Q_LDS ? 1 : KSTEPS];
+    float q_unscale = 1.0f;                                 // F8M: what this lane's query row was divided by on its way to fp8
+#ifndef FA_DEC_F8M_TERMS
+#define FA_DEC_F8M_TERMS 2
+#endif
+    constexpr int NTQ = FA_DEC_F8M_TERMS;                   // F8M: fp8 terms per Q element and per probability (2: ~2^-8 relative, 3: ~2^-12)
+    constexpr int NTP = FA_DEC_F8M_TERMS;
+    // e4m3 bottoms out at 2^-9 ABSOLUTE (subnormals), remainders included: the probabilities must not sit near it.  So this form
+    // rescales on every new row maximum (P <= 1 instead of <= 2^8 under the deferred rescale) and converts 2^8 P: what is lost
+    // lies below 2^-17 of the row's largest probability.  The 2^-8 returns in the final normalisation (exact).
+    constexpr float RESCALE_THR = F8M ? 0.0f : DEC_RESCALE_THR;
+    constexpr float P_UP = F8M ? 256.0f : 1.0f;
     {
         const uint16_t* qrow = reinterpret_cast<const uint16_t*>(p.q) + (int64_t)b * p.q_batch_stride +
                                (int64_t)(q_row0 + t_row) * p.q_row_stride + (int64_t)h * p.q_head_stride;
@@ -165,6 +188,8 @@ __global__ void __launch_bounds__(64 * NW, 1) fa_decode_kernel(const DecArgs da)
         const int pos = L + lp + (da.local ? t_row : 0);
         const uint16_t* cosp = reinterpret_cast<const uint16_t*>(p.rotary_cos) + (int64_t)pos * half;
         const uint16_t* sinp = reinterpret_cast<const uint16_t*>(p.rotary_sin) + (int64_t)pos * half;
+        u32x4 xq[F8M ? KSTEPS : 1];
+        float amax = 0.f;
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks) {
             const int d_base = 16 * ks + 8 * g;
@@ -180,9 +205,33 @@ __global__ void __launch_bounds__(64 * NW, 1) fa_decode_kernel(const DecArgs da)
                     rope_chunk<T>(x, xp, cosp, sinp, d_base, p.rotary_dim, p.rotary_interleaved != 0);
                 }
             }
-            if constexpr (Q_LDS) { if (wave == 0) lds_write_b128(smem + DecSmem<D, NW>::QOFF + (ks * 64 + lane) * 16, x); }
+            if constexpr (F8M) {
+                xq[ks] = x;
+#pragma unroll
+                for (int w2 = 0; w2 < 4; ++w2) amax = fmaxf(amax, fmaxf(fabsf(E::lo(x[w2])), fabsf(E::hi(x[w2]))));
+            } else if constexpr (Q_LDS) { if (wave == 0) lds_write_b128(smem + DecSmem<D, NW>::QOFF + (ks * 64 + lane) * 16, x); }
             else qf[ks] = x;
         }
+        if constexpr (F8M) {
+            // the row's largest magnitude -> 384 (e4m3 tops out at 448); head + remainder per element, 8 + 8 bytes per k-step
+            amax = xhalf_max(amax);
+            const float inv_q = amax > 0.f ? 384.0f / amax : 1.0f;
+            q_unscale = amax > 0.f ? amax * (1.0f / 384.0f) : 1.0f;
+#pragma unroll
+            for (int ks = 0; ks < KSTEPS; ++ks) {
+                float a8[8];
+#pragma unroll
+                for (int w2 = 0; w2 < 4; ++w2) { a8[2 * w2] = E::lo(xq[ks][w2]) * inv_q; a8[2 * w2 + 1] = E::hi(xq[ks][w2]) * inv_q; }
+                u32x2 qt[NTQ];
+                fp8_terms8<NTQ>(a8, qt);
+                const u32x4 hl = {qt[0][0], qt[0][1], qt[1][0], qt[1][1]};
+                if (wave == 0) {       // head and second term where the 16-bit form keeps its fragment, a third behind the Q area
+                    lds_write_b128(smem + DecSmem<D, NW>::QOFF + (ks * 64 + lane) * 16, hl);
+                    if constexpr (NTQ > 2) *reinterpret_cast<u32x2*>(smem + DecSmem<D, NW>::QOFF + DecSmem<D, NW>::QBYTES + (ks * 64 + lane) * 8) = qt[NTQ - 1];
+                }
+            }
+        }
+        (void)xq; (void)amax;
     }
     if constexpr (Q_LDS) __syncthreads();
     (void)qf;
@@ -217,10 +266,15 @@ __global__ void __launch_bounds__(64 * NW, 1) fa_decode_kernel(const DecArgs da)
 #ifndef FA_DEC_NS16
 #define FA_DEC_NS16 2
 #endif
+#ifndef FA_DEC_NS8W8
+#define FA_DEC_NS8W8 2                 // fp8 cache, eight waves
+#endif
 #ifndef FA_DEC_NS256
 #define FA_DEC_NS256 1                 // D = 256: two sets spill (172-280 bytes of scratch per lane)
 #endif
-    constexpr int NS = (D > 128 || NW == 8) ? FA_DEC_NS256 : (KV8 ? FA_DEC_NS8 : FA_DEC_NS16);     // (D = 256, eight waves: register budget)
+    // (D = 256, eight waves: register budget - one set; an fp8 tile is half the registers AND half the bytes in flight: two
+    //  at D = 64 - at D = 128 two sets spill 107 registers, and the fp8-operand form stages by LDS-DMA instead)
+    constexpr int NS = (KV8 && NW == 8 && D <= 64) ? FA_DEC_NS8W8 : ((D > 128 || NW == 8) ? FA_DEC_NS256 : (KV8 ? FA_DEC_NS8 : FA_DEC_NS16));
     constexpr int STAGES = DecSmem<D, NW>::STAGES;
     u32x4 kS[NS][CH], vS[NS][CH];
     // loop-invariant per-lane byte offsets inside a tile (row * row_stride + 16-byte column)
@@ -313,13 +367,18 @@ __global__ void __launch_bounds__(64 * NW, 1) fa_decode_kernel(const DecArgs da)
         }
     };
     auto store_tile = [&](int stage, const u32x4 (&kreg)[CH], const u32x4 (&vreg)[CH]) {
-        char* ks = wsm + stage * 2 * TILE;
-        char* vs = ks + TILE;
+        char* ks = wsm + stage * (F8M ? TILE : 2 * TILE);
+        char* vs = ks + (F8M ? TILE / 2 : TILE);
 #pragma unroll
         for (int i = 0; i < CH; ++i) {
             const int cidx = lane + 64 * i;
             const int row = cidx / CPR, cc = cidx % CPR;
-            if (KV8) {
+            if constexpr (F8M) {
+                // the cache bytes as they are: 128-byte rows, 16-byte slots XOR-ed with row bits so that the 8-byte row reads
+                // of S (32 lanes x 32 rows) are 2-way and the transposing reads of P V (8 rows x 16 B per 16 lanes) conflict-free
+                lds_write_b128(ks + row * D + ((cc ^ ((row >> 1) & 7)) << 4), kreg[i]);
+                lds_write_b128(vs + row * D + ((cc ^ ((((row >> 3) & 1) << 2) | (row & 3))) << 4), vreg[i]);
+            } else if (KV8) {
                 u32x4 l0, h0, l1, h1;
                 fp8x16_to_16bit<T>(kreg[i], l0, h0);
                 fp8x16_to_16bit<T>(vreg[i], l1, h1);
@@ -344,26 +403,51 @@ __global__ void __launch_bounds__(64 * NW, 1) fa_decode_kernel(const DecArgs da)
     // brought to log2 units element by element and the exponent's multiplier becomes 1.  A wave-uniform branch: this
     // kernel waits for HBM, not for the VALU.
     const bool bias = da.bias != 0;
-    const float c = bias ? 1.0f : a.scale_log2e * (KV8 ? p.k_descale : 1.0f);
-    const float sc_lin = p.softmax_scale * (KV8 ? p.k_descale : 1.0f);
+    const float c = bias ? 1.0f : a.scale_log2e * (KV8 ? p.k_descale : 1.0f) * q_unscale;
+    const float sc_lin = p.softmax_scale * (KV8 ? p.k_descale : 1.0f) * q_unscale;
     const float slope = (bias && p.alibi_slopes && row_ok) ? p.alibi_slopes[(int64_t)b * p.alibi_batch_stride + h] : 0.f;
     const float cap = p.softcap, rcap = p.softcap > 0.f ? 1.0f / p.softcap : 0.f;
     const int v_rr = (lane & 15) >> 2;
     const int v_cb = (((lane >> 4) & 1) << 5) + ((lane & 3) << 3);
 
     auto compute_tile = [&](int tile, int stage) {
-        const char* ks = wsm + stage * 2 * TILE;
-        const char* vs = ks + TILE;
+        // (F8M: an fp8 tile is half the bytes - the wave's region holds TWO stages of K | V images of TILE / 2 each)
+        const char* ks = wsm + stage * (F8M ? TILE : 2 * TILE);
+        const char* vs = ks + (F8M ? TILE / 2 : TILE);
         const int n0 = tile * BN;
         // S^T[key][row] = K Q^T
         f32x16 s;
 #pragma unroll
         for (int i = 0; i < 16; ++i) s[i] = 0.f;
+        if constexpr (F8M) {
+            // A: key row l31, bytes 16 ksx + 8 g .. + 7 as stored; B: the query row's terms.  All fragment reads of the tile are
+            // issued before the first MFMA (hipcc otherwise runs read -> wait -> MFMA through one temporary: a full LDS round
+            // trip per k-step, and with two waves per SIMD nothing covers it)
+            u32x2 kf[KSTEPS];
+            u32x4 qhl[KSTEPS];
+#pragma unroll
+            for (int ksx = 0; ksx < KSTEPS; ++ksx) {
+                kf[ksx] = *reinterpret_cast<const u32x2*>(ks + l31 * D + ((ksx ^ ((l31 >> 1) & 7)) << 4) + 8 * g);
+                qhl[ksx] = lds_read_b128(smem + DecSmem<D, NW>::QOFF + (ksx * 64 + lane) * 16);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ksx = 0; ksx < KSTEPS; ++ksx) {
+                const long ka = __builtin_bit_cast(long, kf[ksx]);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(ka, __builtin_bit_cast(long, u32x2{qhl[ksx][0], qhl[ksx][1]}), s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(ka, __builtin_bit_cast(long, u32x2{qhl[ksx][2], qhl[ksx][3]}), s, 0, 0, 0);
+                if constexpr (NTQ > 2) {
+                    const u32x2 q3 = *reinterpret_cast<const u32x2*>(smem + DecSmem<D, NW>::QOFF + DecSmem<D, NW>::QBYTES + (ksx * 64 + lane) * 8);
+                    s = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(ka, __builtin_bit_cast(long, q3), s, 0, 0, 0);
+                }
+            }
+        } else {
 #pragma unroll
         for (int ksx = 0; ksx < KSTEPS; ++ksx) {
             const u32x4 kf = lds_read_b128(ks + swz_row_off<D>(l31, 32 * ksx + 16 * g));
             if constexpr (Q_LDS) s = E::mfma(kf, lds_read_b128(smem + DecSmem<D, NW>::QOFF + (ksx * 64 + lane) * 16), s);
             else s = E::mfma(kf, qf[ksx], s);
+        }
         }
         if (bias) {
 #pragma unroll
@@ -392,7 +476,7 @@ __global__ void __launch_bounds__(64 * NW, 1) fa_decode_kernel(const DecArgs da)
         // deferred rescale (as in fa_fwd_kernel): the running max is only raised - and the accumulators only
         // multiplied - when some row of the wave exceeds it by more than 2^DEC_RESCALE_THR
         // (NaN-safe: -inf - -inf compares false -> takes the rescale path)
-        if (!__all(mx - m_run <= DEC_RESCALE_THR)) {
+        if (!__all(mx - m_run <= RESCALE_THR)) {
             const float m_new = fmaxf(m_run, mx);
             const float m_nu = (m_new == -INFINITY) ? 0.f : m_new;
             const float alpha = fast_exp2(m_run - m_nu);
@@ -408,6 +492,44 @@ __global__ void __launch_bounds__(64 * NW, 1) fa_decode_kernel(const DecArgs da)
 #pragma unroll
         for (int i = 0; i < 16; ++i) { s[i] = fast_exp2(fmaf(s[i], c, -m_use)); psum += s[i]; }
         l_run += psum;
+        if constexpr (F8M) {
+            // transposing read: the 16 lanes of a group bring 8 key rows x 16 d-bytes (source lane s: key j = s >> 1 of the k-step's
+            // eight keys in C-layout order, 8-byte half s & 1) and lane 8 h + c receives, for d = 16 (G & 1) + 8 h + c, the bytes
+            // of keys j = 0 .. 7 - exactly the A operand of V^T (row d, contraction = key) in the key order P's registers have
+            const int sl = lane & 15, gg = lane >> 4;
+            const int jj = sl >> 1;
+            const int key_l = (jj & 3) + 8 * (jj >> 2) + 4 * (gg >> 1);                 // + 16 t2
+            const int dby = 16 * (gg & 1) + 8 * (sl & 1);                               // + 32 d
+            typedef __attribute__((address_space(3))) i32x2_t* lds_i32x2_ptr;
+            i32x2_t vt[BN / 16][DBLKS];
+#pragma unroll
+            for (int t2 = 0; t2 < BN / 16; ++t2) {
+                const int key = 16 * t2 + key_l;
+                const int fv = (((key >> 3) & 1) << 2) | (key & 3);
+#pragma unroll
+                for (int d = 0; d < DBLKS; ++d) {
+                    const int slot = (2 * d + (gg & 1)) ^ fv;
+                    vt[t2][d] = __builtin_amdgcn_ds_read_tr8_b64_v2i32((lds_i32x2_ptr)(vs + key * D + (slot << 4) + (dby & 8)));
+                }
+            }
+            u32x2 pt[BN / 16][NTP];
+#pragma unroll
+            for (int t2 = 0; t2 < BN / 16; ++t2) {
+                float p8[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) p8[j] = s[8 * t2 + j] * P_UP;
+                fp8_terms8<NTP>(p8, pt[t2]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t2 = 0; t2 < BN / 16; ++t2)
+#pragma unroll
+                for (int d = 0; d < DBLKS; ++d) {
+                    const long va = __builtin_bit_cast(long, vt[t2][d]);
+#pragma unroll
+                    for (int t = 0; t < NTP; ++t) oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(va, __builtin_bit_cast(long, pt[t2][t]), oacc[d], 0, 0, 0);
+                }
+        } else
 #pragma unroll
         for (int t2 = 0; t2 < BN / 16; ++t2) {
             u32x4 pf;
@@ -426,6 +548,68 @@ __global__ void __launch_bounds__(64 * NW, 1) fa_decode_kernel(const DecArgs da)
 
     const int t0 = s_lo + wave;
     const int n_my = t0 < s_hi ? (s_hi - t0 + NW - 1) / NW : 0;
+    if constexpr (F8M) {
+        // The cache bytes go HBM -> LDS by LDS-DMA (buffer_load ... lds: no staging registers), two stages per wave: tile s + 1
+        // lands while tile s is computed, behind a COUNTED vmcnt (the 8 pieces of the younger tile stay in flight).  The
+        // destination is lane-linear (lane l of piece i -> row 8 i + l / 8, 16-byte slot l % 8), so the images' slot XORs
+        // are applied to the source column.  Ragged / unaligned tiles (a sequence's last one) take the register path.
+        uint32_t k_dma[CH], v_dma[CH];
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const int row = (lane + 64 * i) / CPR, slot = lane % CPR;
+            k_dma[i] = (uint32_t)(row * p.k_row_stride + ((slot ^ ((row >> 1) & 7)) << 4));
+            v_dma[i] = (uint32_t)(row * p.v_row_stride + ((slot ^ ((((row >> 3) & 1) << 2) | (row & 3))) << 4));
+        }
+        const int n_full_tiles = seqlen_k / BN;                       // tiles that lie completely inside the sequence
+        auto issue = [&](int tile, int stage) -> bool {               // true: by DMA (8 pieces in flight), false: done synchronously
+            char* kdst = wsm + stage * TILE;
+            char* vdst = kdst + TILE / 2;
+            if (!(tiles_aligned && tile < n_full_tiles)) {
+                load_tile(tile, kS[0], vS[0]);
+                store_tile(stage, kS[0], vS[0]);
+                return false;
+            }
+            const int pos0 = lp + tile * BN;
+            int64_t ko, vo, ko2 = 0, vo2 = 0;
+            if (PAGED) {
+                const int pg = da.page_shift >= 0 ? (pos0 >> da.page_shift) : pos0 / p.page_block_size;
+                const int pr = pos0 - pg * p.page_block_size;
+                const int64_t phys = btab_c[pg];
+                ko = phys * p.k_batch_stride + (int64_t)pr * p.k_row_stride;
+                vo = phys * p.v_batch_stride + (int64_t)pr * p.v_row_stride;
+                const int pos1 = pos0 + 16;
+                const int pg1 = da.page_shift >= 0 ? (pos1 >> da.page_shift) : pos1 / p.page_block_size;
+                const int64_t phys1 = btab_c[pg1];
+                ko2 = phys1 * p.k_batch_stride + (int64_t)(pos1 - pg1 * p.page_block_size - 16) * p.k_row_stride;
+                vo2 = phys1 * p.v_batch_stride + (int64_t)(pos1 - pg1 * p.page_block_size - 16) * p.v_row_stride;
+            } else {
+                ko = (int64_t)cb * p.k_batch_stride + (int64_t)pos0 * p.k_row_stride;
+                vo = (int64_t)cb * p.v_batch_stride + (int64_t)pos0 * p.v_row_stride;
+            }
+            auto rsrc_of = [](const uint8_t* ptr) {
+                const uint64_t b64 = reinterpret_cast<uint64_t>(ptr);
+                const uint32_t lo32 = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)b64);
+                const uint32_t hi32 = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(b64 >> 32));
+                return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)hi32 << 32) | lo32), 0, 0x7fffffff, 0x00020000);
+            };
+            const __amdgpu_buffer_rsrc_t kr = rsrc_of(kbase + ko), vr = rsrc_of(vbase + vo);
+            const __amdgpu_buffer_rsrc_t kr2 = PAGED ? rsrc_of(kbase + ko2) : kr, vr2 = PAGED ? rsrc_of(vbase + vo2) : vr;
+#pragma unroll
+            for (int i = 0; i < CH; ++i) buf_load_lds_b128(i * RPS >= 16 ? kr2 : kr, kdst + i * 1024, k_dma[i], 0);
+#pragma unroll
+            for (int i = 0; i < CH; ++i) buf_load_lds_b128(i * RPS >= 16 ? vr2 : vr, vdst + i * 1024, v_dma[i], 0);
+            return true;
+        };
+        bool cur_dma = n_my > 0 ? issue(t0, 0) : false;
+        (void)cur_dma;
+        for (int s1 = 0; s1 < n_my; ++s1) {
+            bool nxt_dma = false;
+            if (s1 + 1 < n_my) nxt_dma = issue(t0 + NW * (s1 + 1), (s1 + 1) & 1);
+            if (nxt_dma) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // (2 x CH pieces of the younger tile may still fly)
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            compute_tile(t0 + NW * s1, s1 & 1);
+        }
+    } else
     if constexpr (STAGES == 1) {
         // eight waves: one LDS stage per wave.  Step s: the set that holds tile s goes to LDS (waits for its loads), the
         // set is re-loaded with tile s + NS, tile s is computed - NS tiles in flight while it runs, and the SIMD's other
@@ -539,7 +723,7 @@ __global__ void __launch_bounds__(64 * NW, 1) fa_decode_kernel(const DecArgs da)
             float l_all = 0.f, sc[NW];
 #pragma unroll
             for (int w2 = 0; w2 < NW; ++w2) { sc[w2] = fast_exp2(mw[w2] - m_s); l_all = fmaf(lw[w2], sc[w2], l_all); }
-            const float inv = l_all > 0.f ? (KV8 ? p.v_descale : 1.0f) / l_all : 0.f;
+            const float inv = l_all > 0.f ? (KV8 ? p.v_descale : 1.0f) / (l_all * P_UP) : 0.f;
             const float lse = l_all > 0.f ? (m_all + fast_log2(l_all)) * kLn2 : -INFINITY;
             const int hq = hk * G + gq3;
             if (da.n_splits == 1) {
@@ -1417,6 +1601,21 @@ static int launch_decode_td(DecArgs& da, hipStream_t stream) {
         // eight waves (two per SIMD, one LDS stage and 256 registers each) or four (one per SIMD, two stages)
         const bool w8 = decode_eight_waves(p);
         if (kv8) {
+#if FA_DEC_F8M
+            if constexpr (D == 128) {
+                // the fp8 cache feeds v_mfma_f32_32x32x16_fp8_fp8 as stored (F8M above); FA_DEC_F8M=0 builds keep the dequantising form
+                if (w8) {
+                    auto kern = paged ? fa_decode_kernel<T, D, true, true, false, 8, true> : fa_decode_kernel<T, D, true, false, false, 8, true>;
+                    const size_t smem_ = DecSmem<D, 8>::QOFF + DecSmem<D, 8>::QBYTES + (D / 16) * 64 * 8;    // (+ the third Q term)
+                    static_assert(DecSmem<D, 8>::QOFF + DecSmem<D, 8>::QBYTES + (D / 16) * 64 * 8 >= DecSmem<D, 8>::MERGE, "merge area");
+                    if (paged) { FA_SET_LDS_ONCE((fa_decode_kernel<T, D, true, true, false, 8, true>), smem_); }
+                    else       { FA_SET_LDS_ONCE((fa_decode_kernel<T, D, true, false, false, 8, true>), smem_); }
+                    hipLaunchKernelGGL(kern, grid, dim3(64 * 8), smem_, stream, da);
+                    if (da.n_splits > 1) launch_decode_combine<T>(da, stream);
+                    return 0;
+                }
+            }
+#endif
             if (w8) { if (paged) FA_LAUNCH_DEC(true, true, false, 8); else FA_LAUNCH_DEC(true, false, false, 8); }
             else    { if (paged) FA_LAUNCH_DEC(true, true, false, 4); else FA_LAUNCH_DEC(true, false, false, 4); }
         } else if (!narrow) {

@@ -653,7 +653,35 @@ def flash_attn_with_kvcache(q, k_cache, v_cache, k=None, v=None, rotary_cos=None
                             alibi_slopes: Optional[torch.Tensor] = None, num_splits: int = 0,
                             return_softmax_lse: bool = False, *,
                             k_descale: Optional[float] = None, v_descale: Optional[float] = None):
-    """FlashAttention with KV cache (B, M, H, D). k_cache / v_cache are updated in place."""
+    """FlashAttention with KV cache (B, M, H, D). k_cache / v_cache are updated in place.
+
+    A decode step is launch-bound at small batch (two kernels of 10-15 us), so the host side matters: the argument checks
+    and the ~60 fields of fa_params depend only on the tensors' GEOMETRY (dtypes, shapes, strides, which optionals are
+    given) and the scalar options - a serving loop repeats one geometry thousands of times.  The filled struct is kept per
+    geometry (`_KV_PLANS`); a repeat call copies it and writes the dozen pointers (tools/host_overhead.py)."""
+    key = _kv_plan_key(q, k_cache, v_cache, k, v, rotary_cos, rotary_sin, cache_seqlens, cache_batch_idx, cache_leftpad,
+                       block_table, softmax_scale, causal, window_size, softcap, rotary_interleaved, alibi_slopes,
+                       num_splits, k_descale, v_descale)
+    plan = _KV_PLANS.get(key) if key is not None else None
+    if plan is not None:
+        tmpl, ws_bytes, lse_shape = plan
+        pp = FaParams.from_buffer_copy(tmpl)
+        out = torch.empty_like(q)
+        lse = torch.empty(lse_shape, dtype=torch.float32, device=q.device)
+        pp.q, pp.k, pp.v, pp.o, pp.lse = q.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), out.data_ptr(), lse.data_ptr()
+        if cache_seqlens is not None: pp.cache_seqlens = cache_seqlens.data_ptr()
+        if block_table is not None: pp.block_table = block_table.data_ptr()
+        if k is not None: pp.k_new = k.data_ptr(); pp.v_new = v.data_ptr()
+        if rotary_cos is not None: pp.rotary_cos = rotary_cos.data_ptr(); pp.rotary_sin = rotary_sin.data_ptr()
+        if cache_batch_idx is not None: pp.cache_batch_idx = cache_batch_idx.data_ptr()
+        if cache_leftpad is not None: pp.cache_leftpad = cache_leftpad.data_ptr()
+        if alibi_slopes is not None: pp.alibi_slopes = alibi_slopes.data_ptr()
+        if ws_bytes:
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=q.device)
+            pp.workspace = ws.data_ptr()
+        with _on_device(q.device):
+            _lib.call("fa_fwd_kvcache", pp, _stream(q.device))
+        return (out, lse) if return_softmax_lse else out
     assert k_cache.stride(-1) == 1, "k_cache must have contiguous last dimension"
     assert v_cache.stride(-1) == 1, "v_cache must have contiguous last dimension"
     _check_device(q, k_cache, v_cache, k, v)
@@ -754,14 +782,42 @@ def flash_attn_with_kvcache(q, k_cache, v_cache, k=None, v=None, rotary_cos=None
         p.rotary_interleaved = int(bool(rotary_interleaved))
     _alibi(p, alibi_slopes, B, H_Q, q.device)
     p.num_splits = int(num_splits)
-    ws = _workspace(_lib.lib.fa_fwd_kvcache_workspace_bytes(ctypes.byref(p)), q.device)
+    ws_bytes = int(_lib.lib.fa_fwd_kvcache_workspace_bytes(ctypes.byref(p)))
+    ws = _workspace(ws_bytes, q.device)
     if ws is not None:
         p.workspace, p.workspace_bytes = _ptr(ws), ws.numel()
     with _on_device(q.device):
         _lib.call("fa_fwd_kvcache", p, _stream(q.device))
+    if key is not None:                                  # (the call went through: this geometry passes every check)
+        if len(_KV_PLANS) >= 256:
+            _KV_PLANS.clear()
+        _KV_PLANS[key] = (bytes(p), ws_bytes, tuple(lse.shape))
     if return_softmax_lse:
         return out, lse
     return out
+
+
+_KV_PLANS = {}
+
+
+def _geom(t):
+    return None if t is None else (t.dtype, t.shape, t.stride(), t.device.index)
+
+
+def _kv_plan_key(q, k_cache, v_cache, k, v, rotary_cos, rotary_sin, cache_seqlens, cache_batch_idx, cache_leftpad,
+                 block_table, softmax_scale, causal, window_size, softcap, rotary_interleaved, alibi_slopes, num_splits,
+                 k_descale, v_descale):
+    """Everything flash_attn_with_kvcache's checks and fa_params fields depend on, except the data pointers - or None
+    when the call needs the slow path anyway (an int cache_seqlens, inputs that must be made contiguous first)."""
+    if not isinstance(q, torch.Tensor) or isinstance(cache_seqlens, int):
+        return None
+    for t in (q, k, v, cache_seqlens, cache_batch_idx, cache_leftpad, block_table):
+        if t is not None and (t.dim() == 0 or t.stride(-1) != 1):
+            return None
+    return (_geom(q), _geom(k_cache), _geom(v_cache), _geom(k), _geom(v), _geom(rotary_cos), _geom(rotary_sin),
+            _geom(cache_seqlens), _geom(cache_batch_idx), _geom(cache_leftpad), _geom(block_table), _geom(alibi_slopes),
+            softmax_scale, bool(causal), tuple(window_size), float(softcap), bool(rotary_interleaved), int(num_splits),
+            k_descale, v_descale)
 
 
 # ======================================================================================

@@ -452,7 +452,11 @@ def test_full_size_config4_decode_paged_rotary_fp8():
                                             causal=True, rotary_interleaved=False, io_dtype=dt,
                                             k_descale=kd, v_descale=vd)
         assert_close(f64(out[b:b + 1]), o_ref, dt, f"out[{b}]", mult=1.5)
-        assert_lse_close(f64(lse[b:b + 1]), lse_ref, f"lse[{b}]", atol=3e-2)
+        # gate 3e-2 = 15 x the 16-bit gate: the APPENDED key reaches the scores as an e4m3 code (2^-4 relative on one of
+        # 8193 logits) while the oracle attends to the 16-bit row; what the kernels actually achieve is printed (pytest -s)
+        # and recorded in profiles/r04_fp8_decode.txt
+        achieved = assert_lse_close(f64(lse[b:b + 1]), lse_ref, f"lse[{b}]", atol=3e-2)
+        print(f"config-4 fp8 decode, batch entry {b}: max |LSE - oracle| = {achieved:.3e} (gate 3e-2)")
         # the appended row: logical position L -> page L // 256, row L % 256 of this entry's table
         phys = int(bt[b, L // page])
         got_k = kc[phys, L % page].float().double().cpu().numpy()
@@ -518,3 +522,40 @@ def test_kvcache_edge_cases():
     kr, vr = f64(kc).copy(), f64(vc).copy()
     o_ref, _ = oracle.kvcache_fwd(f64(q), kr, vr, cache_seqlens=lens, window=(31, 0), io_dtype="fp16")
     assert_close(f64(o), o_ref, "fp16", "out")
+
+
+def test_kvcache_plan_cache_repeats_a_geometry_with_new_tensors():
+    """flash_attn_with_kvcache keeps the filled fa_params per call GEOMETRY (flash_attn_interface._KV_PLANS): a second call with
+    other tensors of the same geometry must use ITS pointers - compared bit for bit with the same call made on an empty plan
+    table - and a call whose geometry differs (another batch size) must not hit the plan."""
+    from flash_attn_mi355 import flash_attn_interface as fi
+    fa = _fa()
+    dt = "bf16"
+    B, Hq, Hk, D, page, pps = 3, 8, 2, 128, 64, 6
+    def mk(seed, B_):
+        nblk = B_ * pps
+        kc = rand16((nblk, page, Hk, D), dt, seed); vc = rand16((nblk, page, Hk, D), dt, seed + 1)
+        bt = torch.randperm(nblk, generator=torch.Generator().manual_seed(seed)).reshape(B_, pps).to(torch.int32).cuda()
+        q = rand16((B_, 1, Hq, D), dt, seed + 2)
+        kn = rand16((B_, 1, Hk, D), dt, seed + 3); vn = rand16((B_, 1, Hk, D), dt, seed + 4)
+        lens = torch.tensor([100 + 37 * i for i in range(B_)], dtype=torch.int32).cuda()
+        return q, kc, vc, kn, vn, lens, bt
+    def call(args):
+        q, kc, vc, kn, vn, lens, bt = args
+        kc, vc = kc.clone(), vc.clone()
+        o, l = fa.flash_attn_with_kvcache(q, kc, vc, k=kn, v=vn, cache_seqlens=lens, block_table=bt, causal=True,
+                                          return_softmax_lse=True)
+        return o, l, kc, vc
+    a1, a2, a3 = mk(10, B), mk(20, B), mk(30, B + 1)
+    fi._KV_PLANS.clear()
+    ref = [call(a) for a in (a2,)]
+    fi._KV_PLANS.clear()
+    call(a1)                                             # fills the plan
+    n_plans = len(fi._KV_PLANS)
+    assert n_plans == 1
+    got = call(a2)                                       # same geometry, other tensors: through the plan
+    assert len(fi._KV_PLANS) == n_plans
+    for x, y in zip(got, ref[0]):
+        assert torch.equal(x, y)
+    call(a3)                                             # another batch size: its own plan
+    assert len(fi._KV_PLANS) == n_plans + 1
