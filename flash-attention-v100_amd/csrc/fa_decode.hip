@@ -88,10 +88,16 @@ struct DecArgs {
 // mantissa bits and the remainder's own exponent: ~2^-8 relative, bf16's resolution), P likewise (its values are <= 2^8
 // under the deferred rescale).  Two MFMAs per k-step instead of one - the matrix pipe idles in decode - and V^T comes out of
 // LDS through ds_read_b64_tr_b8 (tools/probes/probe_fp8_mfma.hip: operand and transpose layouts).
-template <typename T, int D, bool KV8, bool PAGED, bool NARROW = false, int NW = 4, bool F8M = false>
+// HPW ("a head per wave"; eight waves, kv-heads adjacent in a cache row, one 32-row block): the eight waves of a workgroup take
+// eight CONSECUTIVE kv-heads over the SAME key range instead of alternate tiles of one head.  A head's slice of a cache row is
+// 128 / 256 bytes, the next token's slice sits a whole row further: a workgroup that streams one head touches the cache in
+// such pieces (the pure-load ceiling of that pattern was 6.1 TB/s, tools/probes/probe_kv_stream.hip), eight waves side by side
+// read whole rows (7.1).  Every wave owns its head's complete result for the split: no merge, no barrier, Q in registers.
+template <typename T, int D, bool KV8, bool PAGED, bool NARROW = false, int NW = 4, bool F8M = false, bool HPW = false>
 __global__ void __launch_bounds__(64 * NW, 1) fa_decode_kernel(const DecArgs da) {
     using E = Elem<T>;
     static_assert(!F8M || (KV8 && D == 128 && NW == 8 && !NARROW), "fp8 MFMA form: fp8 cache, D = 128, eight waves");
+    static_assert(!HPW || (NW == 8 && D <= 128 && !NARROW), "a head per wave: eight waves");
     constexpr int KSTEPS = D / 16;
     constexpr int DBLKS = D / 32;
     constexpr int TILE = DecSmem<D, NW>::TILE;
@@ -117,9 +123,11 @@ __global__ void __launch_bounds__(64 * NW, 1) fa_decode_kernel(const DecArgs da)
         unit = pair % n_units;
         split = pair / n_units;
     }
-    const int b = unit / p.nheads_k, hk = unit - b * p.nheads_k;
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, g = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int units_per_b = HPW ? p.nheads_k / NW : p.nheads_k;          // HPW: unit = (b, group of NW kv-heads)
+    const int b = unit / units_per_b;
+    const int hk = HPW ? (unit - b * units_per_b) * NW + wave : unit - b * units_per_b;
     char* wsm = smem + wave * DecSmem<D, NW>::WAVE;
 
     const int L = dec_cache_len(p, b);
@@ -168,7 +176,7 @@ __global__ void __launch_bounds__(64 * NW, 1) fa_decode_kernel(const DecArgs da)
     // the missing columns are zeros in Q and in the LDS tiles, and are not written
     const int vcols = NARROW ? p.head_dim_v : D;
     // ---- Q fragments (B operand), RoPE applied in registers ----
-    constexpr bool Q_LDS = DecSmem<D, NW>::QBYTES > 0;
+    constexpr bool Q_LDS = !HPW && DecSmem<D, NW>::QBYTES > 0;          // (HPW: every wave has its own head's rows - registers)
     u32x4 qf[Q_LDS ? 1 : KSTEPS];
     float q_unscale = 1.0f;                                 // F8M: what this lane's query row was divided by on its way to fp8
 #ifndef FA_DEC_F8M_TERMS
@@ -225,7 +233,8 @@ __global__ void __launch_bounds__(64 * NW, 1) fa_decode_kernel(const DecArgs da)
                 u32x2 qt[NTQ];
                 fp8_terms8<NTQ>(a8, qt);
                 const u32x4 hl = {qt[0][0], qt[0][1], qt[1][0], qt[1][1]};
-                if (wave == 0) {       // head and second term where the 16-bit form keeps its fragment, a third behind the Q area
+                if constexpr (!Q_LDS) { static_assert(Q_LDS || NTQ == 2, "register Q fragments: two terms"); qf[ks] = hl; }
+                else if (wave == 0) {  // head and second term where the 16-bit form keeps its fragment, a third behind the Q area
                     lds_write_b128(smem + DecSmem<D, NW>::QOFF + (ks * 64 + lane) * 16, hl);
                     if constexpr (NTQ > 2) *reinterpret_cast<u32x2*>(smem + DecSmem<D, NW>::QOFF + DecSmem<D, NW>::QBYTES + (ks * 64 + lane) * 8) = qt[NTQ - 1];
                 }
@@ -244,7 +253,8 @@ __global__ void __launch_bounds__(64 * NW, 1) fa_decode_kernel(const DecArgs da)
     int tile_hi = (seqlen_k + BN - 1) / BN;
     if (wr >= 0) { const int kmax = t_last + off + wr; const int t2 = kmax < 0 ? 0 : kmax / BN + 1; tile_hi = t2 < tile_hi ? t2 : tile_hi; }
     const int n_all = tile_hi > tile_lo ? tile_hi - tile_lo : 0;
-    const int per_split = ((n_all + da.n_splits - 1) / da.n_splits + NW - 1) / NW * NW;     // multiple of the waves
+    const int per_split = HPW ? (n_all + da.n_splits - 1) / da.n_splits
+                              : ((n_all + da.n_splits - 1) / da.n_splits + NW - 1) / NW * NW;     // multiple of the waves
     const int s_lo = tile_lo + split * per_split;
     int s_hi = s_lo + per_split; s_hi = s_hi < tile_hi ? s_hi : tile_hi;
 
@@ -428,7 +438,8 @@ __global__ void __launch_bounds__(64 * NW, 1) fa_decode_kernel(const DecArgs da)
 #pragma unroll
             for (int ksx = 0; ksx < KSTEPS; ++ksx) {
                 kf[ksx] = *reinterpret_cast<const u32x2*>(ks + l31 * D + ((ksx ^ ((l31 >> 1) & 7)) << 4) + 8 * g);
-                qhl[ksx] = lds_read_b128(smem + DecSmem<D, NW>::QOFF + (ksx * 64 + lane) * 16);
+                if constexpr (Q_LDS) qhl[ksx] = lds_read_b128(smem + DecSmem<D, NW>::QOFF + (ksx * 64 + lane) * 16);
+                else qhl[ksx] = qf[ksx];
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -546,8 +557,9 @@ __global__ void __launch_bounds__(64 * NW, 1) fa_decode_kernel(const DecArgs da)
         }
     };
 
-    const int t0 = s_lo + wave;
-    const int n_my = t0 < s_hi ? (s_hi - t0 + NW - 1) / NW : 0;
+    constexpr int TS = HPW ? 1 : NW;                        // tile stride of a wave (HPW: every wave walks all tiles of the split)
+    const int t0 = s_lo + (HPW ? 0 : wave);
+    const int n_my = t0 < s_hi ? (s_hi - t0 + TS - 1) / TS : 0;
     if constexpr (F8M) {
         // The cache bytes go HBM -> LDS by LDS-DMA (buffer_load ... lds: no staging registers), two stages per wave: tile s + 1
         // lands while tile s is computed, behind a COUNTED vmcnt (the 8 pieces of the younger tile stay in flight).  The
@@ -604,33 +616,33 @@ __global__ void __launch_bounds__(64 * NW, 1) fa_decode_kernel(const DecArgs da)
         (void)cur_dma;
         for (int s1 = 0; s1 < n_my; ++s1) {
             bool nxt_dma = false;
-            if (s1 + 1 < n_my) nxt_dma = issue(t0 + NW * (s1 + 1), (s1 + 1) & 1);
+            if (s1 + 1 < n_my) nxt_dma = issue(t0 + TS * (s1 + 1), (s1 + 1) & 1);
             if (nxt_dma) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // (2 x CH pieces of the younger tile may still fly)
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            compute_tile(t0 + NW * s1, s1 & 1);
+            compute_tile(t0 + TS * s1, s1 & 1);
         }
     } else
     if constexpr (STAGES == 1) {
         // eight waves: one LDS stage per wave.  Step s: the set that holds tile s goes to LDS (waits for its loads), the
         // set is re-loaded with tile s + NS, tile s is computed - NS tiles in flight while it runs, and the SIMD's other
         // wave fills the waits
-        const int n_full1 = t0 < s_hi ? ((seqlen_k / BN < s_hi ? seqlen_k / BN : s_hi) - t0 + NW - 1) / NW : 0;
+        const int n_full1 = t0 < s_hi ? ((seqlen_k / BN < s_hi ? seqlen_k / BN : s_hi) - t0 + TS - 1) / TS : 0;
         int s1 = 0;
         if (tiles_aligned && NS < n_full1) {
 #pragma unroll
-            for (int j = 0; j < NS; ++j) load_fast(t0 + NW * j, kS[j], vS[j]);
+            for (int j = 0; j < NS; ++j) load_fast(t0 + TS * j, kS[j], vS[j]);
             for (; s1 + 2 * NS <= n_full1; s1 += NS) {
 #pragma unroll
                 for (int j = 0; j < NS; ++j) {
                     store_tile(0, kS[j], vS[j]);
-                    load_fast(t0 + NW * (s1 + j + NS), kS[j], vS[j]);
-                    compute_tile(t0 + NW * (s1 + j), 0);
+                    load_fast(t0 + TS * (s1 + j + NS), kS[j], vS[j]);
+                    compute_tile(t0 + TS * (s1 + j), 0);
                 }
             }
         } else {
 #pragma unroll
             for (int j = 0; j < NS; ++j)
-                if (j < n_my) load_tile(t0 + NW * j, kS[j], vS[j]);
+                if (j < n_my) load_tile(t0 + TS * j, kS[j], vS[j]);
         }
         for (; s1 < n_my; s1 += NS) {
 #pragma unroll
@@ -638,8 +650,8 @@ __global__ void __launch_bounds__(64 * NW, 1) fa_decode_kernel(const DecArgs da)
                 const int ss = s1 + j;
                 if (ss < n_my) {
                     store_tile(0, kS[j], vS[j]);
-                    if (ss + NS < n_my) load_tile(t0 + NW * (ss + NS), kS[j], vS[j]);
-                    compute_tile(t0 + NW * ss, 0);
+                    if (ss + NS < n_my) load_tile(t0 + TS * (ss + NS), kS[j], vS[j]);
+                    compute_tile(t0 + TS * ss, 0);
                 }
             }
         }
@@ -649,31 +661,31 @@ __global__ void __launch_bounds__(64 * NW, 1) fa_decode_kernel(const DecArgs da)
     // pipeline over this wave's tiles t0 + 4 s: LDS stage s & 1 holds tile s while the register sets
     // hold tiles s+1 .. s+NS-1 (landed / landing) and the set just stored is re-loaded with s+1+NS.
     // my tiles that lie completely inside [0, seqlen_k): s < n_full
-    const int n_full = t0 < s_hi ? ((seqlen_k / BN < s_hi ? seqlen_k / BN : s_hi) - t0 + NW - 1) / NW : 0;
+    const int n_full = t0 < s_hi ? ((seqlen_k / BN < s_hi ? seqlen_k / BN : s_hi) - t0 + TS - 1) / TS : 0;
     int s0 = 0;
     if (tiles_aligned && 2 * NS < n_full) {
         // steady state: every store / load is unconditional, so the vmcnt waits in front of the
         // stores are exact counts (NS - 1 tiles stay in flight) instead of conservative drains
 #pragma unroll
-        for (int j = 0; j < NS; ++j) load_fast(t0 + NW * j, kS[j], vS[j]);
+        for (int j = 0; j < NS; ++j) load_fast(t0 + TS * j, kS[j], vS[j]);
         store_tile(0, kS[0], vS[0]);
-        load_fast(t0 + NW * NS, kS[0], vS[0]);
+        load_fast(t0 + TS * NS, kS[0], vS[0]);
         for (; s0 + 2 * NS < n_full; s0 += NS) {
 #pragma unroll
             for (int j = 0; j < NS; ++j) {
                 const int nxt = (j + 1) % NS;
                 store_tile(stage_of(s0, j + 1), kS[nxt], vS[nxt]);
-                load_fast(t0 + NW * (s0 + j + 1 + NS), kS[nxt], vS[nxt]);
-                compute_tile(t0 + NW * (s0 + j), stage_of(s0, j));
+                load_fast(t0 + TS * (s0 + j + 1 + NS), kS[nxt], vS[nxt]);
+                compute_tile(t0 + TS * (s0 + j), stage_of(s0, j));
             }
         }
     } else {
 #pragma unroll
         for (int j = 0; j < NS; ++j)
-            if (j < n_my) load_tile(t0 + NW * j, kS[j], vS[j]);
+            if (j < n_my) load_tile(t0 + TS * j, kS[j], vS[j]);
         if (n_my > 0) {
             store_tile(0, kS[0], vS[0]);
-            if (NS < n_my) load_tile(t0 + NW * NS, kS[0], vS[0]);
+            if (NS < n_my) load_tile(t0 + TS * NS, kS[0], vS[0]);
         }
     }
     // remaining tiles (and short sequences): same schedule with every step guarded
@@ -684,14 +696,48 @@ __global__ void __launch_bounds__(64 * NW, 1) fa_decode_kernel(const DecArgs da)
             if (ss < n_my) {
                 const int nxt = (j + 1) % NS;              // compile-time after unrolling
                 if (ss + 1 < n_my) store_tile(stage_of(s0, j + 1), kS[nxt], vS[nxt]);
-                if (ss + 1 + NS < n_my) load_tile(t0 + NW * (ss + 1 + NS), kS[nxt], vS[nxt]);
-                compute_tile(t0 + NW * ss, stage_of(s0, j));
+                if (ss + 1 + NS < n_my) load_tile(t0 + TS * (ss + 1 + NS), kS[nxt], vS[nxt]);
+                compute_tile(t0 + TS * ss, stage_of(s0, j));
             }
         }
     }
 
     }
 
+    if constexpr (HPW) {
+        // ---- every wave stores its own head: row l31, 8-byte pieces of the C layout (d = 32 dblk + 8 rq + 4 g .. + 3) ----
+        const float l_w = xhalf_sum(l_run);
+        const float inv = l_w > 0.f ? (KV8 ? p.v_descale : 1.0f) / (l_w * P_UP) : 0.f;
+        const float lse = l_w > 0.f ? (m_run + fast_log2(l_w)) * kLn2 : -INFINITY;
+        if (row_ok) {
+            if (da.n_splits == 1) {
+                uint16_t* op = reinterpret_cast<uint16_t*>(p.o) + (int64_t)b * p.o_batch_stride + (int64_t)(q_row0 + t_row) * p.o_row_stride +
+                               (int64_t)h * p.o_head_stride;
+#pragma unroll
+                for (int d = 0; d < DBLKS; ++d)
+#pragma unroll
+                    for (int rq = 0; rq < 4; ++rq) {
+                        u32x2 o2;
+                        o2[0] = E::pack2(oacc[d][4 * rq + 0] * inv, oacc[d][4 * rq + 1] * inv);
+                        o2[1] = E::pack2(oacc[d][4 * rq + 2] * inv, oacc[d][4 * rq + 3] * inv);
+                        *reinterpret_cast<u32x2*>(op + d * 32 + 8 * rq + 4 * g) = o2;
+                    }
+                if (g == 0) p.lse[(int64_t)b * p.lse_batch_stride + (int64_t)h * p.lse_head_stride + q_row0 + t_row] = lse;
+            } else {
+                const int64_t prow = (((int64_t)split * p.batch + b) * p.nheads_q + h) * p.seqlen_q + t_row;
+                float* op = da.o_partial + prow * D;
+#pragma unroll
+                for (int d = 0; d < DBLKS; ++d)
+#pragma unroll
+                    for (int rq = 0; rq < 4; ++rq) {
+                        const f32x4 o4 = {oacc[d][4 * rq] * inv, oacc[d][4 * rq + 1] * inv, oacc[d][4 * rq + 2] * inv, oacc[d][4 * rq + 3] * inv};
+                        *reinterpret_cast<f32x4*>(op + d * 32 + 8 * rq + 4 * g) = o4;
+                    }
+                if (g == 0) da.lse_partial[prow] = lse;
+            }
+        }
+        return;
+    }
     // ---- merge the 4 waves through LDS ----
     __syncthreads();                                        // everyone is done with its tiles
     const float l_w = xhalf_sum(l_run);
@@ -1490,9 +1536,25 @@ static int device_cu_count() {
 // grid splits of the key range (x up to 4 key sub-ranges per workgroup in the token-major kernel: <= 1024 partial rows per
 // output row, merged by decode_combine_wide_kernel)
 constexpr int DEC_MAX_SPLITS = 256;
+static bool decode_eight_waves(const fa_params& p);
+// a head per wave (HPW in fa_decode_kernel): D = 128, kv-heads adjacent in the cache rows and a multiple of 8, the packed query
+// rows of a kv-head in one 32-row block; the token-major kernel keeps its shapes
+#ifndef FA_DEC_HPW
+#define FA_DEC_HPW 1
+#endif
+static bool decode_hpw(const fa_params& p) {
+    if (!FA_DEC_HPW || p.head_dim != 128 || p.head_dim_v != 0 || p.nheads_k < 8 || p.nheads_k % 8 != 0) return false;
+    if (p.k_head_stride != p.head_dim || p.v_head_stride != p.head_dim || p.nheads_q % p.nheads_k != 0) return false;
+    // fp8 caches only: the 16-bit form stages through registers (its tiles do not fit twice into a wave's LDS share), and with
+    // the Q fragments in registers as well it spills (37) and streams at 3.5 TB/s instead of 5.9
+    if (p.kv_dtype != FA_FP8_E4M3 || !FA_DEC_F8M) return false;
+    if (p.seqlen_q * (p.nheads_q / p.nheads_k) > 32) return false;
+    return !gemv_tm_applicable(p) && decode_eight_waves(p);
+}
 int decode_num_splits(const fa_params& p) {
     if (p.num_splits >= 1) return p.num_splits > DEC_MAX_SPLITS ? DEC_MAX_SPLITS : p.num_splits;
-    const int units = p.batch * p.nheads_k * ((p.seqlen_q * (p.nheads_q / p.nheads_k) + 31) / 32);   // x row blocks
+    const int units = decode_hpw(p) ? p.batch * (p.nheads_k / 8)      // (a workgroup streams eight kv-heads)
+                                    : p.batch * p.nheads_k * ((p.seqlen_q * (p.nheads_q / p.nheads_k) + 31) / 32);   // x row blocks
     const int max_tiles = (p.seqlen_k + DEC_BN - 1) / DEC_BN;
     int s = 1;
     // one workgroup per CU: every further doubling costs 6-15 % in this kernel (each split re-reads the query rows and
@@ -1585,6 +1647,24 @@ static int launch_decode_td(DecArgs& da, hipStream_t stream) {
         if (kv8 && da.rows == 1 && da.group == 1 && !da.bias) {
             if (paged) hipLaunchKernelGGL((fa_decode_gemv_fp8_kernel<T, true>), grid, dim3(GEMV_THREADS), 0, stream, da);
             else       hipLaunchKernelGGL((fa_decode_gemv_fp8_kernel<T, false>), grid, dim3(GEMV_THREADS), 0, stream, da);
+            if (da.n_splits > 1) launch_decode_combine<T>(da, stream);
+            return 0;
+        }
+    }
+    if constexpr (D == 128) {
+        if (decode_hpw(p)) {
+            const dim3 grid_h(p.batch * (p.nheads_k / 8), da.n_splits, 1);
+            const size_t smem_ = DecSmem<D, 8>::QOFF;                       // the waves' tile regions only: Q in registers, no merge
+#define FA_LAUNCH_HPW(KV8_, PAGED_, F8M_)                                                                          \
+            do {                                                                                                    \
+                auto kern = fa_decode_kernel<T, D, KV8_, PAGED_, false, 8, F8M_, true>;                            \
+                FA_SET_LDS_ONCE(kern, smem_);                                                                       \
+                hipLaunchKernelGGL(kern, grid_h, dim3(512), smem_, stream, da);                                     \
+            } while (0)
+#if FA_DEC_F8M
+            if (paged) FA_LAUNCH_HPW(true, true, true); else FA_LAUNCH_HPW(true, false, true);
+#endif
+#undef FA_LAUNCH_HPW
             if (da.n_splits > 1) launch_decode_combine<T>(da, stream);
             return 0;
         }
