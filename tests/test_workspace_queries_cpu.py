@@ -138,3 +138,41 @@ def test_varlen_forward_workspace_marks_the_decode_routes(lib):
     p = _varlen_paged(lib, 13, 312, 300, 32, 8)
     p.block_table = None
     assert q(ctypes.byref(p)) == 0
+
+
+def test_kvcache_plan_key_is_geometry_only():
+    """flash_attn_with_kvcache's plan key (flash_attn_interface._kv_plan_key): equal for tensors of equal geometry and different
+    data, different when a dtype / shape / stride / optional / scalar option differs, None when the call needs the slow path
+    (an int cache_seqlens, a non-contiguous last dimension)."""
+    import torch
+    from flash_attn_mi355 import flash_attn_interface as fi
+
+    def mk(B=2, Hk=2, page=16, seed=0, dt=torch.float16):
+        g = torch.Generator().manual_seed(seed)
+        q = torch.randn(B, 1, 4, 64, generator=g).to(dt)
+        kc = torch.randn(B * 3, page, Hk, 64, generator=g).to(dt); vc = torch.randn(B * 3, page, Hk, 64, generator=g).to(dt)
+        lens = torch.full((B,), 5, dtype=torch.int32)
+        bt = torch.arange(B * 3, dtype=torch.int32).reshape(B, 3)
+        return q, kc, vc, lens, bt
+
+    def key(q, kc, vc, lens, bt, **kw):
+        a = dict(k=None, v=None, rotary_cos=None, rotary_sin=None, cache_seqlens=lens, cache_batch_idx=None, cache_leftpad=None,
+                 block_table=bt, softmax_scale=None, causal=True, window_size=(-1, -1), softcap=0.0, rotary_interleaved=True,
+                 alibi_slopes=None, num_splits=0, k_descale=None, v_descale=None)
+        a.update(kw)
+        return fi._kv_plan_key(q, kc, vc, a["k"], a["v"], a["rotary_cos"], a["rotary_sin"], a["cache_seqlens"], a["cache_batch_idx"],
+                               a["cache_leftpad"], a["block_table"], a["softmax_scale"], a["causal"], a["window_size"], a["softcap"],
+                               a["rotary_interleaved"], a["alibi_slopes"], a["num_splits"], a["k_descale"], a["v_descale"])
+
+    k0 = key(*mk(seed=0))
+    assert k0 is not None and k0 == key(*mk(seed=1)) and hash(k0) == hash(key(*mk(seed=1)))
+    assert k0 != key(*mk(B=3))
+    assert k0 != key(*mk(dt=torch.bfloat16))
+    assert k0 != key(*mk(), causal=False)
+    assert k0 != key(*mk(), window_size=(7, 0))
+    assert k0 != key(*mk(), num_splits=4)
+    q, kc, vc, lens, bt = mk()
+    assert k0 != key(q, kc, vc, lens, None)
+    assert k0 != key(q, kc[:, :, :1].expand(-1, -1, 2, -1), vc, lens, bt)        # same shape, other strides
+    assert key(q, kc, vc, 5, bt) is None                                          # int cache_seqlens: slow path
+    assert key(q[..., ::2], kc, vc, lens, bt) is None                             # last dim not contiguous: slow path
