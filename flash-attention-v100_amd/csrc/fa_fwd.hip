@@ -57,6 +57,9 @@ constexpr int FWD_BM = 128;
 #ifndef FA_FWD_OCC
 #define FA_FWD_OCC 2
 #endif
+#ifndef FA_FWD_PK
+#define FA_FWD_PK 0                                    // packed fp32 softmax arithmetic at D = 64 (experiment)
+#endif
 #ifndef FA_FWD_MSUM
 #define FA_FWD_MSUM 0                                  // row sums on the matrix pipe (see MSUM in the kernel): measured neutral, off
 #endif
@@ -766,6 +769,26 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : ((WALK && D <= 64 
         const float m_use = (m_run == -INFINITY) ? 0.f : m_run;
         const float ms = BIAS ? m_use - shift : m_use;
         float psum = 0.f;
+#if FA_FWD_PK
+        if constexpr (D <= 64) {
+            // D = 64: the matrix pipe is the idle unit (28 % busy), the VALU the busy one - here packed fp32 (v_pk_fma_f32 /
+            // v_pk_add_f32: two elements per instruction through the matrix datapath) takes 32 + 32 instructions down to 16 + 16
+            typedef float f32x2v __attribute__((ext_vector_type(2)));
+            const f32x2v c2 = {c, c}, nm2 = {-ms, -ms};
+            f32x2v ps2 = {0.f, 0.f};
+#pragma unroll
+            for (int kb = 0; kb < FWD_NKB; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const f32x2v sv = {sacc[kb][r], sacc[kb][r + 1]};
+                    const f32x2v t = __builtin_elementwise_fma(sv, c2, nm2);
+                    f32x2v e2 = {fast_exp2(t[0]), fast_exp2(t[1])};
+                    sacc[kb][r] = e2[0]; sacc[kb][r + 1] = e2[1];
+                    if constexpr (!MSUM) ps2 += e2;
+                }
+            psum = ps2[0] + ps2[1];
+        } else
+#endif
 #pragma unroll
         for (int kb = 0; kb < FWD_NKB; ++kb)
 #pragma unroll
