@@ -100,10 +100,12 @@ __global__ void __launch_bounds__(64 * NW, 1) fa_decode_kernel(const DecArgs da)
     static_assert(!HPW || (NW == 8 && D <= 128 && !NARROW), "a head per wave: eight waves");
     constexpr int KSTEPS = D / 16;
     constexpr int DBLKS = D / 32;
-    constexpr int TILE = DecSmem<D, NW>::TILE;
+    // (HPW over a 16-bit cache: 16-key tiles - two LDS-DMA stages of K | V fit the wave's 16 KiB, see the pipeline below)
+    constexpr bool D16 = HPW && !KV8;
+    constexpr int TILE = D16 ? 16 * D * 2 : DecSmem<D, NW>::TILE;
     constexpr int EB = KV8 ? 1 : 2;                         // bytes per cache element
     constexpr int CPR = D * EB / 16;                        // 16-byte chunks per cache row
-    constexpr int BN = DecSmem<D, NW>::BN;                      // keys per wave tile
+    constexpr int BN = D16 ? 16 : DecSmem<D, NW>::BN;           // keys per wave tile
     constexpr int CH = BN * CPR / 64;                       // chunks per lane per tile
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -560,7 +562,7 @@ __global__ void __launch_bounds__(64 * NW, 1) fa_decode_kernel(const DecArgs da)
     constexpr int TS = HPW ? 1 : NW;                        // tile stride of a wave (HPW: every wave walks all tiles of the split)
     const int t0 = s_lo + (HPW ? 0 : wave);
     const int n_my = t0 < s_hi ? (s_hi - t0 + TS - 1) / TS : 0;
-    if constexpr (F8M) {
+    if constexpr (F8M || D16) {
         // The cache bytes go HBM -> LDS by LDS-DMA (buffer_load ... lds: no staging registers), two stages per wave: tile s + 1
         // lands while tile s is computed, behind a COUNTED vmcnt (the 8 pieces of the younger tile stay in flight).  The
         // destination is lane-linear (lane l of piece i -> row 8 i + l / 8, 16-byte slot l % 8), so the images' slot XORs
@@ -569,13 +571,18 @@ __global__ void __launch_bounds__(64 * NW, 1) fa_decode_kernel(const DecArgs da)
 #pragma unroll
         for (int i = 0; i < CH; ++i) {
             const int row = (lane + 64 * i) / CPR, slot = lane % CPR;
-            k_dma[i] = (uint32_t)(row * p.k_row_stride + ((slot ^ ((row >> 1) & 7)) << 4));
-            v_dma[i] = (uint32_t)(row * p.v_row_stride + ((slot ^ ((((row >> 3) & 1) << 2) | (row & 3))) << 4));
+            if constexpr (F8M) {
+                k_dma[i] = (uint32_t)(row * p.k_row_stride + ((slot ^ ((row >> 1) & 7)) << 4));
+                v_dma[i] = (uint32_t)(row * p.v_row_stride + ((slot ^ ((((row >> 3) & 1) << 2) | (row & 3))) << 4));
+            } else {                                                  // 16-bit images: swz_row_off / swzt_row_off of fa_common.h
+                k_dma[i] = (uint32_t)(row * p.k_row_stride * 2 + (swz_row_off<D>(row, slot * 16) - row * D * 2));
+                v_dma[i] = (uint32_t)(row * p.v_row_stride * 2 + (swzt_row_off<D>(row, slot * 16) - row * D * 2));
+            }
         }
         const int n_full_tiles = seqlen_k / BN;                       // tiles that lie completely inside the sequence
         auto issue = [&](int tile, int stage) -> bool {               // true: by DMA (8 pieces in flight), false: done synchronously
-            char* kdst = wsm + stage * TILE;
-            char* vdst = kdst + TILE / 2;
+            char* kdst = wsm + stage * (F8M ? TILE : 2 * TILE);
+            char* vdst = kdst + (F8M ? TILE / 2 : TILE);
             if (!(tiles_aligned && tile < n_full_tiles)) {
                 load_tile(tile, kS[0], vS[0]);
                 store_tile(stage, kS[0], vS[0]);
@@ -589,11 +596,13 @@ __global__ void __launch_bounds__(64 * NW, 1) fa_decode_kernel(const DecArgs da)
                 const int64_t phys = btab_c[pg];
                 ko = phys * p.k_batch_stride + (int64_t)pr * p.k_row_stride;
                 vo = phys * p.v_batch_stride + (int64_t)pr * p.v_row_stride;
-                const int pos1 = pos0 + 16;
-                const int pg1 = da.page_shift >= 0 ? (pos1 >> da.page_shift) : pos1 / p.page_block_size;
-                const int64_t phys1 = btab_c[pg1];
-                ko2 = phys1 * p.k_batch_stride + (int64_t)(pos1 - pg1 * p.page_block_size - 16) * p.k_row_stride;
-                vo2 = phys1 * p.v_batch_stride + (int64_t)(pos1 - pg1 * p.page_block_size - 16) * p.v_row_stride;
+                if (BN > 16) {                                        // (the tile's second 16-row half may lie in the next page)
+                    const int pos1 = pos0 + 16;
+                    const int pg1 = da.page_shift >= 0 ? (pos1 >> da.page_shift) : pos1 / p.page_block_size;
+                    const int64_t phys1 = btab_c[pg1];
+                    ko2 = phys1 * p.k_batch_stride + (int64_t)(pos1 - pg1 * p.page_block_size - 16) * p.k_row_stride;
+                    vo2 = phys1 * p.v_batch_stride + (int64_t)(pos1 - pg1 * p.page_block_size - 16) * p.v_row_stride;
+                }
             } else {
                 ko = (int64_t)cb * p.k_batch_stride + (int64_t)pos0 * p.k_row_stride;
                 vo = (int64_t)cb * p.v_batch_stride + (int64_t)pos0 * p.v_row_stride;
@@ -604,8 +613,8 @@ __global__ void __launch_bounds__(64 * NW, 1) fa_decode_kernel(const DecArgs da)
                 const uint32_t hi32 = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(b64 >> 32));
                 return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)hi32 << 32) | lo32), 0, 0x7fffffff, 0x00020000);
             };
-            const __amdgpu_buffer_rsrc_t kr = rsrc_of(kbase + ko), vr = rsrc_of(vbase + vo);
-            const __amdgpu_buffer_rsrc_t kr2 = PAGED ? rsrc_of(kbase + ko2) : kr, vr2 = PAGED ? rsrc_of(vbase + vo2) : vr;
+            const __amdgpu_buffer_rsrc_t kr = rsrc_of(kbase + ko * EB), vr = rsrc_of(vbase + vo * EB);
+            const __amdgpu_buffer_rsrc_t kr2 = (PAGED && BN > 16) ? rsrc_of(kbase + ko2 * EB) : kr, vr2 = (PAGED && BN > 16) ? rsrc_of(vbase + vo2 * EB) : vr;
 #pragma unroll
             for (int i = 0; i < CH; ++i) buf_load_lds_b128(i * RPS >= 16 ? kr2 : kr, kdst + i * 1024, k_dma[i], 0);
 #pragma unroll
@@ -1542,12 +1551,15 @@ static bool decode_eight_waves(const fa_params& p);
 #ifndef FA_DEC_HPW
 #define FA_DEC_HPW 1
 #endif
+#ifndef FA_DEC_HPW16
+#define FA_DEC_HPW16 0                       // ... for 16-bit caches too (16-key tiles, LDS-DMA): measured level (5.96-5.98 vs 5.82-6.10 TB/s), off
+#endif
 static bool decode_hpw(const fa_params& p) {
     if (!FA_DEC_HPW || p.head_dim != 128 || p.head_dim_v != 0 || p.nheads_k < 8 || p.nheads_k % 8 != 0) return false;
     if (p.k_head_stride != p.head_dim || p.v_head_stride != p.head_dim || p.nheads_q % p.nheads_k != 0) return false;
-    // fp8 caches only: the 16-bit form stages through registers (its tiles do not fit twice into a wave's LDS share), and with
-    // the Q fragments in registers as well it spills (37) and streams at 3.5 TB/s instead of 5.9
-    if (p.kv_dtype != FA_FP8_E4M3 || !FA_DEC_F8M) return false;
+    // (16-bit caches: 16-key tiles, so that two LDS-DMA stages fit a wave's 16 KiB - with 32-key tiles staged through registers
+    //  and the Q fragments in registers as well the form spilled 37 registers and streamed at 3.5 TB/s instead of 5.9)
+    if (p.kv_dtype == FA_FP8_E4M3 ? !FA_DEC_F8M : (p.kv_dtype != p.dtype || !FA_DEC_HPW16)) return false;
     if (p.seqlen_q * (p.nheads_q / p.nheads_k) > 32) return false;
     return !gemv_tm_applicable(p) && decode_eight_waves(p);
 }
@@ -1661,9 +1673,15 @@ static int launch_decode_td(DecArgs& da, hipStream_t stream) {
                 FA_SET_LDS_ONCE(kern, smem_);                                                                       \
                 hipLaunchKernelGGL(kern, grid_h, dim3(512), smem_, stream, da);                                     \
             } while (0)
+            if (kv8) {
 #if FA_DEC_F8M
-            if (paged) FA_LAUNCH_HPW(true, true, true); else FA_LAUNCH_HPW(true, false, true);
+                if (paged) FA_LAUNCH_HPW(true, true, true); else FA_LAUNCH_HPW(true, false, true);
 #endif
+            } else {
+#if FA_DEC_HPW16
+                if (paged) FA_LAUNCH_HPW(false, true, false); else FA_LAUNCH_HPW(false, false, false);
+#endif
+            }
 #undef FA_LAUNCH_HPW
             if (da.n_splits > 1) launch_decode_combine<T>(da, stream);
             return 0;
