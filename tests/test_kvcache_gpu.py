@@ -559,3 +559,41 @@ def test_kvcache_plan_cache_repeats_a_geometry_with_new_tensors():
         assert torch.equal(x, y)
     call(a3)                                             # another batch size: its own plan
     assert len(fi._KV_PLANS) == n_plans + 1
+
+
+@pytest.mark.parametrize("Hq,Hk,dt", [(32, 8, "fp16"), (64, 8, "bf16"), (8, 8, "bf16")])
+def test_fp8_decode_keeps_the_mass_of_many_small_probabilities(Hq, Hk, dt):
+    """One key with a large score and thousands with scores ~8.5 below it: every one of those probabilities is ~2e-4 of the
+    largest, together they hold most of the row's mass.  The fp8-operand MFMA form of the decode kernel carries P as e4m3
+    fragments, and e4m3 bottoms out at 2^-9 ABSOLUTE: converting P on a scale where the row maximum may sit at 2^8 flushed
+    exactly these (round 4; caught by one softcap case only).  The output must be the V average the oracle computes - with the
+    small probabilities flushed it collapses onto the one large key's V row.  (H 8/8: the token-major kernel, for reference.)"""
+    B, D, page, L = 2, 128, 256, 4096
+    kd, vd = 1.0 / 16, 1.0 / 8
+    g = torch.Generator().manual_seed(7)
+    pps = L // page
+    nblk = B * pps
+    # keys: small random (scores ~ N(0, 0.2)), one key per (batch, kv-head) aligned with q (score ~ +8.5)
+    q = rand16((B, 1, Hq, D), dt, 1)
+    k16 = (torch.randn(nblk, page, Hk, D, generator=g) * 0.15)
+    v16 = torch.randn(nblk, page, Hk, D, generator=g)
+    bt = torch.randperm(nblk, generator=g).reshape(B, pps).to(torch.int32)
+    G = Hq // Hk
+    for b in range(B):
+        for hk in range(Hk):
+            qh = q[b, 0, hk * G].float().cpu()
+            pos = 100 + 37 * hk + 1000 * b
+            k16[int(bt[b, pos // page]), pos % page, hk] = qh * (8.5 * D ** 0.5 / float(qh @ qh))
+    kc = (k16.cuda() / kd).to(torch.float8_e4m3fn); vc = (v16.cuda() / vd).to(torch.float8_e4m3fn)
+    lens = torch.full((B,), L, dtype=torch.int32)
+    out, lse = _fa().flash_attn_with_kvcache(q, kc, vc, cache_seqlens=lens.cuda(), block_table=bt.cuda(), causal=True,
+                                             return_softmax_lse=True, k_descale=kd, v_descale=vd)
+    o_ref, lse_ref = oracle.kvcache_fwd(f64(q), kc.float().double().cpu().numpy(), vc.float().double().cpu().numpy(),
+                                        cache_seqlens=lens.numpy(), block_table=bt.numpy(), causal=True, io_dtype=dt,
+                                        k_descale=kd, v_descale=vd)
+    assert_close(f64(out), o_ref, dt, "out", mult=1.5)
+    assert_lse_close(f64(lse), lse_ref, "lse", atol=2e-3)
+    s0 = (f64(q)[0, 0, 0] @ (kc.float().double().cpu().numpy()[bt[0].long().numpy()].reshape(-1, Hk, D)[:, 0].T * kd)) * D ** -0.5
+    p0 = np.exp(s0 - s0.max())
+    # (the construction does what it says: in the first head's row the ~2e-4 probabilities hold almost half of the mass)
+    assert p0.max() / p0.sum() < 0.6 and np.median(p0) < 1e-3
