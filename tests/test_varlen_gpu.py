@@ -157,6 +157,7 @@ def test_varlen_decode_runs_the_decode_kernels(Tq, Hq, Hk, D, dt, page, use_sequ
     (1, [1, 0, 1, 1], 4, 4, "bf16", True),           # fp8 head-major matrix-vector kernel
     (1, [1, 1, 1, 0], 32, 16, "bf16", True),         # fp8 token-major, G = 2
     (4, [4, 1, 3, 4], 16, 2, "fp16", False),         # MFMA decode kernel, G = 8
+    (2, [2, 2, 1, 0, 2], 32, 8, "bf16", True),       # fp8-operand MFMA form, a kv-head per wave (8 kv-heads, G = 4), varlen-q rows
 ])
 def test_varlen_decode_with_padding_rows_in_q(Tq, qlens, Hq, Hk, dt, fp8):
     """total_q == batch x max_seqlen_q does not prove that sequence b sits at row b T: q may carry padding rows behind
