@@ -216,6 +216,9 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : ((WALK && D <= 64 
         }
         if (wl >= 0) { const int l1 = wrow_last + off - wl; w_lo_max = l1 > 0 ? l1 : 0; }
         w_lo_min = (wl >= 0 && wave_row0 + off - wl > 0) ? wave_row0 + off - wl : 0;
+        // a wave whose 32 rows all lie past the sequence (the tail of a sequence's last block) computes nothing: no tile is
+        // "active" for it (it still takes part in the loads and barriers).  Its rows are not stored.
+        if (wave_row0 >= seqlen_q) { w_hi_max = -1; w_hi_min = -1; }
     };
 
     // ---- pointers -------------------------------------------------------------------------

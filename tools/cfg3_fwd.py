@@ -21,9 +21,17 @@ def ev(fn, n=30, warm=5):
         a.record(); fn(); b.record(); b.synchronize(); ts.append(a.elapsed_time(b))
     ts.sort(); return ts[len(ts) // 2], ts[0]
 fwd = lambda: flash_attn.flash_attn_varlen_func(q, k, v, cu, cu, 2048, 2048, causal=True, window_size=(W, 0))
+def sustained(fn, n=200):
+    for _ in range(10): fn()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n): fn()
+    b.record(); b.synchronize()
+    return a.elapsed_time(b) / n
 with torch.no_grad():
     med, mn = ev(fwd)
-print(f"lib={os.environ.get('FA_MI355_LIB', 'product')}: cfg3 fwd {med:.4f} ms (min {mn:.4f}) = {flops / med / 1e9:.0f} TFLOP/s", flush=True)
+    sus = sustained(fwd)
+print(f"lib={os.environ.get('FA_MI355_LIB', 'product')}: cfg3 fwd {med:.4f} ms (min {mn:.4f}) = {flops / med / 1e9:.0f} TFLOP/s | back-to-back {sus:.4f} ms = {flops / sus / 1e9:.0f} TFLOP/s", flush=True)
 fwdc = lambda: flash_attn.flash_attn_varlen_func(q, k, v, cu, cu, 2048, 2048, causal=True)
 flc = 4.0 * D * H * sum(int(L) * (int(L) + 1) // 2 for L in lens)
 with torch.no_grad():
