@@ -755,31 +755,28 @@ __global__ void __launch_bounds__(BWD_THREADS, 1) fa_bwd_dkdv_kernel(const KArgs
 // 2b. dK / dV, two workgroups per CU
 // ---------------------------------------------------------------------------------------------
 // The one-wave-per-SIMD kernel above cannot overlap anything (knock-out: loads 0.39 + S/dP 0.31 + VALU
-// 0.26 + dV/dK 0.32 + rest 0.26 ms add up to its 1.54 ms).  This variant fits 256 registers and 80 KiB of
-// LDS so that TWO independent workgroups share a CU and one computes while the other loads or does its
-// exp2 / dS arithmetic (the mechanism that carries the forward and dQ kernels):
-//   * the 128 keys' K and V tiles live in LDS (64 KiB); their B fragments are re-read per use
-//     (the register version keeps them in 64 registers);
-//   * Q / dO arrive in 32-row single-buffered stages (16 KiB) by LDS-DMA - no staging registers;
-//   * the 32 row statistics of a stage sit in one register per lane (lanes 0..31 lse2, 32..63 D) and are
-//     gathered per accumulator register with ds_bpermute_b32 (crossbar only, no LDS space: there is
-//     none left - 2 x 81920 B is exactly the CU's 160 KiB).
+// 0.26 + dV/dK 0.32 + rest 0.26 ms add up to its 1.54 ms).  This variant fits 256 registers (D = 64: 168) and
+// 80 KiB of LDS so that TWO (D = 64: THREE) independent workgroups share a CU and one computes while another
+// loads or does its exp2 / dS arithmetic (the mechanism that carries the forward and dQ kernels):
+//   * the 128 keys' K tile lives in LDS (its B fragments are re-read per use), the V fragments in registers;
+//   * Q / dO arrive in 32-row double-buffered stages by LDS-DMA - no staging registers; the DMA of stage
+//     it + 1 is issued right behind the barrier that opens stage it (one barrier per stage);
+//   * the 64 row statistics of a stage (lse log2 e, -D) are fetched by wave 0 a stage ahead and published in
+//     LDS behind the stage; every wave reads them as f32x4 in the accumulator layout, the -D quads straight
+//     into the dP accumulator (dP - D costs no instruction).
+// Round 5: the loop's instruction stream was put on a diet - at D = 64 (BASELINE config 3) the loop is bound by
+// the waves' own VALU / scalar issue, not by the matrix pipe: every LDS read address is a pinned lane constant
+// plus an immediate (the two stage buffers are two unrolled copies of the body), the per-head buffer
+// descriptors and statistics pointers are rebuilt only when the q-head changes, only wave 0 fetches statistics.
 #ifndef FA_DKV2_OCC64
 #define FA_DKV2_OCC64 3
 #endif
 constexpr int DKV2_BQ = 32;
 template <int D> struct Dkv2Smem {
-    static constexpr int KT = DKV_BN * D * 2;            // K (or V) tile
+    static constexpr int KT = DKV_BN * D * 2;            // K tile
     static constexpr int QT = DKV2_BQ * D * 2;           // Q (or dO) stage
-#ifndef FA_DKV2_PADLDS
-#define FA_DKV2_PADLDS 0
-#endif
-#ifdef FA_DKV2_VLDS
-    static constexpr int TOTAL = 2 * KT + 2 * QT + FA_DKV2_PADLDS;          // K, V tiles + one stage
-#else
-    static constexpr int STG = 2 * QT + 256;                                 // Q, dO, 64 row statistics
-    static constexpr int TOTAL = KT + 2 * STG + FA_DKV2_PADLDS;              // K tile + two stages (V fragments in registers)
-#endif
+    static constexpr int STG = 2 * QT + 256;             // Q, dO, 64 row statistics
+    static constexpr int TOTAL = KT + 2 * STG;           // K tile + two stages (V fragments in registers)
 };
 
 #ifndef FA_DKV2_PF
@@ -793,25 +790,13 @@ __global__ void __launch_bounds__(BWD_THREADS, D <= 64 ? FA_DKV2_OCC64 : 2) fa_b
     constexpr int CPR = D / 8;
     constexpr int KT = Dkv2Smem<D>::KT;
     constexpr int QT = Dkv2Smem<D>::QT;
+    constexpr int STG = Dkv2Smem<D>::STG;
     constexpr int ROWS_PI = 64 / CPR;                        // rows per 1-KiB DMA instruction
     constexpr int K_INSTS = DKV_BN / ROWS_PI / 4;            // per wave, per tensor
     constexpr int Q_INSTS = DKV2_BQ / ROWS_PI / 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-#ifdef FA_DKV2_VLDS
-    constexpr bool VREG = false;
-    constexpr int NSTG = 1;
-    constexpr int STG = 2 * QT;
-    char* const ks_base = smem;                              // K tile   [128][D]  swz  (row reads)
-    char* const vs_base = smem + KT;                         // V tile
-    char* const stg_base = smem + 2 * KT;                    // Q stage  [32][D]   swzt (row + transposed reads), dO stage
-#else
-    constexpr bool VREG = true;                              // V fragments in registers: room for a second stage
-    constexpr int NSTG = 2;
-    constexpr int STG = Dkv2Smem<D>::STG;
-    char* const ks_base = smem;
-    char* const vs_base = smem;                              // (unused)
-    char* const stg_base = smem + KT;
-#endif
+    char* const ks_base = smem;                              // K tile   [128][D]  swzt (row reads)
+    char* const stg_base = smem + KT;                        // two stages: Q [32][D] swzt (row + transposed reads), dO, statistics
 
     const fa_params& p = a.p;
     const int n_kblocks = (p.seqlen_k + DKV_BN - 1) / DKV_BN;
@@ -853,13 +838,12 @@ __global__ void __launch_bounds__(BWD_THREADS, D <= 64 ? FA_DKV2_OCC64 : 2) fa_b
 
     // DMA geometry: instruction `inst` covers ROWS_PI rows; lane -> (row, physical 16-byte slot); the source
     // offset carries the swizzle (and the out-of-range trick for columns past head_dim_v)
-    uint32_t k_voff[K_INSTS], v_voff[K_INSTS], q_voff[Q_INSTS], do_voff[Q_INSTS];
+    uint32_t k_voff[K_INSTS], q_voff[Q_INSTS], do_voff[Q_INSTS];
 #pragma unroll
     for (int i = 0; i < K_INSTS; ++i) {
         const int row = (wave * K_INSTS + i) * ROWS_PI + lane / CPR;
         const int cbs = swzt_row_off<D>(row, (lane % CPR) * 16) - row * D * 2;
         k_voff[i] = cbs < dv * 2 ? (uint32_t)(row * p.k_row_stride * 2 + cbs) : kOobVoff;
-        v_voff[i] = cbs < dv * 2 ? (uint32_t)(row * p.v_row_stride * 2 + cbs) : kOobVoff;
     }
 #pragma unroll
     for (int i = 0; i < Q_INSTS; ++i) {
@@ -879,15 +863,25 @@ __global__ void __launch_bounds__(BWD_THREADS, D <= 64 ? FA_DKV2_OCC64 : 2) fa_b
     const uint16_t* k_head = reinterpret_cast<const uint16_t*>(p.k) + kb_off + sg.k_row0 * p.k_row_stride + (int64_t)hk * p.k_head_stride;
     const uint16_t* v_head = reinterpret_cast<const uint16_t*>(p.v) + vb_off + sg.k_row0 * p.v_row_stride + (int64_t)hk * p.v_head_stride;
     const __amdgpu_buffer_rsrc_t k_rsrc = make_rsrc(k_head, p.k_row_stride, sg.seqlen_k, dv);
-    const __amdgpu_buffer_rsrc_t v_rsrc = make_rsrc(v_head, p.v_row_stride, sg.seqlen_k, dv);
-    // lane-constant LDS read offsets
-    // (the K / V tiles use the same swizzle as the stages, so a key-row read is a_rd + a wave-uniform offset)
-    int a_rd[KSTEPS];
+    // lane-constant LDS read addresses, pinned in registers (lds_pin): the stage buffer, the tensor, the 16-row group of
+    // a transposed read are immediate offsets of the read instruction.
+    // (the K tile uses the same swizzle as the stages, so a key-row read is the stage's row address + a wave-uniform offset)
+    const lds_char* q_rp[KSTEPS];                            // row reads of stage 0's Q tile (dO: + QT)
+    const lds_char* k_rp[KSTEPS];                            // row reads of the wave's 32 keys in the K tile
 #pragma unroll
-    for (int ks = 0; ks < KSTEPS; ++ks) a_rd[ks] = swzt_row_off<D>(l31, 32 * ks + 16 * g);
-    const int kv_row0 = wave * 32 * D * 2;
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+        const int a_rd = swzt_row_off<D>(l31, 32 * ks + 16 * g);
+        q_rp[ks] = lds_pin(stg_base + a_rd);
+        k_rp[ks] = lds_pin(ks_base + wave * 32 * D * 2 + a_rd);
+    }
     const int rr = (lane & 15) >> 2;
     const int cb = (((lane >> 4) & 1) << 5) + ((lane & 3) << 3);
+    const lds_char* t_rp[2][DBLKS];                          // transposed reads: rows 4 g + rr (+ 8), 64-byte column group d
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+        for (int d = 0; d < DBLKS; ++d) t_rp[h2][d] = lds_pin(stg_base + swzt_row_off<D>(4 * g + rr + 8 * h2, d * 64 + cb));
+    const lds_char* st_rp = lds_pin(stg_base + 2 * QT + 16 * g);     // statistics: lse2[8 i + 4 g ..], -D 128 bytes further
     const u32x4 alibi_a = alibi_pos_operand<T>(lane);
 
     const int n_pass = (pair && (n_kblocks - 1 - nb0) != nb0) ? 2 : 1;
@@ -924,19 +918,20 @@ __global__ void __launch_bounds__(BWD_THREADS, D <= 64 ? FA_DKV2_OCC64 : 2) fa_b
     const int mt1 = m_hi > m_lo ? (m_hi + DKV2_BQ - 1) / DKV2_BQ : mt0;
     const int n_tiles = mt1 - mt0;
     const int n_iter = n_tiles * group;
+    // the mask of a sub-tile as two lane constants (see fa_fwd.hip): masked <=> (cpos - lo_t) >u width, lo_t = lo_l - q0
+    const bool empty = qhi < qlo;
+    const int lo_l = empty ? 0x3fffffff : qlo - 4 * g;
+    const uint32_t width = empty ? 0u : (uint32_t)(qhi - qlo);
 
-    // ---- K / V tiles of the 128 keys -> LDS ----
+    // ---- K tile of the 128 keys -> LDS, V fragments of the wave's 32 keys -> registers ----
     __syncthreads();                                         // the previous pass is done with the LDS
     {
-        const uint32_t ksoff = (uint32_t)(n0 * p.k_row_stride * 2), vsoff = (uint32_t)(n0 * p.v_row_stride * 2);
+        const uint32_t ksoff = (uint32_t)(n0 * p.k_row_stride * 2);
 #pragma unroll
-        for (int i = 0; i < K_INSTS; ++i) {
-            buf_load_lds_b128(k_rsrc, ks_base + (wave * K_INSTS + i) * 1024, k_voff[i], ksoff);
-            if (!VREG) buf_load_lds_b128(v_rsrc, vs_base + (wave * K_INSTS + i) * 1024, v_voff[i], vsoff);
-        }
+        for (int i = 0; i < K_INSTS; ++i) buf_load_lds_b128(k_rsrc, ks_base + (wave * K_INSTS + i) * 1024, k_voff[i], ksoff);
     }
-    u32x4 vf[VREG ? KSTEPS : 1];
-    if (VREG) {
+    u32x4 vf[KSTEPS];
+    {
         const uint16_t* vr = v_head + (int64_t)my_key * p.v_row_stride + 8 * g;
         const bool ok = my_key < sg.seqlen_k;
 #pragma unroll
@@ -952,62 +947,92 @@ __global__ void __launch_bounds__(BWD_THREADS, D <= 64 ? FA_DKV2_OCC64 : 2) fa_b
 #pragma unroll
         for (int r = 0; r < 16; ++r) { dk_acc[d][r] = 0.f; dv_acc[d][r] = 0.f; }
 
-    // stage `it` lives in buffer it % NSTG.  Two buffers: the DMA of stage it+1 is issued right after the
-    // barrier that opens stage it and lands behind its compute (one barrier per stage).
-    auto issue_stage = [&](int it, int gq, int q0, float& stat_out) {
+    // Per-q-head state of the stage stream (rebuilt when the stream wraps to the next head of a GQA group): the Q / dO
+    // descriptors and, on wave 0 only, the lane's statistics row (lanes 0..31: lse, 32..63: softmax_d)
+    __amdgpu_buffer_rsrc_t q_rsrc, do_rsrc;
+    const float* stat_row = nullptr;
+    auto set_head = [&](int gq) {
         const int h = hk * group + gq;
-        char* qd = stg_base + (it % NSTG) * STG;
-        const __amdgpu_buffer_rsrc_t q_rsrc = make_rsrc(q_base + (int64_t)h * p.q_head_stride, p.q_row_stride, sg.seqlen_q, dv);
-        const __amdgpu_buffer_rsrc_t do_rsrc = make_rsrc(do_base + (int64_t)h * p.do_head_stride, p.do_row_stride, sg.seqlen_q, dv);
-        const uint32_t q_soff = (uint32_t)(q0 * p.q_row_stride * 2), do_soff = (uint32_t)(q0 * p.do_row_stride * 2);
+        q_rsrc = make_rsrc(q_base + (int64_t)h * p.q_head_stride, p.q_row_stride, sg.seqlen_q, dv);
+        do_rsrc = make_rsrc(do_base + (int64_t)h * p.do_head_stride, p.do_row_stride, sg.seqlen_q, dv);
+        if (wave == 0) stat_row = (g ? dsum_base : lse_base) + (int64_t)h * p.lse_head_stride;
+    };
+    const uint32_t q_step = (uint32_t)(DKV2_BQ * p.q_row_stride * 2), do_step = (uint32_t)(DKV2_BQ * p.do_row_stride * 2);
+    // stage stream being fetched: tile mt_n of head gq_n
+    int gq_n = 0, mt_n = mt0;
+    uint32_t q_soff = (uint32_t)mt0 * q_step, do_soff = (uint32_t)mt0 * do_step;
+    float stat_next = 0.f;
+    auto issue_stage = [&](auto par_c) {                      // DMA of stage (gq_n, mt_n) into buffer PAR; wave 0: its statistics
+        constexpr int PAR = decltype(par_c)::value;
+        char* qd = stg_base + PAR * STG;
 #pragma unroll
         for (int i = 0; i < Q_INSTS; ++i) {
             buf_load_lds_b128(q_rsrc, qd + (wave * Q_INSTS + i) * 1024, q_voff[i], q_soff);
             buf_load_lds_b128(do_rsrc, qd + QT + (wave * Q_INSTS + i) * 1024, do_voff[i], do_soff);
         }
-        const int qi = q0 + l31;
-        const int qc = qi < sg.seqlen_q ? qi : (sg.seqlen_q > 0 ? sg.seqlen_q - 1 : 0);
-        // the raw value: any arithmetic on it here would put an s_waitcnt vmcnt(0) - the latency of the tile loads issued
-        // just above - at the top of the stage; stat_fix() is applied where the value is consumed, a stage later
-        stat_out = (g ? dsum_base : lse_base)[(int64_t)h * p.lse_head_stride + qc];
+        if (wave == 0) {
+            const int qi = mt_n * DKV2_BQ + l31;
+            const int qc = qi < sg.seqlen_q ? qi : (sg.seqlen_q > 0 ? sg.seqlen_q - 1 : 0);
+            // the raw value: any arithmetic on it here would put an s_waitcnt vmcnt(0) - the latency of the tile loads issued
+            // just above - at the top of the stage; publish_stats() fixes it up where it is consumed, a stage later
+            stat_next = stat_row[qc];
+        }
     };
-    auto stat_fix = [&](float x, int q0) { return q0 + l31 < sg.seqlen_q ? (g ? x : x * kLog2e) : 0.f; };
-    float statv = 0.f, stat_next = 0.f;
-    (void)statv;
-    int gq = 0, mt = mt0;                                 // stage it = (q-head gq of the group, 32-row tile mt)
-    int gq_n = 0, mt_n = mt0;                             // the same for the stage being prefetched
-    auto advance = [&](int& gq_x, int& mt_x) { if (++mt_x == mt1) { mt_x = mt0; ++gq_x; } };
-    if (NSTG == 2 && n_iter > 0) {
-        issue_stage(0, gq_n, mt_n * DKV2_BQ, stat_next);
-        if (wave == 0) reinterpret_cast<float*>(stg_base + 2 * QT)[lane] = stat_fix(stat_next, mt_n * DKV2_BQ);     // stage 0's statistics
+    // statistics of the stage that was just fetched -> LDS behind its buffer: lse log2 e (rows past the sequence: 0) and -D
+    auto publish_stats = [&](auto par_c, int mt_x) {
+        constexpr int PAR = decltype(par_c)::value;
+        if (wave == 0) {
+            const float x = mt_x * DKV2_BQ + l31 < sg.seqlen_q ? (g ? -stat_next : stat_next * kLog2e) : 0.f;
+            reinterpret_cast<float*>(stg_base + PAR * STG + 2 * QT)[lane] = x;
+        }
+    };
+    auto advance_n = [&]() {
+        ++mt_n; q_soff += q_step; do_soff += do_step;
+        if (mt_n == mt1) {                                    // next q-head of the group, first tile
+            mt_n = mt0; ++gq_n;
+            q_soff = (uint32_t)mt0 * q_step; do_soff = (uint32_t)mt0 * do_step;
+            if (gq_n < group) set_head(gq_n);
+        }
+    };
+    int gq = 0, mt = mt0;                                  // stage it = (q-head gq of the group, 32-row tile mt)
+    if (n_iter > 0) {
+        set_head(0);
+        issue_stage(std::integral_constant<int, 0>{});
+        publish_stats(std::integral_constant<int, 0>{}, mt_n);
     }
-#pragma unroll 1
-    for (int it = 0; it < n_iter; ++it, advance(gq, mt)) {
+
+    // ---- one stage: buffer PAR holds stage it; stage it + 1 is fetched into the other buffer ----
+    auto stage = [&](auto par_c, int it) {
+        constexpr int PAR = decltype(par_c)::value;
+        constexpr int SB = PAR * STG;                          // byte offset of the stage buffer: an immediate of every read
         const int q0 = mt * DKV2_BQ;
         const int h = hk * group + gq;
-        if (NSTG == 1) {
-            if (it > 0) __syncthreads();                     // everyone is done reading the previous stage
-            issue_stage(it, gq, q0, statv);
-            __syncthreads();                                 // (hipcc waits for the DMA in front of the barrier)
-            statv = stat_fix(statv, q0);
-        } else {
-            __syncthreads();                                 // stage it landed (vmcnt(0) before the barrier) and
-            advance(gq_n, mt_n);                             // everyone left stage it-1: its buffer is re-filled
-            if (it + 1 < n_iter) issue_stage(it + 1, gq_n, mt_n * DKV2_BQ, stat_next);
-        }
-        const char* qs = stg_base + (it % NSTG) * STG;
-        const char* dos = qs + QT;
+        (void)h;
+        __syncthreads();                                     // stage it landed (vmcnt(0) before the barrier) and
+        advance_n();                                         // everyone left stage it-1: its buffer is re-filled
+        const bool has_next = it + 1 < n_iter;
+        if (has_next) issue_stage(std::integral_constant<int, PAR ^ 1>{});
+        const int mt_pub = mt_n;
+        if (++mt == mt1) { mt = mt0; ++gq; }
 
         const bool active = wave_has_keys && (q0 <= w_qhi_max) && (q0 + 31 >= w_qlo_min);
-        auto publish_stats = [&]() {      // next stage's statistics -> LDS (loaded a whole stage ago: no wait)
-            if (NSTG == 2 && wave == 0 && it + 1 < n_iter)
-                reinterpret_cast<float*>(stg_base + ((it + 1) % NSTG) * STG + 2 * QT)[lane] = stat_fix(stat_next, mt_n * DKV2_BQ);
-        };
-        if (!active) { publish_stats(); continue; }
-        // ---- S = Q K^T, dP = dO V^T ----
+        if (active) {
+        // ---- S = Q K^T, dP = dO V^T - D ----
         f32x16 s_acc, dp_acc;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { s_acc[r] = 0.f; dp_acc[r] = 0.f; }
+        for (int r = 0; r < 16; ++r) s_acc[r] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const f32x4 d4 = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(st_rp + (SB + 128 + 32 * i));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dp_acc[4 * i + e] = DROPOUT ? 0.f : d4[e];       // the accumulator starts from -D
+        }
+        f32x4 dneg[DROPOUT ? 4 : 1];
+        if (DROPOUT) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                dneg[i] = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(st_rp + (SB + 128 + 32 * i));
+        }
         if (BIAS == 2) {
             const float slope = p.alibi_slopes[b * p.alibi_batch_stride + h];
             const u32x4 ab = alibi_lane_operand<T>(lane, slope / p.softmax_scale, -1.f, (float)l31, (float)(kw0 - off - q0));
@@ -1015,22 +1040,15 @@ __global__ void __launch_bounds__(BWD_THREADS, D <= 64 ? FA_DKV2_OCC64 : 2) fa_b
         }
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks) {
-            const u32x4 qa = lds_read_b128(qs + a_rd[ks]);
-            const u32x4 kb2 = lds_read_b128(ks_base + kv_row0 + a_rd[ks]);
-            const u32x4 da = lds_read_b128(dos + a_rd[ks]);
-            u32x4 vb2;
-            if (VREG) vb2 = vf[ks]; else vb2 = lds_read_b128(vs_base + kv_row0 + a_rd[ks]);
+            const u32x4 qa = lds_read_b128(q_rp[ks] + SB);
+            const u32x4 kb2 = lds_read_b128(k_rp[ks]);
+            const u32x4 da = lds_read_b128(q_rp[ks] + (SB + QT));
             s_acc = E::mfma(qa, kb2, s_acc);
-            dp_acc = E::mfma(da, vb2, dp_acc);
+            dp_acc = E::mfma(da, vf[ks], dp_acc);
         }
         // ---- P, dS ----
         const bool need_mask = key_tail || (q0 < w_qlo_max) || (q0 + 31 > w_qhi_min);
-        const bool empty = qhi < qlo;                      // folded into the operands (see fa_fwd.hip)
-        const int lo_t = empty ? 0x3fffffff : qlo - q0 - 4 * g;
-        const uint32_t width = empty ? 0u : (uint32_t)(qhi - qlo);
         u32x4 pf[2], dsf[2];
-        const int sidx = 16 * g;                             // byte index of lane 4 g for ds_bpermute
-        (void)sidx;
         float pv[16], dsv[16];
         uint32_t kbits = 0xffffu;
         if (DROPOUT) {
@@ -1055,44 +1073,35 @@ __global__ void __launch_bounds__(BWD_THREADS, D <= 64 ? FA_DKV2_OCC64 : 2) fa_b
                 kbits |= ((a3 >> (4 * i + kq)) & 1u) << (4 * i + 3);
             }
         }
+        f32x4 l4[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            f32x4 l4 = {0, 0, 0, 0}, d4 = {0, 0, 0, 0};
-            if (NSTG == 2) {
-                const float* st = reinterpret_cast<const float*>(qs + 2 * QT);
-                l4 = *reinterpret_cast<const f32x4*>(st + 8 * i + 4 * g);
-                d4 = *reinterpret_cast<const f32x4*>(st + 32 + 8 * i + 4 * g);
+        for (int i = 0; i < 4; ++i) l4[i] = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(st_rp + (SB + 32 * i));
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float l2 = l4[r >> 2][r & 3];
+            float pr, chain = 1.0f;
+            if (BIAS == 3) {
+                const float rr1 = fast_rcp(1.0f + fast_exp2(s_acc[r] * cap_k1));
+                const float t = fmaf(rr1, -2.0f, 1.0f);
+                pr = fast_exp2(fmaf(rr1, -2.0f * cap_c2, cap_c2) - l2);
+                chain = fmaf(-t, t, 1.0f);
+            } else {
+                pr = fast_exp2(fmaf(s_acc[r], c, -l2));
             }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int r = 4 * i + e;
-                const int cpos = e + 8 * i;                  // row = cpos + 4 g
-                float l2, dsm;
-                if (NSTG == 2) { l2 = l4[e]; dsm = d4[e]; }
-                else {
-                    l2 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(sidx + 4 * cpos, __builtin_bit_cast(int, statv)));
-                    dsm = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(sidx + 4 * (32 + cpos), __builtin_bit_cast(int, statv)));
-                }
-                float pr, chain = 1.0f;
-                if (BIAS == 3) {
-                    const float rr1 = fast_rcp(1.0f + fast_exp2(s_acc[r] * cap_k1));
-                    const float t = fmaf(rr1, -2.0f, 1.0f);
-                    pr = fast_exp2(fmaf(rr1, -2.0f * cap_c2, cap_c2) - l2);
-                    chain = fmaf(-t, t, 1.0f);
-                } else {
-                    pr = fast_exp2(fmaf(s_acc[r], c, -l2));
-                }
-                if (DROPOUT) {       // dS = P (keep rp dP - D); dV accumulates keep P (rp applied in the epilogue)
-                    const bool keep = (kbits >> r) & 1u;
-                    pv[r] = keep ? pr : 0.f;
-                    dsv[r] = pr * ((keep ? dp_acc[r] * a.rp_dropout : 0.f) - dsm);
-                } else {
-                    pv[r] = pr;
-                    dsv[r] = pr * (dp_acc[r] - dsm) * chain;
-                }
+            if (DROPOUT) {       // dS = P (keep rp dP - D); dV accumulates keep P (rp applied in the epilogue)
+                const bool keep = (kbits >> r) & 1u;
+                pv[r] = keep ? pr : 0.f;
+                dsv[r] = pr * ((keep ? dp_acc[r] * a.rp_dropout : 0.f) + dneg[DROPOUT ? (r >> 2) : 0][r & 3]);
+            } else if (BIAS == 3) {
+                pv[r] = pr;
+                dsv[r] = pr * dp_acc[r] * chain;
+            } else {
+                pv[r] = pr;
+                dsv[r] = pr * dp_acc[r];
             }
         }
         if (need_mask) {                                     // wave-uniform branch: interior tiles skip all of it
+            const int lo_t = lo_l - q0;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int cpos = (r & 3) + 8 * (r >> 2);
@@ -1106,6 +1115,7 @@ __global__ void __launch_bounds__(BWD_THREADS, D <= 64 ? FA_DKV2_OCC64 : 2) fa_b
                 pf[t][w2] = E::pack2(pv[8 * t + 2 * w2], pv[8 * t + 2 * w2 + 1]);
                 dsf[t][w2] = E::pack2(dsv[8 * t + 2 * w2], dsv[8 * t + 2 * w2 + 1]);
             }
+#ifdef FA_MEASURE
         if (a.ds_ws) {
             // dS hand-off to the one-GEMM dQ kernel (see fa_bwd_dkdv_kernel): two coalesced 1-KiB stores
             char* tile = reinterpret_cast<char*>(a.ds_ws) +
@@ -1118,8 +1128,8 @@ __global__ void __launch_bounds__(BWD_THREADS, D <= 64 ? FA_DKV2_OCC64 : 2) fa_b
                 *reinterpret_cast<u32x4*>(tile + t * 1024) = u32x4{x0, x1, y0, y1};
             }
         }
+#endif
         // ---- dV^T += dO^T P,  dK^T += Q^T dS ----
-#if FA_DKV2_PF > 0
         {
             // MFMA i = (t, d, dO | Q); fences keep the transposed operand of MFMA i + PF in flight ahead of MFMA i
             // (S / dP are dead here, so the extra fragments cost no registers; hipcc alone serialises
@@ -1127,10 +1137,9 @@ __global__ void __launch_bounds__(BWD_THREADS, D <= 64 ? FA_DKV2_OCC64 : 2) fa_b
             constexpr int NBK = 4 * DBLKS;
             auto tread = [&](int i) {
                 const int t = i / (2 * DBLKS), d = (i >> 1) % DBLKS;
-                const char* src = (i & 1) ? qs : dos;
-                const int row_a = 16 * t + 4 * g + rr;
-                const u32x2 a0 = lds_read_tr16(src + swzt_row_off<D>(row_a, d * 64 + cb));
-                const u32x2 a1 = lds_read_tr16(src + swzt_row_off<D>(row_a + 8, d * 64 + cb));
+                const int o = SB + ((i & 1) ? 0 : QT) + 16 * t * D * 2;
+                const u32x2 a0 = lds_read_tr16_nw(t_rp[0][d], o);
+                const u32x2 a1 = lds_read_tr16_nw(t_rp[1][d], o);
                 return u32x4{a0[0], a0[1], a1[0], a1[1]};
             };
             u32x4 tf[NBK];
@@ -1139,6 +1148,7 @@ __global__ void __launch_bounds__(BWD_THREADS, D <= 64 ? FA_DKV2_OCC64 : 2) fa_b
 #pragma unroll
             for (int i = 0; i < NBK; ++i) {
                 if (i + FA_DKV2_PF < NBK) tf[i + FA_DKV2_PF] = tread(i + FA_DKV2_PF);
+                lds_tr_wait(tf[i], 2 * ((NBK - 1 - i) < FA_DKV2_PF ? (NBK - 1 - i) : FA_DKV2_PF));
                 __builtin_amdgcn_sched_barrier(0);
                 const int t = i / (2 * DBLKS), d = (i >> 1) % DBLKS;
                 if (i & 1) dk_acc[d] = E::mfma(tf[i], dsf[t], dk_acc[d]);
@@ -1146,24 +1156,13 @@ __global__ void __launch_bounds__(BWD_THREADS, D <= 64 ? FA_DKV2_OCC64 : 2) fa_b
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-#else
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const int row_a = 16 * t + 4 * g + rr;
-#pragma unroll
-            for (int d = 0; d < DBLKS; ++d) {
-                const u32x2 a0 = lds_read_tr16(dos + swzt_row_off<D>(row_a, d * 64 + cb));
-                const u32x2 a1 = lds_read_tr16(dos + swzt_row_off<D>(row_a + 8, d * 64 + cb));
-                u32x4 af = {a0[0], a0[1], a1[0], a1[1]};
-                dv_acc[d] = E::mfma(af, pf[t], dv_acc[d]);
-                const u32x2 b0 = lds_read_tr16(qs + swzt_row_off<D>(row_a, d * 64 + cb));
-                const u32x2 b1 = lds_read_tr16(qs + swzt_row_off<D>(row_a + 8, d * 64 + cb));
-                u32x4 bfr = {b0[0], b0[1], b1[0], b1[1]};
-                dk_acc[d] = E::mfma(bfr, dsf[t], dk_acc[d]);
-            }
-        }
-#endif
-        publish_stats();
+        }   // active
+        if (has_next) publish_stats(std::integral_constant<int, PAR ^ 1>{}, mt_pub);
+    };
+#pragma unroll 1
+    for (int it = 0; it < n_iter; it += 2) {
+        stage(std::integral_constant<int, 0>{}, it);
+        if (it + 1 < n_iter) stage(std::integral_constant<int, 1>{}, it + 1);
     }
 
     if (my_key < sg.seqlen_k) {
@@ -1505,10 +1504,10 @@ __global__ void __launch_bounds__(BWD_THREADS, OCC) fa_bwd_dq_kernel(const KArgs
                 for (int t = 0; t < 2; ++t)
 #pragma unroll
                     for (int w2 = 0; w2 < 4; ++w2) dsf[t][w2] = E::pack2(dsv[8 * t + 2 * w2], dsv[8 * t + 2 * w2 + 1]);
-                auto tread = [&](int i) {
+                auto tread = [&](int i) {           // (asm form: no vmcnt wait for the DMA of the next tile, see lds_read_tr16_nw)
                     const int t = i / DBLKS, d = i % DBLKS;
-                    const u32x2 a0 = lds_read_tr16(t_ptr[0][d] + (stage * STAGE + (kb * 32 + 16 * t) * D * 2));
-                    const u32x2 a1 = lds_read_tr16(t_ptr[1][d] + (stage * STAGE + (kb * 32 + 16 * t) * D * 2));
+                    const u32x2 a0 = lds_read_tr16_nw(t_ptr[0][d], stage * STAGE + (kb * 32 + 16 * t) * D * 2);
+                    const u32x2 a1 = lds_read_tr16_nw(t_ptr[1][d], stage * STAGE + (kb * 32 + 16 * t) * D * 2);
                     return u32x4{a0[0], a0[1], a1[0], a1[1]};
                 };
                 u32x4 tf[NDQ];
@@ -1517,6 +1516,7 @@ __global__ void __launch_bounds__(BWD_THREADS, OCC) fa_bwd_dq_kernel(const KArgs
 #pragma unroll
                 for (int i = 0; i < NDQ; ++i) {
                     if (i + FA_DQ_PFT < NDQ) tf[i + FA_DQ_PFT] = tread(i + FA_DQ_PFT);
+                    lds_tr_wait(tf[i], 2 * ((NDQ - 1 - i) < FA_DQ_PFT ? (NDQ - 1 - i) : FA_DQ_PFT));
                     __builtin_amdgcn_sched_barrier(0);
                     dq_acc[i % DBLKS] = E::mfma(tf[i], dsf[i / DBLKS], dq_acc[i % DBLKS]);
                     __builtin_amdgcn_sched_barrier(0);

@@ -89,6 +89,22 @@ __device__ __forceinline__ u32x4 lds_read_b128(const lds_char* p) {
 __device__ __forceinline__ u32x2 lds_read_tr16(const lds_char* p) {
     return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) lds_i16x4_t*)(p)));
 }
+// ds_read_b64_tr_b16 as inline asm + an explicit counted wait.  Why: for the BUILTIN form hipcc's waitcnt pass puts an
+// s_waitcnt vmcnt(0) in front of the first transposed read that follows an LDS-DMA (buffer_load ... lds) - it cannot
+// tell that the DMA in flight fills the OTHER stage buffer - so every tile step stalled for the full latency of the loads
+// it had just issued for the next tile (plain ds_read_b128 loads do not get that wait).  The asm form carries no memory
+// operand; its completion is waited for with lds_tr_wait(frag, n): n = LDS instructions issued after the fragment's
+// reads (LDS returns in order, so "at most n outstanding" means the fragment has landed; instructions the compiler
+// adds in between only make the wait stricter).  The "+v" tie keeps the consuming MFMA behind the wait.
+__device__ __forceinline__ u32x2 lds_read_tr16_nw(const lds_char* p, int off) {
+    u32x2 r;
+    const lds_char* q = p + (off & ~0xffff);             // (the offset field has 16 bits; `off` is a constant after inlining)
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(q), "i"(off & 0xffff) : "memory");
+    return r;
+}
+__device__ __forceinline__ void lds_tr_wait(u32x4& frag, int n) {
+    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(frag) : "i"(n));
+}
 __device__ __forceinline__ u32x4 lds_read_b128(const char* smem_ptr) {
     return *reinterpret_cast<const u32x4*>(smem_ptr);
 }
