@@ -843,8 +843,9 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : ((WALK && D <= 64 
             // rows kb*32 + 16 ks2 + 8 hf + 4 g + (0..3) = 16 t + ..., 64-byte column block d
             auto vread = [&](int i) {
                 const int t = i / DBLKS, d = i % DBLKS;
-                const u32x2 v0 = lds_read_tr16(v_ptr[0][d] + (stage * STAGE + 16 * t * D * 2));
-                const u32x2 v1 = lds_read_tr16(v_ptr[1][d] + (stage * STAGE + 16 * t * D * 2));
+                // (asm form + counted wait: the builtin gets an s_waitcnt vmcnt(0) - the DMA of the NEXT tile - in front of it, fa_common.h)
+                const u32x2 v0 = lds_read_tr16_nw(v_ptr[0][d], stage * STAGE + 16 * t * D * 2);
+                const u32x2 v1 = lds_read_tr16_nw(v_ptr[1][d], stage * STAGE + 16 * t * D * 2);
                 return u32x4{v0[0], v0[1], v1[0], v1[1]};
             };
             u32x4 vf[NPV];
@@ -853,6 +854,7 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : ((WALK && D <= 64 
 #pragma unroll
             for (int i = 0; i < NPV; ++i) {
                 if (i + FA_FWD_PFV < NPV) vf[i + FA_FWD_PFV] = vread(i + FA_FWD_PFV);
+                lds_tr_wait(vf[i], 2 * ((NPV - 1 - i) < FA_FWD_PFV ? (NPV - 1 - i) : FA_FWD_PFV));
                 __builtin_amdgcn_sched_barrier(0);
                 oacc[i % DBLKS] = E::mfma(vf[i], pf[i / DBLKS], oacc[i % DBLKS]);
                 if (i % DBLKS == DBLKS - 1) msum(pf[i / DBLKS]);
