@@ -16,8 +16,13 @@ path shards batch x heads with no collective, so every rank runs the full per-GP
 Besides the contract fields the JSON line carries
   roofline        - the dominant kernel of the step (by measured launch duration), its ALGORITHMIC FLOPs per launch /
                     that duration vs the 2.5 PFLOP/s dense bf16 MFMA peak; durations measured here with HIP events on
-                    the stream the kernels run on (torch's current stream).  `traffic` is NOT measured in this run: it
-                    is the HBM byte count of the committed rocprofv3 PMC passes (`traffic_source` names the file);
+                    the stream the kernels run on (torch's current stream).  `achieved` / `frac` use the MEAN launch
+                    duration (the statistic a rocprofv3 kernel trace reports; the median rides along as *_median).
+                    `practical_ceiling`: what a bare chip-wide MFMA loop on RANDOM bf16 operands sustains on THIS socket
+                    in THIS run (tools/probes/probe_mfma_ceiling.hip, ~1 s, with socket power and shader clock sampled
+                    next to the same figures for the sustained step): the part is power-limited under matrix load, the
+                    2.5 PF peak assumes 2.4 GHz.  `traffic` is NOT measured in this run: it is the HBM byte count of
+                    the committed rocprofv3 PMC passes (`traffic_source` names the file);
   kernels         - the same for every kernel of the step (fwd, bwd dK/dV, bwd dQ): median and min over individually
                     evented launches, taken right behind the timed steps; `timing.sum_over_step` compares their sum
                     with ms_per_step (tests/test_bench_contract.py fails a recorded line where they differ by > 3 %);
@@ -85,6 +90,107 @@ def med_min(ts):
 def event_time_ms(fn, iters, warm=1):
     """Median duration of `fn` over `iters` individually-evented calls."""
     return med_min(event_times_ms(fn, iters, warm))[0]
+
+
+# ------------------------------------------------------------------------------------------------ power / clock
+class _Smi:
+    """Socket power (W) and shader clock (MHz) of GPU `index`: amdsmi python module, else hwmon / pp_dpm_sclk in sysfs."""
+
+    def __init__(self, index=0):
+        self.kind = None
+        try:
+            import amdsmi
+            amdsmi.amdsmi_init()
+            self.h = amdsmi.amdsmi_get_processor_handles()[index]
+            self.amdsmi = amdsmi
+            self.kind = "amdsmi"
+            self.read()
+            return
+        except Exception:                    # noqa: BLE001
+            self.kind = None
+        import glob
+        cards = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_average") +
+                       glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_input"))
+        if cards:
+            self.pw = cards[min(index, len(cards) - 1)]
+            self.dev = os.path.dirname(os.path.dirname(os.path.dirname(self.pw)))
+            self.kind = "sysfs"
+
+    def read(self):
+        if self.kind == "amdsmi":
+            m = self.amdsmi.amdsmi_get_gpu_metrics_info(self.h)
+            w = m.get("current_socket_power") or m.get("average_socket_power")
+            clk = m.get("current_gfxclks") or m.get("current_gfxclk") or m.get("average_gfxclk_frequency")
+            if isinstance(clk, (list, tuple)):
+                vals = [x for x in clk if isinstance(x, (int, float)) and 0 < x < 60000]
+                clk = sum(vals) / len(vals) if vals else None
+            return (float(w) if isinstance(w, (int, float)) and 0 < w < 5000 else None,
+                    float(clk) if isinstance(clk, (int, float)) and 0 < clk < 60000 else None)
+        if self.kind == "sysfs":
+            w = clk = None
+            try:
+                w = int(open(self.pw).read()) / 1e6
+                for line in open(os.path.join(self.dev, "pp_dpm_sclk")):
+                    if "*" in line:
+                        clk = float(line.split(":")[1].strip().rstrip("*").strip().lower().replace("mhz", ""))
+            except Exception:                # noqa: BLE001
+                pass
+            return w, clk
+        return None, None
+
+
+def sampled(smi, fn):
+    """Run fn() (which keeps the GPU busy and returns when it is done) while a thread samples power / clock every 50 ms.
+    -> (fn's result, {"watts": mean, "mhz": mean, "samples": n}); the first 30 % of the samples (ramp) are dropped."""
+    import threading
+    stop, ws, cs = threading.Event(), [], []
+
+    def loop():
+        while not stop.is_set():
+            try:
+                w, c = smi.read()
+            except Exception:                # noqa: BLE001
+                w = c = None
+            if w:
+                ws.append(w)
+            if c:
+                cs.append(c)
+            stop.wait(0.05)
+    th = threading.Thread(target=loop, daemon=True)
+    if smi.kind:
+        th.start()
+    res = fn()
+    stop.set()
+    if smi.kind:
+        th.join(timeout=2.0)
+    tail = lambda x: x[len(x) * 3 // 10:] if len(x) >= 4 else x
+    mean = lambda x: round(sum(x) / len(x), 1) if x else None
+    return res, {"watts": mean(tail(ws)), "mhz": mean(tail(cs)), "samples": len(ws), "source": smi.kind}
+
+
+def mfma_ceiling(smi, seconds=1.0):
+    """Chip-wide bare MFMA loop on random bf16 operands for ~`seconds` (tools/probes/libfa_probe.so, built by
+    __graft_entry__.build()): the matrix rate this socket sustains at its power limit -> dict, or None without the library."""
+    import ctypes
+    path = os.path.join(ROOT, "tools", "probes", "libfa_probe.so")
+    if not os.path.exists(path):
+        return None
+    lib = ctypes.CDLL(path)
+    lib.fa_probe_mfma.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_double)]
+    ms, fl = ctypes.c_float(0), ctypes.c_double(0)
+    iters = 4000
+    torch.cuda.synchronize()
+    if lib.fa_probe_mfma(2, iters, 1, ctypes.byref(ms), ctypes.byref(fl)) != 0 or ms.value <= 0:
+        return None
+    launches = max(2, int(seconds * 1e3 / (ms.value / 2)))
+
+    def run():
+        lib.fa_probe_mfma(launches, iters, 1, ctypes.byref(ms), ctypes.byref(fl))
+        return fl.value / (ms.value * 1e-3) / 1e12
+    tf, st = sampled(smi, run)
+    return {"tflops": round(tf, 1), "seconds": round(ms.value * 1e-3, 3), "watts": st["watts"], "mhz": st["mhz"],
+            "what": "bare chip-wide v_mfma_f32_32x32x16_bf16 loop, random bf16 operands, one block of 4 waves x 8 accumulator "
+                    "chains per CU slot, measured in this run right after the timed steps (tools/probes/probe_mfma_ceiling.hip)"}
 
 
 # ------------------------------------------------------------------------------------------------ CPU baseline
@@ -404,6 +510,21 @@ def main():
         st = med_min(event_times_ms(fb, it, warm=3))
         kern["step"], kmin["step"], kmean["step"] = st[0], st[1], st.mean
 
+        # ---- the step sustained for ~2 s with power / clock sampled (this is also what a coarse GPU-busy sampler gets to
+        #      see: the K timed steps above are 45 ms), then the bare-MFMA ceiling of this socket in the same state -------
+        smi = _Smi(local_rank if world > 1 else 0)
+
+        def sustain(seconds=2.0):
+            n = max(20, int(seconds * 1e3 / ms_per_step))
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(n):
+                fb()
+            b.record(); b.synchronize()
+            return a.elapsed_time(b) / n, n
+        (sus_ms, sus_n), sus_state = sampled(smi, sustain)
+        ceiling = mfma_ceiling(smi)
+
     # ---- strong scaling, BASELINE configs[4]: every rank takes 32 / N heads of all 64 batches ----------------------
     strong = None
     if not args.no_other_configs:
@@ -432,11 +553,15 @@ def main():
         # and dQ kernel 1 (its S/dP recomputation is overhead, not algorithmic work).
         alg = {"fwd": 2 * pairs_flops, "bwd_dkdv": 4 * pairs_flops, "bwd_dq": 1 * pairs_flops}
         dur = {"fwd": t_fwd, "bwd_dkdv": kern["bwd_dkdv"], "bwd_dq": kern["bwd_dq"]}
+        kmean["bwd_dkdv"] = kmean["bwd_all"] - kmean["bwd_dq"]
         kernels = {}
         for name in ("fwd", "bwd_dkdv", "bwd_dq"):
             ach = alg[name] / (dur[name] * 1e-3) / 1e12
-            kernels[name] = {"ms": round(dur[name], 4), "ms_min": round(kmin[name], 4), "algorithmic_tflop": round(alg[name] / 1e12, 5),
-                             "achieved": round(ach, 1), "frac": round(ach / PEAK_BF16_TFLOPS, 4)}
+            ach_mean = alg[name] / (kmean[name] * 1e-3) / 1e12
+            kernels[name] = {"ms": round(dur[name], 4), "ms_min": round(kmin[name], 4), "ms_mean": round(kmean[name], 4),
+                             "algorithmic_tflop": round(alg[name] / 1e12, 5),
+                             "achieved": round(ach, 1), "frac": round(ach / PEAK_BF16_TFLOPS, 4),
+                             "achieved_mean": round(ach_mean, 1), "frac_mean": round(ach_mean / PEAK_BF16_TFLOPS, 4)}
         kernels["bwd_dkdv"]["note"] = "median(bwd, dq + dk + dv) - median(bwd, dq only): the full backward is these two launches"
         kernels["bwd_dkdv_plus_preprocess"] = {
             "ms": round(kern["bwd_dkdv_pre"], 4), "ms_min": round(kmin["bwd_dkdv_pre"], 4),
@@ -462,8 +587,18 @@ def main():
         dkdv_kernel = "fa_bwd_dkdv2_kernel" if os.environ.get("FA_BWD_ASM") == "0" else "fa_bwd_dkdv_asm_kernel"
         roofline = {"bound": "mfma", "kernel": {"fwd": fwd_kernel, "bwd_dkdv": dkdv_kernel,
                                                   "bwd_dq": "fa_bwd_dq_kernel" if os.environ.get("FA_BWD_DQ_ASM") == "0" else "fa_bwd_dq_asm_kernel"}[dom],
-                    "achieved": kernels[dom]["achieved"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                    "frac": kernels[dom]["frac"], "traffic": None}
+                    "achieved": kernels[dom]["achieved_mean"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                    "frac": kernels[dom]["frac_mean"], "statistic": "mean launch duration over 30 evented launches (what a rocprofv3 "
+                    "kernel trace averages); median-based figures: achieved_median / frac_median",
+                    "achieved_median": kernels[dom]["achieved"], "frac_median": kernels[dom]["frac"], "traffic": None}
+        roofline["practical_ceiling"] = ceiling
+        if ceiling:
+            roofline["frac_of_ceiling"] = round(kernels[dom]["achieved_mean"] / ceiling["tflops"], 4)
+            roofline["step_frac_of_ceiling"] = round(step_flops / (sus_ms * 1e-3) / 1e12 / ceiling["tflops"], 4)
+            roofline["fwd_frac_of_ceiling"] = round(kernels["fwd"]["achieved_mean"] / ceiling["tflops"], 4)
+        roofline["sustained_step"] = {"ms": round(sus_ms, 4), "steps": sus_n, "tflops": round(step_flops / (sus_ms * 1e-3) / 1e12, 1),
+                                      "watts": sus_state["watts"], "mhz": sus_state["mhz"], "power_source": sus_state["source"],
+                                      "note": "the step back to back for ~2 s after the timed region, socket power and shader clock sampled every 50 ms"}
         tr = measured_traffic(roofline["kernel"])
         if tr:
             roofline["traffic"] = tr[0]

@@ -129,6 +129,22 @@ def build(force=False, verbose=False, defines=(), out=None):
     return LIB
 
 
+PROBE_SRC = os.path.join(ROOT, "tools", "probes", "probe_mfma_ceiling.hip")
+PROBE_LIB = os.path.join(ROOT, "tools", "probes", "libfa_probe.so")
+
+
+def build_probe(force=False):
+    """Measurement aid next to the product library (never linked into it): the chip-wide random-operand MFMA loop bench.py
+    runs after the timed steps for roofline.practical_ceiling (tools/probes/probe_mfma_ceiling.hip)."""
+    if (not force and os.path.exists(PROBE_LIB) and os.path.getmtime(PROBE_LIB) >= os.path.getmtime(PROBE_SRC)):
+        return PROBE_LIB
+    r = subprocess.run([_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", PROBE_SRC, "-o", PROBE_LIB],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    if r.returncode != 0:
+        raise RuntimeError("probe build failed:\n" + r.stdout.decode(errors="replace"))
+    return PROBE_LIB
+
+
 def _build_variant(defines, out, verbose):
     tag = hashlib.sha256(" ".join(defines).encode()).hexdigest()[:8]
     bdir = os.path.join(CSRC, "build", "var_" + tag)
@@ -158,3 +174,4 @@ if __name__ == "__main__":
         print(build(out=os.path.abspath(sys.argv[2]), defines=sys.argv[3:]))
         sys.exit(0)
     print(build(force="--force" in sys.argv, verbose=True))
+    print(build_probe(force="--force" in sys.argv))

@@ -65,7 +65,7 @@ static int check_common(const fa_params& p, bool need_out) {
     FA_CHECK(p.q && (no_keys || (p.k && p.v)), "q, k, v must not be NULL");
     FA_CHECK(!need_out || (p.o && p.lse), "o and lse must not be NULL");
     FA_CHECK(p.dtype == FA_FP16 || p.dtype == FA_BF16, "q must be fp16 or bf16");
-    FA_CHECK(p.reserved0 == 0, "fa_params::reserved0 must be 0 (zero-initialise the struct)");
+    FA_CHECK((p.flags & ~FA_FLAG_KEEP_WINDOW) == 0, "fa_params::flags has unknown bits set (zero-initialise the struct)");
     FA_CHECK(p.batch > 0, "batch size must be positive");
     FA_CHECK(p.head_dim <= 256, "head dimension must be <= 256");
     FA_CHECK(p.head_dim % 8 == 0, "head dimension must be multiple of 8");
@@ -96,16 +96,17 @@ static int check_common(const fa_params& p, bool need_out) {
     return FA_OK;
 }
 
-// Flag normalisation (reference: fused_mha_forward.cu:343-352).  A window is dropped only where dropping it cannot
-// change a result: a left window of >= seqlen_k keys never hides one (the smallest j' is seqlen_q - seqlen_k, the largest
-// row seqlen_q - 1), a right window hides key j' > i + wr, i.e. something while wr < seqlen_q - 1.  The reference tests
-// `>= seqlen_k` only, which is the same thing for seqlen_q <= seqlen_k and silently un-masks rows when seqlen_q is larger
-// (divergence 8; what a context-parallel shard looks like: all queries over a slice of the keys).
+// Flag normalisation, the reference's (fused_mha_forward.cu:343-352): a window of >= seqlen_k keys is dropped.  For
+// seqlen_q <= seqlen_k that cannot change a result.  For seqlen_q > seqlen_k a right window of seqlen_k <= wr < seqlen_q - 1
+// keys still hides key j' > i + wr from the first rows and the reference un-masks them; the drop-in API does the same.
+// FA_FLAG_KEEP_WINDOW (this library's context-parallel wrapper: all queries over a slice of the keys, the shard's causal
+// offset as a right window) drops a right window only where it hides nothing.
 static void normalize(fa_params& p, bool kvcache) {
     if (p.seqlen_q == 1 && !p.alibi_slopes) p.is_causal = 0;
     if (kvcache && p.is_causal) p.window_right = 0;
     if (p.window_left >= p.seqlen_k) p.window_left = -1;
-    if (p.window_right >= p.seqlen_k && p.window_right >= p.seqlen_q - 1) p.window_right = -1;
+    const bool keep = (p.flags & FA_FLAG_KEEP_WINDOW) != 0;
+    if (p.window_right >= p.seqlen_k && (!keep || p.window_right >= p.seqlen_q - 1)) p.window_right = -1;
 }
 
 static fa::KArgs make_args(const fa_params& p, int block_m) {

@@ -9,7 +9,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FA_MI355_LIB") or os.path.join(_HERE, "libfa_mi355.so")   # env: A/B experiment builds
 
 FA_FP16, FA_BF16, FA_FP8_E4M3 = 0, 1, 2
-FA_ABI_VERSION = 2
+FA_ABI_VERSION = 3
+FA_FLAG_KEEP_WINDOW = 1
 
 _i64, _i32, _f32, _u64 = ctypes.c_int64, ctypes.c_int32, ctypes.c_float, ctypes.c_uint64
 _ptr = ctypes.c_void_p
@@ -48,7 +49,7 @@ class FaParams(ctypes.Structure):
         ("rotary_cos", _ptr), ("rotary_sin", _ptr),
         ("rotary_interleaved", _i32), ("seqlen_ro", _i32),
         ("k_descale", _f32), ("v_descale", _f32),
-        ("num_splits", _i32), ("reserved0", _i32),
+        ("num_splits", _i32), ("flags", _i32),
         ("workspace", _ptr), ("workspace_bytes", ctypes.c_size_t),
     ]
 

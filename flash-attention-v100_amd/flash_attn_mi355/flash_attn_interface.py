@@ -13,6 +13,7 @@ deliberate (DESIGN.md "divergences"):
   * `flash_attn_with_kvcache` accepts fp8-e4m3 caches with `k_descale` / `v_descale`.
 There is no CPU fallback: tensors must live on an AMD GPU and the HIP library must load.
 """
+import collections
 import ctypes
 import traceback
 import warnings
@@ -202,8 +203,10 @@ def _base_params(q, dtype, scale, causal, window_size, softcap):
 # DENSE ATTENTION (B, M, H, D)
 # ======================================================================================
 def _dense_forward(q, k, v, dropout_p, softmax_scale, causal, window_size, softcap, alibi_slopes,
-                   return_softmax, out=None):
-    """One fa_fwd call on [B, S, H, D] views (any strides with a contiguous last dim)."""
+                   return_softmax, out=None, keep_window=False):
+    """One fa_fwd call on [B, S, H, D] views (any strides with a contiguous last dim).  keep_window (sharding.py only):
+    FA_FLAG_KEEP_WINDOW - a right window of >= seqlen_k keys stays a window where it still hides keys (seqlen_q >
+    seqlen_k); the public functions keep the reference's normalisation, which drops it."""
     _check_device(q, k, v)
     _check_qkv(q, k, v)
     if q.dim() != 4:
@@ -229,6 +232,8 @@ def _dense_forward(q, k, v, dropout_p, softmax_scale, causal, window_size, softc
     p.lse_batch_stride, p.lse_head_stride = lse.stride(0), lse.stride(1)
     p.batch, p.nheads_q, p.nheads_k = B, H_Q, H_K
     p.seqlen_q, p.seqlen_k = M, N
+    if keep_window:
+        p.flags = _lib.FA_FLAG_KEEP_WINDOW
     _set_head_dim(p, dpad)
     _alibi(p, alibi_slopes, B, H_Q, q.device)
     rng = _philox(p, dropout_p, B, H_Q, q.device)
@@ -248,7 +253,7 @@ def _dense_forward(q, k, v, dropout_p, softmax_scale, causal, window_size, softc
 
 
 def _dense_backward(dout, q_, k_, v_, out_, lse, alibi_slopes, dropout_p, softmax_scale, causal,
-                    window_size, softcap, rng, dq_, dk_, dv_):
+                    window_size, softcap, rng, dq_, dk_, dv_, keep_window=False):
     """One fa_bwd call; dq_/dk_/dv_ are caller-allocated [B, S, H, dpad] views (written in place).  dq_ = None, or
     dk_ = dv_ = None, skips that gradient's kernel (autograd's needs_input_grad)."""
     B, M, H_Q, dpad = q_.shape
@@ -271,6 +276,8 @@ def _dense_backward(dout, q_, k_, v_, out_, lse, alibi_slopes, dropout_p, softma
     p.lse_batch_stride, p.lse_head_stride = lse.stride(0), lse.stride(1)
     p.batch, p.nheads_q, p.nheads_k = B, H_Q, H_K
     p.seqlen_q, p.seqlen_k = M, N
+    if keep_window:
+        p.flags = _lib.FA_FLAG_KEEP_WINDOW
     _set_head_dim(p, dpad)
     _alibi(p, alibi_slopes, B, H_Q, q_.device)
     _philox(p, dropout_p, B, H_Q, q_.device, rng=rng)
@@ -664,6 +671,7 @@ def flash_attn_with_kvcache(q, k_cache, v_cache, k=None, v=None, rotary_cos=None
                        num_splits, k_descale, v_descale)
     plan = _KV_PLANS.get(key) if key is not None else None
     if plan is not None:
+        _KV_PLANS.move_to_end(key)
         tmpl, ws_bytes, lse_shape = plan
         pp = FaParams.from_buffer_copy(tmpl)
         out = torch.empty_like(q)
@@ -789,15 +797,16 @@ def flash_attn_with_kvcache(q, k_cache, v_cache, k=None, v=None, rotary_cos=None
     with _on_device(q.device):
         _lib.call("fa_fwd_kvcache", p, _stream(q.device))
     if key is not None:                                  # (the call went through: this geometry passes every check)
-        if len(_KV_PLANS) >= 256:
-            _KV_PLANS.clear()
+        while len(_KV_PLANS) >= _KV_PLANS_MAX:           # least recently used geometry out (a workload whose geometry keeps
+            _KV_PLANS.popitem(last=False)                # changing must not wipe the plans of the steady ones)
         _KV_PLANS[key] = (bytes(p), ws_bytes, tuple(lse.shape))
     if return_softmax_lse:
         return out, lse
     return out
 
 
-_KV_PLANS = {}
+_KV_PLANS = collections.OrderedDict()
+_KV_PLANS_MAX = 256
 
 
 def _geom(t):
@@ -808,16 +817,21 @@ def _kv_plan_key(q, k_cache, v_cache, k, v, rotary_cos, rotary_sin, cache_seqlen
                  block_table, softmax_scale, causal, window_size, softcap, rotary_interleaved, alibi_slopes, num_splits,
                  k_descale, v_descale):
     """Everything flash_attn_with_kvcache's checks and fa_params fields depend on, except the data pointers - or None
-    when the call needs the slow path anyway (an int cache_seqlens, inputs that must be made contiguous first)."""
+    when the call needs the slow path anyway: an int cache_seqlens, descales given as tensors, or ANY input the slow path
+    would route through maybe_contiguous() (the template holds the strides of the tensors the kernel was launched on: a
+    view such as hidden[:, -1:] or block_table[:, :n] has a unit last stride but is not contiguous, and its copy's
+    strides under the original's data pointer would read the wrong rows)."""
     if not isinstance(q, torch.Tensor) or isinstance(cache_seqlens, int):
         return None
+    if isinstance(k_descale, torch.Tensor) or isinstance(v_descale, torch.Tensor):
+        return None
     for t in (q, k, v, cache_seqlens, cache_batch_idx, cache_leftpad, block_table):
-        if t is not None and (t.dim() == 0 or t.stride(-1) != 1):
+        if t is not None and (t.dim() == 0 or not t.is_contiguous()):
             return None
     return (_geom(q), _geom(k_cache), _geom(v_cache), _geom(k), _geom(v), _geom(rotary_cos), _geom(rotary_sin),
             _geom(cache_seqlens), _geom(cache_batch_idx), _geom(cache_leftpad), _geom(block_table), _geom(alibi_slopes),
             softmax_scale, bool(causal), tuple(window_size), float(softcap), bool(rotary_interleaved), int(num_splits),
-            k_descale, v_descale)
+            None if k_descale is None else float(k_descale), None if v_descale is None else float(v_descale))
 
 
 # ======================================================================================

@@ -60,8 +60,11 @@ def merge_attention_shards(outs, lses):
 
 
 def _local_fwd(q, k, v, window, scale):
-    from .flash_attn_interface import flash_attn_func
-    o, lse, _ = flash_attn_func(q, k, v, softmax_scale=scale, causal=False, window_size=window, return_attn_probs=True)
+    """Local attention of one rank: all queries over its key shard, the shard's causal offset as a right window.  That window
+    is >= the shard's length on every rank but the last, where the public API - like the reference, fused_mha_forward.cu:351-352
+    - would drop it; the private keep_window route (FA_FLAG_KEEP_WINDOW) keeps it."""
+    from . import flash_attn_interface as fi
+    o, lse, *_ = fi._dense_forward(q, k, v, 0.0, scale, False, window, 0.0, None, False, keep_window=True)
     return o, lse
 
 
@@ -76,7 +79,7 @@ def _local_bwd(dout, q, k, v, out, lse, window, scale):
     q_, k_, v_, o_ = (fi._prep(t, dpad) for t in (q, k, v, out))
     dq_, dk_, dv_ = (fi._prep(torch.empty_like(t), dpad) for t in (q_, k_, v_))
     fi._dense_backward(dout, q_, k_, v_, o_, lse.contiguous(), None, 0.0, d ** -0.5 if scale is None else scale, False,
-                       window, 0.0, None, dq_, dk_, dv_)
+                       window, 0.0, None, dq_, dk_, dv_, keep_window=True)
     return dq_[..., :d], dk_[..., :d], dv_[..., :d]
 
 

@@ -30,7 +30,13 @@
 extern "C" {
 #endif
 
-#define FA_ABI_VERSION 2   /* 2: fa_params::reserved0 (was bwd_phases); fa_bwd / fa_varlen_bwd skip outputs passed as NULL */
+#define FA_ABI_VERSION 3   /* 2: fa_bwd / fa_varlen_bwd skip outputs passed as NULL; 3: fa_params::flags (was reserved0) */
+
+/* fa_params::flags.  The reference drops a window of >= seqlen_k keys before anything else (fused_mha_forward.cu:343-352); so
+ * do the five ops.  With seqlen_q > seqlen_k that also drops right windows that still hide keys from the first rows - the
+ * mask of a context-parallel shard (all queries over a slice of the keys).  FA_FLAG_KEEP_WINDOW keeps such a window; it is an
+ * extension for this library's own sharding wrapper and never set by the drop-in Python API. */
+#define FA_FLAG_KEEP_WINDOW 1
 
 typedef enum fa_dtype {
     FA_FP16 = 0,      /* IEEE half */
@@ -141,7 +147,7 @@ typedef struct fa_params {
 
     /* ---- split-KV (decode) ---- */
     int32_t num_splits;             /* 0 = heuristic, 1 = no split */
-    int32_t reserved0;              /* must be 0 (ABI 1 had a measurement switch here; ABI 2 rejects non-zero values) */
+    int32_t flags;                  /* FA_FLAG_* bits, 0 for the reference's semantics (unknown bits are rejected) */
     void*   workspace;              /* >= fa_*_workspace_bytes(params) bytes, or NULL if 0 */
     size_t  workspace_bytes;
 } fa_params;

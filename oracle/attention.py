@@ -45,19 +45,19 @@ def round_to(x, dtype):
 
 
 def normalize_flags(seqlen_q, seqlen_k, causal, window_left, window_right, has_alibi,
-                    kvcache=False):
+                    kvcache=False, keep_window=False):
     """kernel/fused_mha_forward.cu:343-352 (dense), fused_mha_forward_varlen.cu:425,481-482
-    (varlen: pass max_seqlen_*), fused_mha_forward_kvcache.cu:465-466,597-598 (kvcache)."""
+    (varlen: pass max_seqlen_*), fused_mha_forward_kvcache.cu:465-466,597-598 (kvcache).
+    keep_window: not the reference - the product's FA_FLAG_KEEP_WINDOW (include/fa_mi355.h), used by its context-parallel
+    wrapper only: a right window of >= seqlen_k keys is dropped only where it hides nothing (seqlen_q > seqlen_k: key
+    j' > i + wr is hidden and j' reaches seqlen_q - 1)."""
     if seqlen_q == 1 and not has_alibi:
         causal = False
     if kvcache and causal:
         window_right = 0
     if window_left >= seqlen_k:
         window_left = -1
-    # the reference drops a right window of >= seqlen_k keys; that is a no-op only while seqlen_q <= seqlen_k
-    # (key j' > i + wr is hidden, j' reaches seqlen_q - 1).  For seqlen_q > seqlen_k the reference un-masks rows the
-    # caller asked to mask; this restatement (and the product) keeps the window there - DESIGN section 5, divergence 8.
-    if window_right >= seqlen_k and window_right >= seqlen_q - 1:
+    if window_right >= seqlen_k and (not keep_window or window_right >= seqlen_q - 1):
         window_right = -1
     return causal, window_left, window_right
 
@@ -102,7 +102,7 @@ def _slope(alibi_slopes, b, h):
 
 def attn_fwd(q, k, v, scale, causal=False, window=(-1, -1), softcap=0.0, alibi_slopes=None,
              dropout_p=0.0, seed=0, offset=0, out_dtype=None, normalize=True,
-             return_p=False):
+             return_p=False, keep_window=False):
     """q [B,Hq,Sq,D], k/v [B,Hk,Sk,D] -> out [B,Hq,Sq,D] fp64 (rounded to out_dtype if
     given), lse [B,Hq,Sq] fp32, keep-mask [Sq,Sk] or None.
 
@@ -115,7 +115,7 @@ def attn_fwd(q, k, v, scale, causal=False, window=(-1, -1), softcap=0.0, alibi_s
     Hk, Sk = k.shape[1], k.shape[2]
     wl, wr = window
     if normalize:
-        causal, wl, wr = normalize_flags(Sq, Sk, causal, wl, wr, alibi_slopes is not None)
+        causal, wl, wr = normalize_flags(Sq, Sk, causal, wl, wr, alibi_slopes is not None, keep_window=keep_window)
     group = Hq // Hk
     out = np.zeros((B, Hq, Sq, v.shape[3]), dtype=np.float64)
     lse = np.full((B, Hq, Sq), -np.inf, dtype=np.float64)
@@ -154,7 +154,7 @@ def attn_fwd(q, k, v, scale, causal=False, window=(-1, -1), softcap=0.0, alibi_s
 
 
 def attn_bwd(dout, q, k, v, out, lse, scale, causal=False, window=(-1, -1), softcap=0.0,
-             alibi_slopes=None, dropout_p=0.0, seed=0, offset=0, normalize=True):
+             alibi_slopes=None, dropout_p=0.0, seed=0, offset=0, normalize=True, keep_window=False):
     """Returns dq [B,Hq,Sq,D], dk, dv [B,Hk,Sk,D] (fp64) and softmax_d [B,Hq,Sq].
 
       D_i   = sum_d O_id * dO_id   (from the saved 16-bit O)    include/product.h:72-94
@@ -173,7 +173,7 @@ def attn_bwd(dout, q, k, v, out, lse, scale, causal=False, window=(-1, -1), soft
     Hk, Sk = k.shape[1], k.shape[2]
     wl, wr = window
     if normalize:
-        causal, wl, wr = normalize_flags(Sq, Sk, causal, wl, wr, alibi_slopes is not None)
+        causal, wl, wr = normalize_flags(Sq, Sk, causal, wl, wr, alibi_slopes is not None, keep_window=keep_window)
     group = Hq // Hk
     dq = np.zeros_like(q)
     dk = np.zeros_like(k)

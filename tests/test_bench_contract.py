@@ -50,6 +50,13 @@ def test_bench_json_line_contract():
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 2500.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert r["traffic"] is None or (r["traffic"] > 1e8 and "NOT measured in this run" in r["traffic_source"])
+    # the socket's own matrix ceiling, measured in the run (bare MFMA loop, random operands), next to the nominal peak
+    pc = r["practical_ceiling"]
+    assert pc is not None and 1000.0 < pc["tflops"] <= 2600.0 and pc["seconds"] > 0.3, pc
+    assert abs(r["frac_of_ceiling"] - r["achieved"] / pc["tflops"]) < 1e-3
+    assert r["frac_of_ceiling"] < 1.0 and r["step_frac_of_ceiling"] < 1.0
+    assert r["sustained_step"]["steps"] >= 20 and r["sustained_step"]["tflops"] > 0
+    assert abs(r["frac_median"] - r["achieved_median"] / r["peak"]) < 1e-3
     oc = d["other_configs"]
     assert {"config3", "config4_fp8_kv", "config4_fp16_kv", "config5_shard_1_of_8"} <= set(oc)
     assert oc["config4_fp8_kv"]["achieved_gbs"] > 0 and oc["config3"]["fwd_tflops"] > 0

@@ -561,6 +561,46 @@ def test_kvcache_plan_cache_repeats_a_geometry_with_new_tensors():
     assert len(fi._KV_PLANS) == n_plans + 1
 
 
+def test_kvcache_plan_cache_is_not_used_for_views_that_get_copied():
+    """Round-4 advisor finding: q = hidden[:, -1:] (the usual way to take the last token) and a column slice of a wider block
+    table have a unit last stride but are not contiguous; the slow path copies them, so a plan keyed on the ORIGINAL strides
+    held the COPY's strides and a second call read the wrong rows without an error.  Two calls per geometry, each compared bit
+    for bit with the same call on an empty plan table (and with contiguous inputs)."""
+    from flash_attn_mi355 import flash_attn_interface as fi
+    fa = _fa()
+    dt = "bf16"
+    B, Hq, Hk, D, page, pps, T = 3, 8, 2, 128, 64, 6, 5
+    def mk(seed):
+        nblk = B * pps
+        kc = rand16((nblk, page, Hk, D), dt, seed); vc = rand16((nblk, page, Hk, D), dt, seed + 1)
+        bt_wide = torch.randperm(nblk * 2, generator=torch.Generator().manual_seed(seed))[:B * (pps + 3)].remainder(nblk) \
+            .reshape(B, pps + 3).to(torch.int32).cuda()
+        hidden = rand16((B, T, Hq, D), dt, seed + 2)
+        kn_all = rand16((B, T, Hk, D), dt, seed + 3); vn_all = rand16((B, T, Hk, D), dt, seed + 4)
+        lens = torch.tensor([100 + 37 * i for i in range(B)], dtype=torch.int32).cuda()
+        return hidden[:, -1:], kc, vc, kn_all[:, -1:], vn_all[:, -1:], lens, bt_wide[:, :pps]
+    def call(args, contiguous=False):
+        q, kc, vc, kn, vn, lens, bt = args
+        if contiguous:
+            q, kn, vn, bt = q.contiguous(), kn.contiguous(), vn.contiguous(), bt.contiguous()
+        kc, vc = kc.clone(), vc.clone()
+        o, l = fa.flash_attn_with_kvcache(q, kc, vc, k=kn, v=vn, cache_seqlens=lens, block_table=bt, causal=True,
+                                          return_softmax_lse=True)
+        return o, l, kc, vc
+    a1, a2 = mk(40), mk(50)
+    assert a1[0].stride(-1) == 1 and not a1[0].is_contiguous() and not a1[6].is_contiguous()
+    fi._KV_PLANS.clear()
+    ref = call(a2, contiguous=True)
+    fi._KV_PLANS.clear()
+    call(a1)                                             # views: must not leave a plan behind ...
+    assert len(fi._KV_PLANS) == 0
+    got1 = call(a2)                                      # ... so the repeat call is as good as the first
+    got2 = call(a2)
+    for got in (got1, got2):
+        for x, y in zip(got, ref):
+            assert torch.equal(x.contiguous(), y)
+
+
 @pytest.mark.parametrize("Hq,Hk,dt", [(32, 8, "fp16"), (64, 8, "bf16"), (8, 8, "bf16")])
 def test_fp8_decode_keeps_the_mass_of_many_small_probabilities(Hq, Hk, dt):
     """One key with a large score and thousands with scores ~8.5 below it: every one of those probabilities is ~2e-4 of the

@@ -528,10 +528,10 @@ def test_context_parallel_two_shards_on_one_gpu(causal, Sq, Sk, N):
     q = rand16((B, Sq, H, D), dt, 1); k = rand16((B, Sk, Hk, D), dt, 2); v = rand16((B, Sk, Hk, D), dt, 3)
     skl = Sk // N
     outs, lses = [], []
+    from flash_attn_mi355 import sharding
     for r in range(N):
         window = (-1, (N - 1 - r) * skl) if causal else (-1, -1)
-        o, lse, _ = fa.flash_attn_func(q, k[:, r * skl:(r + 1) * skl], v[:, r * skl:(r + 1) * skl], causal=False,
-                                       window_size=window, return_attn_probs=True)
+        o, lse = sharding._local_fwd(q, k[:, r * skl:(r + 1) * skl], v[:, r * skl:(r + 1) * skl], window, None)
         outs.append(o); lses.append(lse)
     out, lse = merge_attention_shards(outs, lses)
     t = lambda x: f64(x).transpose(0, 2, 1, 3)
@@ -574,30 +574,58 @@ def test_context_parallel_backward_two_shards_on_one_gpu(causal, Sq, Sk, N):
     assert_close(t(k1.grad), g_ref[1], dt, "dk (autograd)", mult=2.0)
 
 
-@pytest.mark.parametrize("Sq,Sk,wr", [(1024, 256, 256), (1024, 256, 700), (1024, 256, 1022), (1024, 256, 1023),
-                                       (300, 64, 64), (300, 64, 298)])
-def test_right_window_longer_than_the_key_side_is_kept(Sq, Sk, wr):
-    """seqlen_q > seqlen_k: a right window of seqlen_k <= wr < seqlen_q - 1 keys still hides keys from the first rows
-    (j - (Sk - Sq) > i + wr).  The reference drops every window >= seqlen_k (fused_mha_forward.cu:343-352) - DESIGN
-    section 5, divergence 8; forward and backward against the oracle, which keeps it."""
+_LONG_RIGHT_WINDOWS = [(1024, 256, 256), (1024, 256, 700), (1024, 256, 1022), (1024, 256, 1023), (300, 64, 64), (300, 64, 298)]
+
+
+@pytest.mark.parametrize("Sq,Sk,wr", _LONG_RIGHT_WINDOWS)
+def test_right_window_of_at_least_seqlen_k_is_dropped_like_the_reference(Sq, Sk, wr):
+    """seqlen_q > seqlen_k and a right window of wr >= seqlen_k keys: the reference drops the window before launching
+    (fused_mha_forward.cu:351-352) although for wr < seqlen_q - 1 it would still hide keys from the first rows.  The drop-in
+    API must give the REFERENCE's result: forward and backward equal the call without a window, bit for bit, and the oracle
+    (reference normalisation)."""
     fa = _fa()
     dt = "fp16"
     B, H, D = 1, 2, 128
-    q = rand16((B, Sq, H, D), dt, 1).requires_grad_(True); k = rand16((B, Sk, H, D), dt, 2).requires_grad_(True)
-    v = rand16((B, Sk, H, D), dt, 3).requires_grad_(True); do = rand16((B, Sq, H, D), dt, 4)
-    o, lse, _ = fa.flash_attn_func(q, k, v, window_size=(-1, wr), return_attn_probs=True)
-    o.backward(do)
+    def run(window):
+        q = rand16((B, Sq, H, D), dt, 1).requires_grad_(True); k = rand16((B, Sk, H, D), dt, 2).requires_grad_(True)
+        v = rand16((B, Sk, H, D), dt, 3).requires_grad_(True); do = rand16((B, Sq, H, D), dt, 4)
+        o, lse, _ = fa.flash_attn_func(q, k, v, window_size=window, return_attn_probs=True)
+        o.backward(do)
+        return q, k, v, do, o, lse
+    q, k, v, do, o, lse = run((-1, wr))
+    q0, k0, v0, _, o0, lse0 = run((-1, -1))
+    for a, b in ((o, o0), (lse, lse0), (q.grad, q0.grad), (k.grad, k0.grad), (v.grad, v0.grad)):
+        assert torch.equal(a, b)
     t = lambda x: f64(x.detach()).transpose(0, 2, 1, 3)
     o_ref, lse_ref, _ = oracle.attn_fwd(t(q), t(k), t(v), D ** -0.5, window=(-1, wr))
+    assert_close(t(o), o_ref, dt, "out")
+
+
+@pytest.mark.parametrize("Sq,Sk,wr", _LONG_RIGHT_WINDOWS)
+def test_private_keep_window_route_keeps_a_right_window_longer_than_the_key_side(Sq, Sk, wr):
+    """FA_FLAG_KEEP_WINDOW (include/fa_mi355.h; sharding._local_fwd / _local_bwd, the per-rank calls of
+    context_parallel_attention): seqlen_q > seqlen_k, a right window of seqlen_k <= wr < seqlen_q - 1 keys still hides keys
+    from the first rows (j - (Sk - Sq) > i + wr) and is kept; forward and backward against the oracle's keep_window form."""
+    from flash_attn_mi355 import sharding
+    dt = "fp16"
+    B, H, D = 1, 2, 128
+    q = rand16((B, Sq, H, D), dt, 1); k = rand16((B, Sk, H, D), dt, 2); v = rand16((B, Sk, H, D), dt, 3)
+    do = rand16((B, Sq, H, D), dt, 4)
+    o, lse = sharding._local_fwd(q, k, v, (-1, wr), None)
+    dq, dk, dv = sharding._local_bwd(do, q, k, v, o, lse, (-1, wr), None)
+    t = lambda x: f64(x.detach()).transpose(0, 2, 1, 3)
+    o_ref, lse_ref, _ = oracle.attn_fwd(t(q), t(k), t(v), D ** -0.5, window=(-1, wr), keep_window=True)
     if wr < Sq - 1:                                                # the window really hides something: row 0 sees
         n_vis0 = max(0, min(Sk, wr + 1 - (Sq - Sk)))               # keys j <= wr - (Sq - Sk)
         assert n_vis0 < Sk
+        o_drop, _, _ = oracle.attn_fwd(t(q), t(k), t(v), D ** -0.5, window=(-1, wr))
+        assert np.abs(o_drop - o_ref).max() > 1e-4                 # (and the two normalisations really differ here: >= 1 key of row 0)
     g_ref = oracle.attn_bwd(t(do), t(q), t(k), t(v), oracle.round_to(o_ref, dt), lse_ref.astype(np.float64), D ** -0.5,
-                            window=(-1, wr))
+                            window=(-1, wr), keep_window=True)
     assert_close(t(o), o_ref, dt, "out")
-    assert_close(t(q.grad), g_ref[0], dt, "dq", mult=2.0)
-    assert_close(t(k.grad), g_ref[1], dt, "dk", mult=2.0)
-    assert_close(t(v.grad), g_ref[2], dt, "dv", mult=2.0)
+    assert_close(t(dq), g_ref[0], dt, "dq", mult=2.0)
+    assert_close(t(dk), g_ref[1], dt, "dk", mult=2.0)
+    assert_close(t(dv), g_ref[2], dt, "dv", mult=2.0)
 
 
 # ------------------------------------------------------------------------------------------------ fp8 matrix-vector decode

@@ -176,3 +176,34 @@ def test_kvcache_plan_key_is_geometry_only():
     assert k0 != key(q, kc[:, :, :1].expand(-1, -1, 2, -1), vc, lens, bt)        # same shape, other strides
     assert key(q, kc, vc, 5, bt) is None                                          # int cache_seqlens: slow path
     assert key(q[..., ::2], kc, vc, lens, bt) is None                             # last dim not contiguous: slow path
+    # unit last stride but NOT contiguous: the slow path copies these (maybe_contiguous), so the plan's strides would belong
+    # to the copy - such calls must not be keyed (round-4 advisor finding: q = hidden[:, -1:], block_table[:, :n])
+    hidden = torch.randn(2, 7, 4, 64).to(torch.float16)
+    assert hidden[:, -1:].stride(-1) == 1 and not hidden[:, -1:].is_contiguous()
+    assert key(hidden[:, -1:], kc, vc, lens, bt) is None
+    wide = torch.arange(2 * 5, dtype=torch.int32).reshape(2, 5)
+    assert key(q, kc, vc, lens, wide[:, :3]) is None
+    assert key(q, kc, vc, torch.zeros(4, dtype=torch.int32)[::2], bt) is None
+    kn = torch.randn(2, 3, 2, 64).to(torch.float16)
+    assert key(q, kc, vc, lens, bt, k=kn[:, :1], v=kn[:, :1]) is None
+    assert key(q, kc, vc, lens, bt, k=kn[:, :1].contiguous(), v=kn[:, :1].contiguous()) is not None
+    # descales: numbers are part of the key as floats, tensors take the slow path (no device read while building a key)
+    assert key(q, kc, vc, lens, bt, k_descale=2, v_descale=1) == key(q, kc, vc, lens, bt, k_descale=2.0, v_descale=1.0)
+    assert key(q, kc, vc, lens, bt, k_descale=torch.tensor(2.0)) is None
+
+
+def test_kvcache_plan_table_is_lru():
+    """_KV_PLANS drops the least recently USED geometry when full (it used to be wiped as a whole)."""
+    from flash_attn_mi355 import flash_attn_interface as fi
+    saved = fi._KV_PLANS.copy()
+    try:
+        fi._KV_PLANS.clear()
+        for i in range(fi._KV_PLANS_MAX):
+            fi._KV_PLANS[("g", i)] = (b"", 0, ())
+        fi._KV_PLANS.move_to_end(("g", 0))                # what a hit does
+        while len(fi._KV_PLANS) >= fi._KV_PLANS_MAX:      # what an insert does
+            fi._KV_PLANS.popitem(last=False)
+        fi._KV_PLANS[("g", "new")] = (b"", 0, ())
+        assert ("g", 0) in fi._KV_PLANS and ("g", 1) not in fi._KV_PLANS and len(fi._KV_PLANS) == fi._KV_PLANS_MAX
+    finally:
+        fi._KV_PLANS.clear(); fi._KV_PLANS.update(saved)
