@@ -54,6 +54,8 @@ V_BK = (77, 78)          # in/out: the integer n0 + 4g - q - off of the lane's r
                          # (kept exact: a float tile term accumulated over 60+ tiles drifts by 1e-3 in the LSE)
 V_BETA = 79              # in (uniform): beta
 V_C0 = 240               # 16 regs: beta * ((r & 3) + 8 (r >> 2)), the start value of every S^T accumulator chain
+V_TRI = 240              # plain variant, the same 16 registers: the triangle of an ALIGNED diagonal 32 x 32 sub-block as a lane
+                         # constant, 0 where key position (r & 3) + 8 (r >> 2) + 4 g <= row l31, -inf above (see gen_mask_routine)
 # AGPR
 A_O = (0, 64)            # O^T accumulators per q-block: [dblk] x 16
 A_Q = (128, 160)         # Q fragments per q-block: [ks] x 4
@@ -147,6 +149,7 @@ class Gen:
         self.dtype = dtype
         self.alibi = alibi
         self.reverse = alibi
+        self.tri = not alibi       # lane-constant triangle for aligned diagonal sub-blocks (the ALiBi variant owns v240..v255)
         self.mf = "v_mfma_f32_32x32x16_bf16" if dtype == "bf16" else "v_mfma_f32_32x32x16_f16"
         self.cvt = "v_cvt_pk_bf16_f32" if dtype == "bf16" else "v_cvt_pk_f16_f32"
         self.out = []          # final text lines
@@ -638,6 +641,7 @@ class Gen:
         o.append(f"v_mov_b32 {tinf}, 0xff800000")
         o.append("s_nop 0")
         st = S_SUB                                                       # s62, s63: idle after the set-up (the caller's temps are s56..s59)
+        tri = self.tri and not getattr(self, "timers_build", False)
         for kb in range(2):
             # wave-uniform state of the 32-key sub-block: every row sees all of it (nothing to do - on a causal diagonal
             # that is one of the two sub-blocks of a tile), no row sees any of it (fill), or mixed (test every element)
@@ -646,6 +650,23 @@ class Gen:
             o.append(f"s_add_u32 s{st + 1}, s{st}, 31")
             o.append(f"s_cmp_gt_i32 s{st}, s{S_HIMAX[qb]}")
             o.append(f"s_cbranch_scc1 L_mfill{u}_%=")
+            if tri:
+                # the ALIGNED diagonal sub-block of a causal-like mask: it starts at the first row's last visible key
+                # (st == HIMIN), every row sees one key more than the row above (HIMAX - HIMIN == 31: no clipping at the key
+                # tail, no row past the sequence) and no left window cuts into it - then "key position > row" is the same
+                # for every pass and tile: ONE v_add of the lane-constant triangle (0 / -inf) per element instead of the
+                # sub / compare / select chain (this routine runs on one wave while the other three wait at the barrier)
+                o.append(f"s_cmp_eq_u32 s{st}, s{S_HIMIN[qb]}")
+                o.append(f"s_cbranch_scc0 L_mnotri{u}_%=")
+                o.append(f"s_sub_u32 s{S_TOP}, s{S_HIMAX[qb]}, s{S_HIMIN[qb]}")      # (s61: the ALiBi variant's, idle here)
+                o.append(f"s_cmp_eq_u32 s{S_TOP}, 31")
+                o.append(f"s_cbranch_scc0 L_mnotri{u}_%=")
+                o.append(f"s_cmp_ge_i32 s{st}, s{S_LOMAX[qb]}")
+                o.append(f"s_cbranch_scc0 L_mnotri{u}_%=")
+                for r in range(16):
+                    o.append(f"v_add_f32 v{S + 16 * kb + r}, v{S + 16 * kb + r}, v{V_TRI + r}")
+                o.append(f"s_branch L_mnext{u}_%=")
+                o.append(f"L_mnotri{u}_%=:")
             o.append(f"s_cmp_gt_i32 s{st + 1}, s{S_HIMIN[qb]}")
             o.append(f"s_cbranch_scc1 L_mpart{u}_%=")
             o.append(f"s_cmp_lt_i32 s{st}, s{S_LOMAX[qb]}")
@@ -739,6 +760,7 @@ class Gen:
         L = []
         A = L.append
         timers = cfg.get("timers", 0)      # measurement build: s_memtime stamps land in the LSE rows r0 .. r0+4 of the wave
+        self.timers_build = bool(timers)   # (its stamps live in v246..v251: no triangle block)
 
         def stamp(i):
             if timers:
@@ -819,6 +841,20 @@ class Gen:
             for r in range(16):
                 cr = float((r & 3) + 8 * (r >> 2))
                 A(f"v_mul_f32 v{V_C0 + r}, 0x{struct.unpack('<I', struct.pack('<f', cr))[0]:08x}, v{V_BETA}")
+        if self.tri and not timers:
+            # the triangle of an aligned diagonal sub-block: register r holds key position (r & 3) + 8 (r >> 2) + 4 g of the
+            # lane's row l31 - masked (-inf) where the position is past the row
+            T = V_T
+            A(f"v_mbcnt_lo_u32_b32 v{T}, -1, 0")
+            A(f"v_mbcnt_hi_u32_b32 v{T}, -1, v{T}")
+            A(f"v_and_b32 v{T + 1}, 31, v{T}")
+            A(f"v_lshrrev_b32 v{T + 2}, 5, v{T}")
+            A(f"v_lshlrev_b32 v{T + 2}, 2, v{T + 2}")
+            A(f"v_sub_u32 v{T + 1}, v{T + 1}, v{T + 2}")             # l31 - 4 g (signed)
+            A(f"v_mov_b32 v{T + 3}, 0xff800000")
+            for r in range(16):
+                A(f"v_cmp_gt_i32 vcc, {(r & 3) + 8 * (r >> 2)}, v{T + 1}")
+                A(f"v_cndmask_b32 v{V_TRI + r}, 0, v{T + 3}, vcc")
         A(f"s_waitcnt vmcnt({2 * NP})")                  # Q and K(n_min) have landed
         if stage_q:
             A(f"s_lshl_b32 s{S_N0}, s{S_W1024}, 4")
