@@ -105,6 +105,16 @@ __device__ __forceinline__ u32x2 lds_read_tr16_nw(const lds_char* p, int off) {
 __device__ __forceinline__ void lds_tr_wait(u32x4& frag, int n) {
     asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(frag) : "i"(n));
 }
+// the byte form (fp8 operands: ds_read_b64_tr_b8) and a wait on one 8-byte fragment, same reasoning
+__device__ __forceinline__ u32x2 lds_read_tr8_nw(const lds_char* p, int off) {
+    u32x2 r;
+    const lds_char* q = p + (off & ~0xffff);
+    asm volatile("ds_read_b64_tr_b8 %0, %1 offset:%2" : "=v"(r) : "v"(q), "i"(off & 0xffff) : "memory");
+    return r;
+}
+__device__ __forceinline__ void lds_tr_wait(u32x2& frag, int n) {
+    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(frag) : "i"(n));
+}
 __device__ __forceinline__ u32x4 lds_read_b128(const char* smem_ptr) {
     return *reinterpret_cast<const u32x4*>(smem_ptr);
 }

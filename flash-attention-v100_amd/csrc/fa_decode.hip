@@ -513,8 +513,9 @@ __global__ void __launch_bounds__(64 * NW, 1) fa_decode_kernel(const DecArgs da)
             const int jj = sl >> 1;
             const int key_l = (jj & 3) + 8 * (jj >> 2) + 4 * (gg >> 1);                 // + 16 t2
             const int dby = 16 * (gg & 1) + 8 * (sl & 1);                               // + 32 d
-            typedef __attribute__((address_space(3))) i32x2_t* lds_i32x2_ptr;
-            i32x2_t vt[BN / 16][DBLKS];
+            // (asm form + counted waits, fa_common.h: the builtin gets an s_waitcnt vmcnt(0) in front of it - the DMA of the NEXT
+            //  tile, issued a moment ago - which emptied the two-stage pipeline once per tile: 5.6 TB/s where whole rows stream at 7)
+            u32x2 vt[BN / 16][DBLKS];
 #pragma unroll
             for (int t2 = 0; t2 < BN / 16; ++t2) {
                 const int key = 16 * t2 + key_l;
@@ -522,7 +523,7 @@ __global__ void __launch_bounds__(64 * NW, 1) fa_decode_kernel(const DecArgs da)
 #pragma unroll
                 for (int d = 0; d < DBLKS; ++d) {
                     const int slot = (2 * d + (gg & 1)) ^ fv;
-                    vt[t2][d] = __builtin_amdgcn_ds_read_tr8_b64_v2i32((lds_i32x2_ptr)(vs + key * D + (slot << 4) + (dby & 8)));
+                    vt[t2][d] = lds_read_tr8_nw((const lds_char*)(vs + key * D + (slot << 4) + (dby & 8)), 0);
                 }
             }
             u32x2 pt[BN / 16][NTP];
@@ -538,6 +539,7 @@ __global__ void __launch_bounds__(64 * NW, 1) fa_decode_kernel(const DecArgs da)
             for (int t2 = 0; t2 < BN / 16; ++t2)
 #pragma unroll
                 for (int d = 0; d < DBLKS; ++d) {
+                    lds_tr_wait(vt[t2][d], (BN / 16) * DBLKS - 1 - (t2 * DBLKS + d));
                     const long va = __builtin_bit_cast(long, vt[t2][d]);
 #pragma unroll
                     for (int t = 0; t < NTP; ++t) oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(va, __builtin_bit_cast(long, pt[t2][t]), oacc[d], 0, 0, 0);
@@ -551,9 +553,17 @@ __global__ void __launch_bounds__(64 * NW, 1) fa_decode_kernel(const DecArgs da)
             const int row_a = 16 * t2 + 4 * g + v_rr;
 #pragma unroll
             for (int d = 0; d < DBLKS; ++d) {
-                const u32x2 v0 = lds_read_tr16(vs + swzt_row_off<D>(row_a, d * 64 + v_cb));
-                const u32x2 v1 = lds_read_tr16(vs + swzt_row_off<D>(row_a + 8, d * 64 + v_cb));
-                u32x4 vf = {v0[0], v0[1], v1[0], v1[1]};
+                u32x4 vf;
+                if constexpr (D16) {                            // tiles by LDS-DMA: asm form, see above
+                    const u32x2 v0 = lds_read_tr16_nw((const lds_char*)(vs + swzt_row_off<D>(row_a, d * 64 + v_cb)), 0);
+                    const u32x2 v1 = lds_read_tr16_nw((const lds_char*)(vs + swzt_row_off<D>(row_a + 8, d * 64 + v_cb)), 0);
+                    vf = u32x4{v0[0], v0[1], v1[0], v1[1]};
+                    lds_tr_wait(vf, 0);
+                } else {
+                    const u32x2 v0 = lds_read_tr16(vs + swzt_row_off<D>(row_a, d * 64 + v_cb));
+                    const u32x2 v1 = lds_read_tr16(vs + swzt_row_off<D>(row_a + 8, d * 64 + v_cb));
+                    vf = u32x4{v0[0], v0[1], v1[0], v1[1]};
+                }
                 oacc[d] = E::mfma(vf, pf, oacc[d]);
             }
         }
