@@ -459,8 +459,6 @@ struct KArgs {
     int rope_q;                    // kv-cache general path: fa_fwd_kernel rotates its Q fragments in registers (rotary_cos / sin at
                                    // position cache_seqlens[b] + leftpad (+ row under a causal / local mask), include/rotary.h:176-202)
     int fuse_pre;                  // the dQ kernel computes D = rowsum(dO o O) itself, runs first and writes softmax_d + stats_ws
-    int walk;                      // forward: a workgroup walks `walk` consecutive 128-row blocks of one (sequence, head) (fa_fwd.hip);
-                                   // with it n_qblocks / flat_blocks count RUNS of that many blocks
 };
 
 // ---- ALiBi through the matrix pipe (causal-like masks: every visible key is at or left of the diagonal) ----

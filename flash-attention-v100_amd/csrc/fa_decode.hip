@@ -22,11 +22,7 @@
 
 namespace fa {
 
-#ifdef FA_DEC_NO_SADDR              // A/B switches of the round-3 addressing changes (tools/define_variant.py)
-#define FA_DEC_PIN(o)
-#else
 #define FA_DEC_PIN(o) asm volatile("" : "+v"(o))
-#endif
 #define FA_DEC_UNIFORM(x) (x)
 
 #ifndef FA_DEC_F8M
@@ -100,12 +96,12 @@ __global__ void __launch_bounds__(64 * NW, 1) fa_decode_kernel(const DecArgs da)
     static_assert(!HPW || (NW == 8 && D <= 128 && !NARROW), "a head per wave: eight waves");
     constexpr int KSTEPS = D / 16;
     constexpr int DBLKS = D / 32;
-    // (HPW over a 16-bit cache: 16-key tiles - two LDS-DMA stages of K | V fit the wave's 16 KiB, see the pipeline below)
-    constexpr bool D16 = HPW && !KV8;
-    constexpr int TILE = D16 ? 16 * D * 2 : DecSmem<D, NW>::TILE;
+    static_assert(!HPW || F8M, "a head per wave: the fp8-operand form (a 16-bit build with 16-key LDS-DMA tiles measured level in rounds 4 "
+                               "and 5 - 5.6-5.8 TB/s - and lives in tools/experiments/decode_round4_5_experiments.patch)");
+    constexpr int TILE = DecSmem<D, NW>::TILE;
     constexpr int EB = KV8 ? 1 : 2;                         // bytes per cache element
     constexpr int CPR = D * EB / 16;                        // 16-byte chunks per cache row
-    constexpr int BN = D16 ? 16 : DecSmem<D, NW>::BN;           // keys per wave tile
+    constexpr int BN = DecSmem<D, NW>::BN;                  // keys per wave tile
     constexpr int CH = BN * CPR / 64;                       // chunks per lane per tile
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -553,17 +549,9 @@ __global__ void __launch_bounds__(64 * NW, 1) fa_decode_kernel(const DecArgs da)
             const int row_a = 16 * t2 + 4 * g + v_rr;
 #pragma unroll
             for (int d = 0; d < DBLKS; ++d) {
-                u32x4 vf;
-                if constexpr (D16) {                            // tiles by LDS-DMA: asm form, see above
-                    const u32x2 v0 = lds_read_tr16_nw((const lds_char*)(vs + swzt_row_off<D>(row_a, d * 64 + v_cb)), 0);
-                    const u32x2 v1 = lds_read_tr16_nw((const lds_char*)(vs + swzt_row_off<D>(row_a + 8, d * 64 + v_cb)), 0);
-                    vf = u32x4{v0[0], v0[1], v1[0], v1[1]};
-                    lds_tr_wait(vf, 0);
-                } else {
-                    const u32x2 v0 = lds_read_tr16(vs + swzt_row_off<D>(row_a, d * 64 + v_cb));
-                    const u32x2 v1 = lds_read_tr16(vs + swzt_row_off<D>(row_a + 8, d * 64 + v_cb));
-                    vf = u32x4{v0[0], v0[1], v1[0], v1[1]};
-                }
+                const u32x2 v0 = lds_read_tr16(vs + swzt_row_off<D>(row_a, d * 64 + v_cb));
+                const u32x2 v1 = lds_read_tr16(vs + swzt_row_off<D>(row_a + 8, d * 64 + v_cb));
+                u32x4 vf = {v0[0], v0[1], v1[0], v1[1]};
                 oacc[d] = E::mfma(vf, pf, oacc[d]);
             }
         }
@@ -572,7 +560,7 @@ __global__ void __launch_bounds__(64 * NW, 1) fa_decode_kernel(const DecArgs da)
     constexpr int TS = HPW ? 1 : NW;                        // tile stride of a wave (HPW: every wave walks all tiles of the split)
     const int t0 = s_lo + (HPW ? 0 : wave);
     const int n_my = t0 < s_hi ? (s_hi - t0 + TS - 1) / TS : 0;
-    if constexpr (F8M || D16) {
+    if constexpr (F8M) {
         // The cache bytes go HBM -> LDS by LDS-DMA (buffer_load ... lds: no staging registers), two stages per wave: tile s + 1
         // lands while tile s is computed, behind a COUNTED vmcnt (the 8 pieces of the younger tile stay in flight).  The
         // destination is lane-linear (lane l of piece i -> row 8 i + l / 8, 16-byte slot l % 8), so the images' slot XORs
@@ -581,13 +569,8 @@ __global__ void __launch_bounds__(64 * NW, 1) fa_decode_kernel(const DecArgs da)
 #pragma unroll
         for (int i = 0; i < CH; ++i) {
             const int row = (lane + 64 * i) / CPR, slot = lane % CPR;
-            if constexpr (F8M) {
-                k_dma[i] = (uint32_t)(row * p.k_row_stride + ((slot ^ ((row >> 1) & 7)) << 4));
-                v_dma[i] = (uint32_t)(row * p.v_row_stride + ((slot ^ ((((row >> 3) & 1) << 2) | (row & 3))) << 4));
-            } else {                                                  // 16-bit images: swz_row_off / swzt_row_off of fa_common.h
-                k_dma[i] = (uint32_t)(row * p.k_row_stride * 2 + (swz_row_off<D>(row, slot * 16) - row * D * 2));
-                v_dma[i] = (uint32_t)(row * p.v_row_stride * 2 + (swzt_row_off<D>(row, slot * 16) - row * D * 2));
-            }
+            k_dma[i] = (uint32_t)(row * p.k_row_stride + ((slot ^ ((row >> 1) & 7)) << 4));
+            v_dma[i] = (uint32_t)(row * p.v_row_stride + ((slot ^ ((((row >> 3) & 1) << 2) | (row & 3))) << 4));
         }
         const int n_full_tiles = seqlen_k / BN;                       // tiles that lie completely inside the sequence
         auto issue = [&](int tile, int stage) -> bool {               // true: by DMA (8 pieces in flight), false: done synchronously
@@ -1240,9 +1223,6 @@ __host__ __device__ inline bool gemv_tm_applicable(const fa_params& p) {
     // and 4-9 % on 16-bit ones (B 1 33.0 -> 30.0, B 8 61.4 -> 57.4, B 64 389 -> 372; B 32 196 vs 200), and pages of 16
     // tokens cost it nothing (this kernel restarts its pipeline per page: + 12 %)
     if (!(G == 1 || G == 2)) return false;
-#ifdef FA_EXP_TM16_MAXG                 // experiment builds (tools/define_variant.py): 16-bit caches above this group size -> MFMA kernel
-    if (!kv8 && G > FA_EXP_TM16_MAXG) return false;
-#endif
     return p.nheads_k % gemv_tm_hpw(p) == 0 && p.k_head_stride == 128 && p.v_head_stride == 128;
 }
 
@@ -1532,9 +1512,6 @@ bool decode_takes(const fa_params& p) {
     //  4 x the passes - B 1, T_q 512, H 64/8 over 32 k: 0.92 ms against 1.34 -; at two per CU the general path wins)
     const int cus = device_cu_count();
     int64_t factor = fwd_wgs <= cus ? 8 : (fwd_wgs < 2 * cus ? 2 : 1);
-#ifdef FA_EXP_DEC_FACTOR                 // experiment builds only (tools/define_variant.py, tools/chunked_prefill_probe.py)
-    factor = FA_EXP_DEC_FACTOR;
-#endif
     if (row_blocks <= factor * fwd_passes) return true;
     return p.kv_dtype == FA_FP8_E4M3 && row_blocks <= 2;
 }
@@ -1561,15 +1538,10 @@ static bool decode_eight_waves(const fa_params& p);
 #ifndef FA_DEC_HPW
 #define FA_DEC_HPW 1
 #endif
-#ifndef FA_DEC_HPW16
-#define FA_DEC_HPW16 0                       // ... for 16-bit caches too (16-key tiles, LDS-DMA): measured level (5.96-5.98 vs 5.82-6.10 TB/s), off
-#endif
 static bool decode_hpw(const fa_params& p) {
     if (!FA_DEC_HPW || p.head_dim != 128 || p.head_dim_v != 0 || p.nheads_k < 8 || p.nheads_k % 8 != 0) return false;
     if (p.k_head_stride != p.head_dim || p.v_head_stride != p.head_dim || p.nheads_q % p.nheads_k != 0) return false;
-    // (16-bit caches: 16-key tiles, so that two LDS-DMA stages fit a wave's 16 KiB - with 32-key tiles staged through registers
-    //  and the Q fragments in registers as well the form spilled 37 registers and streamed at 3.5 TB/s instead of 5.9)
-    if (p.kv_dtype == FA_FP8_E4M3 ? !FA_DEC_F8M : (p.kv_dtype != p.dtype || !FA_DEC_HPW16)) return false;
+    if (p.kv_dtype != FA_FP8_E4M3 || !FA_DEC_F8M) return false;      // (fp8 caches; 16-bit ones keep a workgroup per kv-head)
     if (p.seqlen_q * (p.nheads_q / p.nheads_k) > 32) return false;
     return !gemv_tm_applicable(p) && decode_eight_waves(p);
 }
@@ -1688,9 +1660,6 @@ static int launch_decode_td(DecArgs& da, hipStream_t stream) {
                 if (paged) FA_LAUNCH_HPW(true, true, true); else FA_LAUNCH_HPW(true, false, true);
 #endif
             } else {
-#if FA_DEC_HPW16
-                if (paged) FA_LAUNCH_HPW(false, true, false); else FA_LAUNCH_HPW(false, false, false);
-#endif
             }
 #undef FA_LAUNCH_HPW
             if (da.n_splits > 1) launch_decode_combine<T>(da, stream);

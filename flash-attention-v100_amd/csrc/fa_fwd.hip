@@ -23,25 +23,6 @@
 #include "fa_common.h"
 #include "fa_rope.h"
 
-#ifdef FA_FWD_STAMPS
-// development aid (variant builds only, tools/fwd_stamps.py): s_memtime sums over wave 0 of EVERY workgroup of fa_fwd_kernel -
-// [0] entry -> work item known, [1] -> geometry (cu_seqlens) known, [2] -> first tile in LDS (first barrier), [3] tile loop,
-// [4] epilogue, [5] workgroups, [6] tile steps, [7] waits at the barriers (vmcnt(0) + s_barrier) inside the loop
-constexpr int FA_STAMP_WGS = 32768;                      // one private row per workgroup (no atomics: they would serialise the kernel)
-__device__ unsigned long long g_fwd_stamps[FA_STAMP_WGS][8];
-extern "C" int fa_debug_read_fwd_stamps(unsigned long long* out, int reset) {
-    static unsigned long long host[FA_STAMP_WGS][8];
-    int rc = (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_fwd_stamps), sizeof(host));
-    for (int j = 0; j < 8; ++j) out[j] = 0;
-    for (int i = 0; i < FA_STAMP_WGS; ++i) for (int j = 0; j < 8; ++j) out[j] += host[i][j];
-    if (reset) rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(g_fwd_stamps), (memset(host, 0, sizeof(host)), host), sizeof(host));
-    return rc;
-}
-#define FA_STAMP(var) const long long var = clock64()
-#else
-#define FA_STAMP(var)
-#endif
-
 namespace fa {
 
 constexpr int FWD_BM = 128;
@@ -56,15 +37,6 @@ constexpr int FWD_BM = 128;
 #endif
 #ifndef FA_FWD_OCC
 #define FA_FWD_OCC 2
-#endif
-#ifndef FA_FWD_PK
-#define FA_FWD_PK 0                                    // packed fp32 softmax arithmetic at D = 64 (experiment)
-#endif
-#ifndef FA_FWD_MSUM
-#define FA_FWD_MSUM 0                                  // row sums on the matrix pipe (see MSUM in the kernel): measured neutral, off
-#endif
-#ifndef FA_FWD_CMASK
-#define FA_FWD_CMASK 0                                 // lane-constant triangular masks for aligned causal / window problems: measured neutral, off
 #endif
 constexpr int FWD_BN = FA_FWD_BN;
 constexpr int FWD_NKB = FWD_BN / 32;               // 32-key blocks per tile
@@ -82,11 +54,8 @@ template <int D> struct FwdSmem {
 // KV8: the K / V rows are fp8-e4m3 (KV cache): a tile is fetched to registers (16 codes per chunk), dequantised with the
 //      packed converts of fa_common.h and written to the same LDS images - ONCE per 128 query rows (chunked prefill over an
 //      fp8 cache); `k_descale` folds into the softmax scale, `v_descale` into the final normalisation.
-// WALK: the workgroup may carry a run of more than two passes (KArgs::walk) and keeps its pipeline going across pass
-//       boundaries (tile stream, Q prefetch); instantiated for the plain 16-bit variants of D <= 128 only - the others keep
-//       the per-pass pipeline with compile-time LDS stages (their register budgets have no room for the run-time stage).
-template <typename T, int D, int BIAS, bool PAGED, bool DROPOUT, bool KV8 = false, bool WALK = false>
-__global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : ((WALK && D <= 64 && FA_FWD_OCC < 3) ? 3 : FA_FWD_OCC))) fa_fwd_kernel(const KArgs a) {
+template <typename T, int D, int BIAS, bool PAGED, bool DROPOUT, bool KV8 = false>
+__global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : FA_FWD_OCC)) fa_fwd_kernel(const KArgs a) {
     using E = Elem<T>;
     constexpr int KSTEPS = D / 16;
     constexpr int DBLKS = D / 32;
@@ -99,12 +68,10 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : ((WALK && D <= 64 
     const fa_params& p = a.p;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    FA_STAMP(st_a);
-    const WorkItem w = a.flat_blocks                  // (flat list over runs of a.walk blocks: w.qb counts runs)
-        ? decode_work_flat(blockIdx.x, a.flat_blocks, FWD_BM * ((WALK && a.walk > 1) ? a.walk : 1), p.batch, p.nheads_q, p.nheads_k, p.cu_seqlens_q, lane)
+    const WorkItem w = a.flat_blocks
+        ? decode_work_flat(blockIdx.x, a.flat_blocks, FWD_BM, p.batch, p.nheads_q, p.nheads_k, p.cu_seqlens_q, lane)
         : decode_work(blockIdx.x, p.batch, p.nheads_q, p.nheads_k, a.n_qblocks);
     if (!w.valid) return;
-    FA_STAMP(st_b);
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform
     const int l31 = lane & 31;
     const int g = lane >> 5;
@@ -142,7 +109,6 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : ((WALK && D <= 64 
     k_row0 = (int64_t)__builtin_amdgcn_readfirstlane((int)k_row0);
     q_row0 = (int64_t)__builtin_amdgcn_readfirstlane((int)q_row0);
 
-    FA_STAMP(st_c);
     const int off = seqlen_k - seqlen_q;               // bottom-right alignment
     const int wl = p.window_left;
     const int wr = p.is_causal ? 0 : p.window_right;   // causal == window_right 0 (include/mat_mul.h:92,103)
@@ -152,25 +118,12 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : ((WALK && D <= 64 
         dc.thr = a.drop_thr; dc.offset = p.philox_offset;
     }
     const uint64_t drop_n_glob = (uint64_t)p.seqlen_k;        // dense: S_k; varlen: max_seqlen_k
-    // ---- the workgroup's RUN of 128-row blocks (passes) --------------------------------------------
-    //  * a.pair_qblocks (causal load balance): q-block qb (heavy) and then its mirror n_qblocks-1-qb (light), so every
-    //    workgroup carries the same number of KV tiles;
-    //  * a.walk = R > 1 (masks with a LEFT window, packed or dense): R consecutive blocks of one (sequence, head), walked
-    //    upwards.  Consecutive blocks of a windowed row share most of their key band, the K / V tile stream simply continues
-    //    across the seam and the next block's Q rows are fetched while the current block computes;
-    //  * otherwise one block.
-    // Within a run the pipeline never drains (SEAM): the last tile step of a pass issues the first tile of the next pass,
-    // the epilogue's stores leave behind the next pass's first MFMAs, Q of pass i + 1 is requested at the start of pass i.
-    const int n_qb_seq = (seqlen_q + FWD_BM - 1) / FWD_BM;
-    int n_pass = 1;
-    if (WALK && a.walk > 1) {
-        const int left = n_qb_seq - w.qb * a.walk;
-        if (left <= 0) return;                                               // (the spare slot of the flat list)
-        n_pass = left < a.walk ? left : a.walk;
-    } else if (a.pair_qblocks && (a.n_qblocks_total - 1 - w.qb) != w.qb) {
-        n_pass = 2;
-    }
-    auto qb_of = [&](int pass) { return (WALK && a.walk > 1) ? w.qb * a.walk + pass : (pass == 0 ? w.qb : a.n_qblocks_total - 1 - w.qb); };
+    // ---- the workgroup's passes: with a.pair_qblocks (causal load balance) q-block qb (heavy) and then its mirror
+    //      n_qblocks-1-qb (light), so that every workgroup carries the same number of KV tiles; otherwise one block.
+    //      (A workgroup walking a RUN of consecutive blocks with the tile stream continuing across the seams was built for
+    //      BASELINE config 3 in round 4 and measured slower at every run length: tools/experiments/fwd_d64_round4_experiments.patch)
+    const int n_pass = (a.pair_qblocks && (a.n_qblocks_total - 1 - w.qb) != w.qb) ? 2 : 1;
+    auto qb_of = [&](int pass) { return pass == 0 ? w.qb : a.n_qblocks_total - 1 - w.qb; };
     // key-tile range of the 128-row block at row m0
     auto tile_range = [&](int m0, int& t_min, int& t_max) {
         t_min = 0; t_max = (seqlen_k + FWD_BN - 1) / FWD_BN;
@@ -185,23 +138,15 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : ((WALK && D <= 64 
             if (kmin > 0) t_min = kmin / FWD_BN;
         }
         if (m0 >= seqlen_q) t_max = t_min;                                   // (no rows: no tiles)
-        // WALK: every pass takes an EVEN number of tile steps, so that it starts in LDS stage 0 and the stages stay
-        // compile-time constants across the seams.  The extra tile lies below the window / above the last visible key:
-        // no wave computes on it (wave_active), it costs one tile load and one barrier.
-        if (WALK && ((t_max - t_min) & 1)) { if (t_min > 0) --t_min; else ++t_max; }
     };
     // per-pass state (set by begin_pass)
     int m_block = 0, n_min = 0, n_max = 0;
-    int nx_min = 0, nx_max = 0;                        // tile range of the NEXT pass of the run (nx_min >= nx_max: none)
-    int q_next_row = -1;                               // WALK: this lane's row in the next pass (-1: no next pass with tiles)
     int wave_row0 = 0, my_row = 0;                     // this wave's first row, this lane's query row
     int lo = 0, hi = -1;                               // visible keys of my row: lo <= j <= hi
     int w_hi_min = 0, w_hi_max = 0, w_lo_max = 0, w_lo_min = 0;   // wave-uniform bounds for tile skipping / mask elision
     auto begin_pass = [&](int pass) {
         m_block = qb_of(pass) * FWD_BM;
         tile_range(m_block, n_min, n_max);
-        nx_min = nx_max = 0;
-        if (pass + 1 < n_pass) tile_range(qb_of(pass + 1) * FWD_BM, nx_min, nx_max);
         wave_row0 = m_block + wave * 32;
         my_row = wave_row0 + l31;
         lo = 0; hi = seqlen_k - 1;
@@ -259,10 +204,7 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : ((WALK && D <= 64 
             dst[ks] = buf_load_b128(q_rsrc, (row < seqlen_q && 16 * ks + 8 * g < dv) ? base + 32 * ks : kOobVoff, 0);
     };
     u32x4 qf[KSTEPS];
-    int qnext_row = -1;                                // WALK: >= 0 in the last tile step of a pass - the next pass's row of this lane, whose
-                                                       // Q is fetched into qf right behind the pass's last S MFMAs (qf is dead from there on)
     auto rope_q = [&]() {
-#ifndef FA_NO_ROPE_Q
         if (a.rope_q && my_row < seqlen_q) {
             // kv-cache call with rotary tables: rotate the row in registers (no rotated-Q copy, no extra launch).  The
             // partner chunk of the non-interleaved form (d +- rotary_dim / 2) is one more 16-byte load per chunk.
@@ -289,7 +231,6 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : ((WALK && D <= 64 
                 }
             }
         }
-#endif
     };
 
     // ---- staging ---------------------------------------------------------------------------
@@ -531,43 +472,6 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : ((WALK && D <= 64 
         for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
     float m_run = -INFINITY;     // running (deferred) max, log2 domain (scaled)
     float l_run = 0.f;           // this lane's partial row sum (its 32 keys per tile)
-    // MSUM: the row sums ride on the matrix pipe.  v_mfma_f32_4x4x4_16b_f16 with A = ones gives every lane the sum of ITS
-    // OWN four B values in all four result registers (16 independent 4 x 4 blocks, lane 4 b + j owns column j:
-    // tools/probes/probe_mfma4x4.hip) - so one such MFMA (2 passes) per register PAIR of the packed P that feeds P V anyway
-    // replaces four v_add_f32, with a 4-register accumulator.  Where the VALU is the busiest unit (D = 64: 13.6 VALU per
-    // MFMA, matrix pipe 28 % busy at BASELINE config 3) that takes 33 of ~180 VALU instructions out of a 64-key tile.
-    // l is then the sum of the ROUNDED probabilities - the same P that O's numerator uses.  fp16 only (11-bit P: the row
-    // sum moves by < 2^-12 relative); bf16 keeps the fp32 adds.
-    constexpr bool MSUM = FA_FWD_MSUM && (BIAS == 0) && !DROPOUT && std::is_same<T, fp16_tag>::value && D <= 128;
-    typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
-    f32x4 lacc = {0.f, 0.f, 0.f, 0.f};
-    const h16x4 ones_a = {(_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f};
-    auto msum = [&](const u32x4& pk) {                 // lacc += this lane's eight probabilities of pk
-        if constexpr (MSUM) {
-            const u32x2 lo2 = {pk[0], pk[1]}, hi2 = {pk[2], pk[3]};
-            lacc = __builtin_amdgcn_mfma_f32_4x4x4f16(ones_a, __builtin_bit_cast(h16x4, lo2), lacc, 0, 0, 0);
-            lacc = __builtin_amdgcn_mfma_f32_4x4x4f16(ones_a, __builtin_bit_cast(h16x4, hi2), lacc, 0, 0, 0);
-        }
-    };
-    // CMASK: causal / windowed masks whose edges fall on 32-key boundaries relative to the wave's rows (seqlen_k - seqlen_q
-    // and the left window multiples of 32, no right window): the diagonal and the window-edge sub-block then have ONE
-    // triangular pattern each, a lane constant - bit r of `vis_diag` / `vis_edge` says whether this lane's register r is
-    // visible - built once per workgroup, and only those two 32 x 32 sub-blocks pay a select (2 VALU per element); every
-    // other visible sub-block is mask-free.  (The general path builds per-row bit words per tile and selects over the
-    // whole 64-key tile: ~84 VALU instructions where 32 do.)
-    constexpr bool CMASK = FA_FWD_CMASK && (BIAS == 0) && !DROPOUT;
-    uint32_t vis_diag = 0, vis_edge = 0;
-    if (CMASK) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int kk = (r & 3) + 8 * (r >> 2) + 4 * g;
-            vis_diag |= (kk <= l31 ? 1u : 0u) << r;                 // key k0 + kk is visible to row r0 + l31 on the diagonal
-            vis_edge |= (kk >= l31 ? 1u : 0u) << r;                 // ... at the left window's edge
-        }
-    }
-    const bool cmask_ok = CMASK && wr == 0 && (off & 31) == 0 && (wl < 0 || (wl & 31) == 0);
-    (void)cmask_ok;
-
     // lane-constant LDS read offsets
     int k_rd[KSTEPS];
 #pragma unroll
@@ -618,9 +522,7 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : ((WALK && D <= 64 
         for (int kb = 0; kb < FWD_NKB; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
-#ifndef FA_NO_SETPRIO
         __builtin_amdgcn_s_setprio(1);
-#endif
 #if FA_FWD_PFK > 0
         {
             // hipcc's scheduler, left alone, serialises read -> wait -> MFMA through ONE temporary (every
@@ -648,10 +550,7 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : ((WALK && D <= 64 
             for (int kb = 0; kb < FWD_NKB; ++kb) sacc[kb] = E::mfma(kk[kb], qf[ks], sacc[kb]);
         }
 #endif
-#ifndef FA_NO_SETPRIO
         __builtin_amdgcn_s_setprio(0);
-#endif
-        if constexpr (WALK) { if (qnext_row >= 0) { load_q(qnext_row, qf); qnext_row = -1; } }
         // ---- bias / softcap (rare variants), then masking on edge tiles ----
         float shift = 0.f;
         if (BIAS && lin) {
@@ -686,27 +585,7 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : ((WALK && D <= 64 
                 }
         }
         const bool need_mask = (n0 + FWD_BN - 1 > w_hi_min) || (n0 < w_lo_max);
-        if (CMASK && need_mask && cmask_ok) {
-#pragma unroll
-            for (int kb = 0; kb < FWD_NKB; ++kb) {
-                const int dlt = n0 + 32 * kb - (wave_row0 + off);          // sub-block's first key relative to the wave's diagonal
-                if (dlt > 0 || (wl >= 0 && dlt < -wl)) {                    // nothing visible
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) sacc[kb][r] = -INFINITY;
-                } else {
-                    uint32_t vw = 0xffffu;
-                    if (dlt == 0) vw &= vis_diag;
-                    if (wl >= 0 && dlt == -wl) vw &= vis_edge;
-                    if (vw != 0xffffu || dlt == 0 || (wl >= 0 && dlt == -wl)) {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const uint32_t m = (uint32_t)((int32_t)(vw << (31 - r)) >> 31);
-                            sacc[kb][r] = select_bits(sacc[kb][r], m, 0xff800000u);
-                        }
-                    }
-                }
-            }
-        } else if (need_mask) {
+        if (need_mask) {
             // the key of register (kb, r) is n0 + 4 g + c with c a compile-time constant: the lane builds the visibility
             // bits of its row for this tile once (bit c set <=> lo <= n0 + 4 g + c <= hi; one 32-bit word per 32-key
             // block), and every element costs a sign-extending bit extract and a three-input bit op (v_bfe_i32,
@@ -748,9 +627,6 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : ((WALK && D <= 64 
 #pragma unroll
         for (int kb = 1; kb < FWD_NKB; ++kb) mx = max3_f32(mx, mxb[kb], kb + 1 < FWD_NKB ? sacc[kb][15] : mxb[kb]);
         mx = xhalf_max(mx) * c;
-#ifdef FA_FWD_KO_MAX             // timing knock-out: no row maximum (the compiler drops the max tree)
-        mx = m_run == -INFINITY ? 0.f : m_run;
-#endif
         if (BIAS) mx += shift;
         // keep the old max unless some row of the wave would exceed it by > 2^THR
         // (NaN-safe: -inf - -inf compares false -> takes the rescale path)
@@ -760,10 +636,6 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : ((WALK && D <= 64 
             const float alpha = fast_exp2(m_run - m_use);
             m_run = m_new;
             l_run *= alpha;
-            if constexpr (MSUM) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) lacc[r] *= alpha;
-            }
 #pragma unroll
             for (int d = 0; d < DBLKS; ++d)
 #pragma unroll
@@ -772,37 +644,13 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : ((WALK && D <= 64 
         const float m_use = (m_run == -INFINITY) ? 0.f : m_run;
         const float ms = BIAS ? m_use - shift : m_use;
         float psum = 0.f;
-#if FA_FWD_PK
-        if constexpr (D <= 64) {
-            // D = 64: the matrix pipe is the idle unit (28 % busy), the VALU the busy one - here packed fp32 (v_pk_fma_f32 /
-            // v_pk_add_f32: two elements per instruction through the matrix datapath) takes 32 + 32 instructions down to 16 + 16
-            typedef float f32x2v __attribute__((ext_vector_type(2)));
-            const f32x2v c2 = {c, c}, nm2 = {-ms, -ms};
-            f32x2v ps2 = {0.f, 0.f};
-#pragma unroll
-            for (int kb = 0; kb < FWD_NKB; ++kb)
-#pragma unroll
-                for (int r = 0; r < 16; r += 2) {
-                    const f32x2v sv = {sacc[kb][r], sacc[kb][r + 1]};
-                    const f32x2v t = __builtin_elementwise_fma(sv, c2, nm2);
-                    f32x2v e2 = {fast_exp2(t[0]), fast_exp2(t[1])};
-                    sacc[kb][r] = e2[0]; sacc[kb][r + 1] = e2[1];
-                    if constexpr (!MSUM) ps2 += e2;
-                }
-            psum = ps2[0] + ps2[1];
-        } else
-#endif
 #pragma unroll
         for (int kb = 0; kb < FWD_NKB; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-#ifdef FA_FWD_KO_EXP             // timing knock-out: no exp2
-                const float e = fmaf(sacc[kb][r], c, -ms);
-#else
                 const float e = fast_exp2(fmaf(sacc[kb][r], c, -ms));
-#endif
                 sacc[kb][r] = e;
-                if constexpr (!MSUM) psum += e;
+                psum += e;
             }
         l_run += psum;                                      // PRE-dropout sum (include/softmax.h:187)
         if (DROPOUT) {
@@ -857,7 +705,6 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : ((WALK && D <= 64 
                 lds_tr_wait(vf[i], 2 * ((NPV - 1 - i) < FA_FWD_PFV ? (NPV - 1 - i) : FA_FWD_PFV));
                 __builtin_amdgcn_sched_barrier(0);
                 oacc[i % DBLKS] = E::mfma(vf[i], pf[i / DBLKS], oacc[i % DBLKS]);
-                if (i % DBLKS == DBLKS - 1) msum(pf[i / DBLKS]);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -879,95 +726,43 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : ((WALK && D <= 64 
                 u32x4 vf = {v0[0], v0[1], v1[0], v1[1]};
                 oacc[d] = E::mfma(vf, pf, oacc[d]);
             }
-            msum(pf);
         }
 #endif
     };
 
-    // Within a run the tile stream does not stop at a pass boundary (contiguous 16-bit K / V): the tile after the last one
-    // of a pass is the first one of the next pass.  (Paged and fp8 tiles keep their per-pass pipeline start: the block-table
-    // entry of a tile is requested one tile ahead inside load_tile.)
-    constexpr bool SEAM = WALK && !PAGED && !KV8;
-#ifdef FA_FWD_STAMPS
-    long long st_loop0 = 0, st_loop1 = 0, st_bar = 0; int st_steps = 0;
-#endif
     auto tile_step = [&](auto stage_c, int nb) {
         constexpr int stage = decltype(stage_c)::value;
-        const bool in_pass = nb + 1 < n_max;
-        const bool has_next = in_pass || (SEAM && nx_min < nx_max);
-        const int nb_next = in_pass ? nb + 1 : nx_min;
-#ifndef FA_FWD_KO_DMA            // timing knock-out (tools/define_variant.py): no tile loads in the loop - results are garbage
+        const bool has_next = nb + 1 < n_max;
+        const int nb_next = nb + 1;
         if (has_next) load_tile(nb_next, std::integral_constant<int, stage ^ 1>{});
-#endif
         const int n0 = nb * FWD_BN;
         // wave-uniform: does this wave see anything in this tile?
         const bool wave_active = (n0 <= w_hi_max) && (n0 + FWD_BN - 1 >= w_lo_min);
-        if constexpr (SEAM) { if (!in_pass && has_next) qnext_row = q_next_row; }
-#ifndef FA_FWD_KO_COMPUTE        // timing knock-out: loads and barriers only
         if (wave_active) compute_tile(stage_c, nb);
-#endif
-        if constexpr (SEAM) { if (qnext_row >= 0) { load_q(qnext_row, qf); qnext_row = -1; } }      // (a wave that skipped the tile)
         if (has_next) store_tile(std::integral_constant<int, stage ^ 1>{}, nb_next);
-#ifdef FA_FWD_STAMPS
-        const long long sb0 = clock64();
         __syncthreads();
-        st_bar += clock64() - sb0;
-#elif defined(FA_FWD_KO_BAR)        // timing knock-out: the tile's own loads are waited for, the other waves are not (garbage results)
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-#elif defined(FA_FWD_KO_VMWAIT)     // timing knock-out: barrier without waiting for the loads (garbage results)
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#else
-        __syncthreads();
-#endif
     };
 
-    bool primed = false;                               // the pass's first tile is in LDS stage 0 already (issued by the previous pass)
-    int q_in_pass = -1;                                // the pass whose Q rows qf holds / has in flight
     for (int pass = 0; pass < n_pass; ++pass) {
     begin_pass(pass);
     if (m_block >= seqlen_q) continue;
-    if (q_in_pass != pass) load_q(my_row, qf);
-    q_next_row = -1;
-    if (SEAM && nx_min < nx_max) { q_next_row = qb_of(pass + 1) * FWD_BM + wave * 32 + l31; q_in_pass = pass + 1; }
+    load_q(my_row, qf);
     rope_q();
 
-    if constexpr (WALK) {
-        if (n_min < n_max && !primed) {
-            load_tile(n_min, std::integral_constant<int, 0>{});
-            store_tile(std::integral_constant<int, 0>{}, n_min);
-            __syncthreads();
-        }
-        FA_STAMP(st_d);
-        for (int nb = n_min; nb < n_max; nb += 2) {              // (even number of steps: tile_range)
-            tile_step(std::integral_constant<int, 0>{}, nb);
-            tile_step(std::integral_constant<int, 1>{}, nb + 1);
-        }
-        primed = SEAM && n_min < n_max && nx_min < nx_max;
-#ifdef FA_FWD_STAMPS
-        if (pass == 0) st_loop0 = st_d;
-        st_loop1 = clock64(); st_steps += n_max > n_min ? n_max - n_min : 0;
-#endif
-    } else {
-        if (n_min < n_max) {
-            if (PAGED && (paged_aligned || paged_dma)) pf_request(n_min);
-            if (PAGED && paged_q16) pf8_request(n_min);
-            load_tile(n_min, std::integral_constant<int, 0>{});
-            store_tile(std::integral_constant<int, 0>{}, n_min);
-        }
-        __syncthreads();
-        FA_STAMP(st_d);
-        for (int nb = n_min; nb < n_max; nb += 2) {
-            tile_step(std::integral_constant<int, 0>{}, nb);
-            if (nb + 1 < n_max) tile_step(std::integral_constant<int, 1>{}, nb + 1);
-        }
-#ifdef FA_FWD_STAMPS
-        if (pass == 0) st_loop0 = st_d;
-        st_loop1 = clock64(); st_steps += n_max > n_min ? n_max - n_min : 0;
-#endif
+    if (n_min < n_max) {
+        if (PAGED && (paged_aligned || paged_dma)) pf_request(n_min);
+        if (PAGED && paged_q16) pf8_request(n_min);
+        load_tile(n_min, std::integral_constant<int, 0>{});
+        store_tile(std::integral_constant<int, 0>{}, n_min);
+    }
+    __syncthreads();
+    for (int nb = n_min; nb < n_max; nb += 2) {
+        tile_step(std::integral_constant<int, 0>{}, nb);
+        if (nb + 1 < n_max) tile_step(std::integral_constant<int, 1>{}, nb + 1);
     }
 
     // ---- epilogue: O / l, LSE ---------------------------------------------------------------
-    const float l_tot = xhalf_sum(MSUM ? lacc[0] : l_run);
+    const float l_tot = xhalf_sum(l_run);
     const float inv = l_tot > 0.f ? (DROPOUT ? a.rp_dropout : (KV8 ? p.v_descale : 1.0f)) / l_tot : 0.f;
     if (my_row < seqlen_q) {
         uint16_t* op = reinterpret_cast<uint16_t*>(p.o) + (p.cu_seqlens_q ? 0 : (int64_t)w.b * p.o_batch_stride)
@@ -994,19 +789,7 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : ((WALK && D <= 64 
             for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
         m_run = -INFINITY;
         l_run = 0.f;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) lacc[r] = 0.f;
     }
-#ifdef FA_FWD_STAMPS
-    if (tid == 0 && pass == n_pass - 1) {
-        const long long st_e = clock64();
-        unsigned long long* row = g_fwd_stamps[blockIdx.x % FA_STAMP_WGS];
-        row[0] = (unsigned long long)(st_b - st_a); row[1] = (unsigned long long)(st_c - st_b);
-        row[2] = (unsigned long long)(st_loop0 - st_c); row[3] = (unsigned long long)(st_loop1 - st_loop0);
-        row[4] = (unsigned long long)(st_e - st_loop1); row[5] = 1ull;
-        row[6] = (unsigned long long)st_steps; row[7] = (unsigned long long)st_bar;
-    }
-#endif
     }   // pass
 }
 
@@ -1050,17 +833,6 @@ static int launch_fwd_td(const KArgs& a, bool paged, hipStream_t stream) {
         else FA_LAUNCH(1, false, false);
     }
     else if (paged) FA_LAUNCH(0, true, false);
-#ifdef FA_EXP_WALK                      // experiment builds only: the WALK instantiation (see fwd_walk_blocks)
-    else if (a.walk > 1) {
-        if constexpr (D <= 64) {
-            auto kern = fa_fwd_kernel<T, D, 0, false, false, false, true>;
-            FA_SET_LDS_ONCE(kern, smem);
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(FWD_THREADS), smem, stream, a);
-        } else {
-            return -2;
-        }
-    }
-#endif
     else FA_LAUNCH(0, false, false);
 #undef FA_LAUNCH
     return 0;
@@ -1076,33 +848,9 @@ static bool fwd_asm_enabled() {
     return on;
 }
 
-// Runs of consecutive 128-row blocks per workgroup (KArgs::walk, the WALK instantiation): ONE dispatch, one geometry lookup
-// and one pipeline fill for R blocks of one (sequence, head), the K / V tile stream and the Q fetch continuing across the
-// block seams.  Built for BASELINE config 3 (packed, D 64, window 512: 18 k blocks of <= 10 tiles) and MEASURED SLOWER there
-// at every R (profiles/r04_config3_forward.txt: R 1 / 2 / 3 / 4 = 0.51-0.54 / 0.556 / 0.582 / 0.572 ms at equal occupancy;
-// VALU instructions -15 %, scalar -20 %, and the SIMDs idle more) - the per-block fixed costs are not what bounds that
-// kernel.  Kept as an experiment build (-DFA_EXP_WALK=R, tools/define_variant.py); the product runs one block per workgroup.
-static int fwd_walk_blocks(const KArgs& a) {
-#ifdef FA_EXP_WALK
-    const fa_params& p = a.p;
-    if (a.kv_mode || a.pair_qblocks || a.has_bias || p.block_table || p.p_dropout > 0.f || p.kv_dtype != p.dtype || p.head_dim > 64) return 1;
-    if (!a.flat_blocks && p.window_left < 0) return 1;
-    return FA_EXP_WALK;
-#else
-    (void)a;
-    return 1;
-#endif
-}
-
 int launch_fwd(const KArgs& a0, hipStream_t stream) {
     if (fwd_asm_enabled() && fwd_asm_applicable(a0)) return launch_fwd_asm(a0, stream);
-    KArgs a = a0;
-    const int R = fwd_walk_blocks(a);
-    if (R > 1) {
-        a.walk = R;
-        if (a.flat_blocks) a.flat_blocks = (int)(a.p.total_q / (128 * R)) + a.p.batch;
-        else a.n_qblocks = (a.n_qblocks_total + R - 1) / R;
-    }
+    const KArgs& a = a0;
     const bool paged = a.p.block_table != nullptr;
     const bool bf = a.p.dtype == FA_BF16;
     switch (a.p.head_dim) {
