@@ -75,7 +75,9 @@ def _check_asm_kernels(all_res):
         if "asm_kernel" not in name and "ws_kernel" not in name:
             continue
         total_cap = 256 if "ws_kernel" in name else 512            # two waves per SIMD | one
-        if (r.get("spill", 0) or r.get("sgpr_spill", 0) or r.get("scratch", 0) or r.get("vgpr", 0) > 256 or r.get("agpr", 0) > 256
+        # (SGPR spills are allowed: they live in lanes of the compiler's own v0..v15 around the asm statement - the paged forward
+        #  pins 85 scalar registers -, never in memory; what must not happen is scratch or a VGPR spill)
+        if (r.get("spill", 0) or r.get("scratch", 0) or r.get("vgpr", 0) > 256 or r.get("agpr", 0) > 256
                 or r.get("vgpr", 0) + r.get("agpr", 0) > total_cap):
             bad.append(f"{name}: {r}")
     if bad:

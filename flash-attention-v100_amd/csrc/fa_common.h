@@ -409,6 +409,20 @@ static inline void fa_set_max_lds(std::atomic<uint64_t>& done, const void* kern,
         fa_set_max_lds(fa_attr_done_, reinterpret_cast<const void*>(kern), (int)(bytes)); \
     } while (0)
 
+// Compute units of the current device (cached per device ordinal: one process may drive several GPUs).
+static inline int fa_device_cu_count() {
+    // per device ordinal: one process may drive several GPUs (cf. FA_SET_LDS_ONCE in fa_common.h)
+    constexpr int MAXDEV = 64;
+    static std::atomic<int> cache[MAXDEV];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) return 256;
+    int v = cache[dev].load(std::memory_order_relaxed);
+    if (v > 0) return v;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+    cache[dev].store(v, std::memory_order_relaxed);
+    return v;
+}
+
 // Mirrored block pairs (causal masks): the low block first in every workgroup.  -DFA_PAIR_FLIP=1 (experiment build)
 // alternates the order with the workgroup index so that the pro / epilogues of the CUs do not line up at launch:
 // measured 1-2 % SLOWER on forward and dQ at config 2 (tools/experiments/README.md)

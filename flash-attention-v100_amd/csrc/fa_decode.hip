@@ -1491,7 +1491,6 @@ bool decode_applicable(const fa_params& p) {
     return true;                  // any number of packed rows, 32 per workgroup (blockIdx.z); decode_takes() decides who runs
 }
 
-static int device_cu_count();
 // Which kernel serves a multi-token query block (speculative / tree decode, chunked prefill) over the cache?  Both stream
 // the K / V of a kv-head once per "pass": the decode kernel per 32 PACKED rows (t x G + g: the heads of a group share the
 // stream, split-KV fills the chip at small batch; row blocks after the first read from L2), fa_fwd_kernel per 128 query
@@ -1510,24 +1509,12 @@ bool decode_takes(const fa_params& p) {
     const int64_t fwd_wgs = (int64_t)p.batch * p.nheads_q * fwd_blocks;
     // (chunked_prefill_probe.py with FA_DEC_FACTOR: at one general-path workgroup per CU or fewer the row blocks win even at
     //  4 x the passes - B 1, T_q 512, H 64/8 over 32 k: 0.92 ms against 1.34 -; at two per CU the general path wins)
-    const int cus = device_cu_count();
+    const int cus = fa_device_cu_count();
     int64_t factor = fwd_wgs <= cus ? 8 : (fwd_wgs < 2 * cus ? 2 : 1);
     if (row_blocks <= factor * fwd_passes) return true;
     return p.kv_dtype == FA_FP8_E4M3 && row_blocks <= 2;
 }
 
-static int device_cu_count() {
-    // per device ordinal: one process may drive several GPUs (cf. FA_SET_LDS_ONCE in fa_common.h)
-    constexpr int MAXDEV = 64;
-    static std::atomic<int> cache[MAXDEV];
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) return 256;
-    int v = cache[dev].load(std::memory_order_relaxed);
-    if (v > 0) return v;
-    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
-    cache[dev].store(v, std::memory_order_relaxed);
-    return v;
-}
 
 // grid splits of the key range (x up to 4 key sub-ranges per workgroup in the token-major kernel: <= 1024 partial rows per
 // output row, merged by decode_combine_wide_kernel)
@@ -1553,7 +1540,7 @@ int decode_num_splits(const fa_params& p) {
     int s = 1;
     // one workgroup per CU: every further doubling costs 6-15 % in this kernel (each split re-reads the query rows and
     // writes a partial row; tools/decode_splits_sweep.py, H 64/8 and 32/2, B 2-64)
-    while (units * s < device_cu_count() && s < 64 && max_tiles / (s * 2) >= 8) s *= 2;       // >= 8 tiles (256 keys) per split
+    while (units * s < fa_device_cu_count() && s < 64 && max_tiles / (s * 2) >= 8) s *= 2;       // >= 8 tiles (256 keys) per split
     // The streaming fp8 kernel keeps three workgroups per CU resident: with 4096 units on 256 CUs the grid runs 5.33
     // "rounds" and the last one is a third full (11 % of the time at a third of the rate).  Split the key range so that
     // the grid is a near-multiple of what is resident; the partials cost 4 MB and one tiny combine launch.
@@ -1564,7 +1551,7 @@ int decode_num_splits(const fa_params& p) {
         // (one workgroup per CU streams best at 32 kv-heads: 2 splits 7.0 TB/s, 4 splits 6.8, 12 splits 6.4; with few kv-heads -
         // the waves of a workgroup share head groups and take key sub-ranges - two per CU are 11-16 % faster than one
         // and than four: tools/decode_splits_sweep.py, H 32/8 fp16 and fp8, B 16-256)
-        const double resident = (gemv_tm_ksub(p) > 1 ? 2.0 : 1.0) * device_cu_count();
+        const double resident = (gemv_tm_ksub(p) > 1 ? 2.0 : 1.0) * fa_device_cu_count();
         const int cap = p.seqlen_k / 32 > 0 ? (p.seqlen_k / 32 < DEC_MAX_SPLITS ? p.seqlen_k / 32 : DEC_MAX_SPLITS) : 1;     // >= 32 keys per split
         int best = 1;
         double best_score = -1.0;
@@ -1580,7 +1567,7 @@ int decode_num_splits(const fa_params& p) {
     }
     const bool gemv = p.kv_dtype == FA_FP8_E4M3 && p.head_dim == 128 && p.seqlen_q == 1 && p.nheads_q == p.nheads_k;
     if (gemv && s == 1) {
-        const double resident = 3.0 * device_cu_count();
+        const double resident = 3.0 * fa_device_cu_count();
         auto eff = [&](int k) { const double r = units * (double)k / resident; return r / (double)(int64_t)(r + 0.999999); };
         for (int k = 1; k <= 8; ++k) {
             if (k > 1 && max_tiles / k < 16) break;                             // >= 512 keys per split

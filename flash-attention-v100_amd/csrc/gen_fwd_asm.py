@@ -90,6 +90,15 @@ S_RC, S_FASTLO, S_FASTEND = 81, 82, 83     # in: 1 / c; fast-loop iteration rang
 S_QRB = 84               # in (D = 128): bytes per Q row
 S_HIMAX = (85, 86)       # in: max over the q-block's rows of the last visible key (a 32-key sub-block that starts past it is masked
                          # for every row: the mask routine fills it instead of testing each element)
+# paged K / V (block_table; pages of 64 * 2^n keys): a tile lies inside one page, its descriptor (base, extent) is rebuilt on the
+# scalar unit per tile from the block-table entry, which is requested ONE ITERATION ahead (s_load) - the reference's paged
+# path is the same kernel as the contiguous one (kernel/fused_mha_forward_varlen.cu:184-193)
+S_KB, S_VB = 87, 89      # in: words 0, 1 of the K / V descriptor of this kv-head at page 0, row 0 (s[20:23] / s[24:27] are rebuilt per tile)
+S_BT = 92                # in: s[92:93] this sequence's block-table row (an aligned pair)
+S_PSH, S_PMASK = 91, 94  # in: log2(tiles per page), tiles per page - 1
+S_KPAGE, S_VPAGE = 95, 96   # in: bytes between pages
+S_SEQK = 97              # in: keys of this sequence (rows past it read as zeros: V rows of a page's unused tail may hold anything)
+S_BLKK, S_BLKV, S_BLKN = 98, 99, 100     # owned: page of the K tile fetched this iteration (j + 4), of the V tile (j + 3), of the next K tile (in flight)
 
 # ----------------------------------------------------------------------------- head dimension (128 or 64)
 HD = 128
@@ -145,9 +154,11 @@ class Ins:
 
 
 class Gen:
-    def __init__(self, dtype, alibi=False):
+    def __init__(self, dtype, alibi=False, paged=False):
         self.dtype = dtype
         self.alibi = alibi
+        self.paged = paged
+        assert not (alibi and paged)
         self.reverse = alibi
         self.tri = not alibi       # lane-constant triangle for aligned diagonal sub-blocks (the ALiBi variant owns v240..v255)
         self.mf = "v_mfma_f32_32x32x16_bf16" if dtype == "bf16" else "v_mfma_f32_32x32x16_f16"
@@ -454,6 +465,69 @@ class Gen:
             g.append((p, "dma"))
         return g
 
+    # ------------------------------------------------------------------ paged K / V
+    def paged_desc(self, which, tile_s, blk_s):
+        """SALU: descriptor words 0..2 of the tile `tile_s` (SGPR) whose page is in `blk_s`: base = pool base + page * page
+        bytes + (tile inside the page) * tile bytes, extent = the tile's rows inside the sequence (0 .. 64) in bytes.
+        Temps s62..s65 (idle outside the called routines; the group is emitted in one piece)."""
+        rs, base, page, tileb, s16 = ((S_KRS, S_KB, S_KPAGE, S_KTILE, S_K16) if which == "k" else (S_VRS, S_VB, S_VPAGE, S_VTILE, S_V16))
+        t1, t2, t3 = S_SUB, S_SUB + 1, S_RET
+        I = lambda txt, rd, wr: Ins(txt, "salu", rd, wr, w=0.5)
+        return [
+            I(f"s_lshl_b32 s{t1}, s{tile_s}, 6", [f"s{tile_s}"], [f"s{t1}"]),
+            I(f"s_sub_i32 s{t1}, s{S_SEQK}, s{t1}", [f"s{t1}"], [f"s{t1}", "scc"]),
+            I(f"s_max_i32 s{t1}, s{t1}, 0", [f"s{t1}"], [f"s{t1}", "scc"]),
+            I(f"s_min_i32 s{t1}, s{t1}, 64", [f"s{t1}"], [f"s{t1}", "scc"]),
+            I(f"s_mul_i32 s{rs + 2}, s{t1}, s{s16}", [f"s{t1}"], [f"s{rs + 2}"]),
+            I(f"s_lshr_b32 s{rs + 2}, s{rs + 2}, 4", [f"s{rs + 2}"], [f"s{rs + 2}", "scc"]),          # rows * row bytes
+            I(f"s_and_b32 s{t2}, s{tile_s}, s{S_PMASK}", [f"s{tile_s}"], [f"s{t2}", "scc"]),
+            I(f"s_mul_i32 s{t2}, s{t2}, s{tileb}", [f"s{t2}"], [f"s{t2}"]),
+            I(f"s_mul_hi_u32 s{t3}, s{blk_s}, s{page}", [f"s{blk_s}"], [f"s{t3}"]),
+            I(f"s_mul_i32 s{t1}, s{blk_s}, s{page}", [f"s{blk_s}"], [f"s{t1}"]),
+            I(f"s_add_u32 s{t1}, s{t1}, s{t2}", [f"s{t1}", f"s{t2}"], [f"s{t1}", "scc"]),
+            I(f"s_addc_u32 s{t3}, s{t3}, 0", [f"s{t3}", "scc"], [f"s{t3}", "scc"]),
+            I(f"s_add_u32 s{rs}, s{base}, s{t1}", [f"s{t1}"], [f"s{rs}", "scc"]),
+            I(f"s_addc_u32 s{rs + 1}, s{base + 1}, s{t3}", [f"s{t3}", "scc"], [f"s{rs + 1}", "scc"]),
+        ]
+
+    def paged_request(self, tile_expr_lines, dst):
+        """raw lines: dst <- block_table[min(tile, n_max - 1) >> PSH]; tile in s62 after `tile_expr_lines`."""
+        t = S_SUB
+        return tile_expr_lines + [
+            f"s_sub_u32 s{t + 1}, s{S_NMAX}, 1",
+            f"s_min_i32 s{t}, s{t}, s{t + 1}",
+            f"s_max_i32 s{t}, s{t}, 0",
+            f"s_lshr_b32 s{t}, s{t}, s{S_PSH}",
+            f"s_lshl_b32 s{t}, s{t}, 2",
+            f"s_load_dword s{dst}, {sr(S_BT, 2)}, s{t}",
+        ]
+
+    def misc_stream_paged(self, fast):
+        """K(j+4) -> slot R0, V(j+3) -> slot R2 out of a paged cache: one group rotates the page registers and rebuilds the two
+        descriptors, the pieces then only differ in M0 and the 16-row scalar offset.  Same stream in the generic and the fast
+        copies (the fast ones take the ring slots as immediates)."""
+        g = []
+        t0 = S_TMP
+        I = lambda txt, rd, wr: Ins(txt, "salu", rd, wr, w=0.5)
+        offs = [I(f"s_add_u32 s{t0}, s{S_J}, 4", [f"s{S_J}"], [f"s{t0}", "scc"])]
+        offs += self.paged_desc("k", t0, S_BLKK)
+        offs.append(I(f"s_add_u32 s{t0}, s{S_J}, 3", [f"s{S_J}"], [f"s{t0}", "scc"]))
+        offs += self.paged_desc("v", t0, S_BLKV)
+        if fast is None:
+            offs.append(I(f"s_add_u32 s{t0 + 1}, s{S_R0}, s{S_W1024}", [], [f"s{t0 + 1}", "scc"]))
+            offs.append(I(f"s_add_u32 s{t0 + 2}, s{S_R2}, s{S_W1024}", [], [f"s{t0 + 2}", "scc"]))
+        g.append((offs, "offs"))
+        for (rs, vo, sj, reg, slot_s, slot_i) in ((S_KRS, V_DMAK, S_KJ, 0, t0 + 1, None if fast is None else fast[0]),
+                                                   (S_VRS, V_DMAV, S_VJ, LDS_VREGION, t0 + 2, None if fast is None else fast[2])):
+            for jj in range(NP):
+                so = "0" if jj == 0 else f"s{sj + jj - 1}"
+                if fast is None:
+                    m0w = Ins(f"s_add_u32 m0, s{slot_s}, {reg + 4096 * jj}", "salu", [f"s{slot_s}"], ["m0", "scc"], w=0.5)
+                else:
+                    m0w = Ins(f"s_add_u32 m0, s{S_W1024}, {reg + slot_i + 4096 * jj}", "salu", [], ["m0", "scc"], w=0.5)
+                g.append(([m0w, Ins(f"buffer_load_dwordx4 v{vo}, {sr(rs, 4)}, {so} offen lds", "dma", ["m0", f"v{vo}"], [], w=4.0)], "dma"))
+        return g
+
     def misc_stream_fast(self, fast):
         """Fast loop: K(j+4) -> slot r0, V(j+3) -> slot r2; the source tile is in the voffset registers."""
         r0, r1, r2 = fast
@@ -540,11 +614,21 @@ class Gen:
         val1 = self.softmax(0) if a1 else []
         val2 = self.softmax(1) if a1 else []
         if fast is None:
-            misc = self.misc_stream()
+            misc = self.misc_stream_paged(None) if self.paged else self.misc_stream()
             ka, va, rot = self.addr_update()
         else:
-            misc = self.misc_stream_fast(fast)
+            misc = self.misc_stream_paged(fast) if self.paged else self.misc_stream_fast(fast)
             ka, va, rot = [], [], []
+        if self.paged:
+            # the page of NEXT iteration's K tile (j + 5): requested now, read after this iteration's closing lgkmcnt(0).  (An
+            # outstanding scalar load only makes the counted LDS waits below stricter: "at most n outstanding" still implies
+            # that the LDS read n + 1 places back has returned.)
+            # (first the rotation: the entry that arrived during the previous iteration is this iteration's K page, the previous
+            #  K page - tile j + 3 - this iteration's V page; only then may the next request overwrite BLKN)
+            self.raw(f"s_mov_b32 s{S_BLKV}, s{S_BLKK}")
+            self.raw(f"s_mov_b32 s{S_BLKK}, s{S_BLKN}")
+            for l in self.paged_request([f"s_add_u32 s{S_SUB}, s{S_J}, 5"], S_BLKN):
+                self.raw(l)
 
         # ---- phase 1
         if a1 and fast is None and "maskchk" not in self.ko:
@@ -565,6 +649,8 @@ class Gen:
         for ins in rot:
             self.emit(ins)
         self.drain_lds()
+        if self.paged:
+            self.raw("s_waitcnt lgkmcnt(0)")          # the block-table entry requested at the top of the iteration
 
     def _emit_valu(self, ins):
         if ins.kind == "call_rescale":
@@ -741,6 +827,18 @@ class Gen:
         o = []
         rs, tb, s16, vo, reg = ((S_KRS, S_KTILE, S_K16, V_DMAK, 0) if which == "k" else
                                 (S_VRS, S_VTILE, S_V16, V_DMAV, LDS_VREGION))
+        if self.paged:
+            # synchronous lookup (the prologue is not hot), then the tile's own descriptor
+            o += self.paged_request([f"s_mov_b32 s{S_SUB}, s{tile_s}"], S_BLKN)
+            o.append("s_waitcnt lgkmcnt(0)")
+            o += [i.txt for i in self.paged_desc(which, tile_s, S_BLKN)]
+            o.append(f"s_add_u32 s{tmp + 1}, s{slot_s}, s{S_W1024}")
+            for jj in range(NP):
+                o.append(f"s_add_u32 m0, s{tmp + 1}, {reg + 4096 * jj}")
+                o.append("s_nop 0")
+                so = "0" if jj == 0 else f"s{(S_KJ if which == 'k' else S_VJ) + jj - 1}"
+                o.append(f"buffer_load_dwordx4 v{vo}, {sr(rs, 4)}, {so} offen lds")
+            return o
         if self.reverse:
             o.append(f"s_sub_u32 s{tmp}, s{S_TOP}, s{tile_s}")
             o.append(f"s_mul_i32 s{tmp}, s{tmp}, s{tb}")
@@ -824,6 +922,12 @@ class Gen:
         L += self.gen_dma_tile("v", t, S_R1, t + 1)
         A(f"s_add_u32 s{t}, s{S_J}, 3")
         L += self.gen_dma_tile("k", t, S_R2, t + 1)
+        if self.paged:
+            # page registers for the first iteration (j = n_min - 2): its V tile is n_min + 1 (BLKK rotates into BLKV), its K
+            # tile n_min + 2 (BLKN rotates into BLKK); gen_dma_tile left the page of tile n_min + 1 in BLKN
+            A(f"s_mov_b32 s{S_BLKK}, s{S_BLKN}")
+            L += self.paged_request([f"s_add_u32 s{S_SUB}, s{S_J}, 4"], S_BLKN)
+            A("s_waitcnt lgkmcnt(0)")
         # ---- state
         for i in range(2 * 16 * DB):
             A(f"v_accvgpr_write_b32 a{i}, 0")
@@ -882,16 +986,17 @@ class Gen:
             A("s_cbranch_scc0 L_generic_%=")
             A(f"s_cmp_lt_i32 s{S_J}, s{S_FASTEND}")
             A("s_cbranch_scc0 L_generic_%=")
-            A(f"s_add_u32 s{t1}, s{S_J}, 4")
-            if self.reverse:
-                A(f"s_sub_u32 s{t1}, s{S_TOP}, s{t1}")
-            A(f"s_mul_i32 s{t1}, s{t1}, s{S_KTILE}")
-            A(f"v_add_u32 v{V_DMAK_CUR}, s{t1}, v{V_DMAK}")
-            A(f"s_add_u32 s{t1}, s{S_J}, 3")
-            if self.reverse:
-                A(f"s_sub_u32 s{t1}, s{S_TOP}, s{t1}")
-            A(f"s_mul_i32 s{t1}, s{t1}, s{S_VTILE}")
-            A(f"v_add_u32 v{V_DMAV_CUR}, s{t1}, v{V_DMAV}")
+            if not self.paged:
+                A(f"s_add_u32 s{t1}, s{S_J}, 4")
+                if self.reverse:
+                    A(f"s_sub_u32 s{t1}, s{S_TOP}, s{t1}")
+                A(f"s_mul_i32 s{t1}, s{t1}, s{S_KTILE}")
+                A(f"v_add_u32 v{V_DMAK_CUR}, s{t1}, v{V_DMAK}")
+                A(f"s_add_u32 s{t1}, s{S_J}, 3")
+                if self.reverse:
+                    A(f"s_sub_u32 s{t1}, s{S_TOP}, s{t1}")
+                A(f"s_mul_i32 s{t1}, s{t1}, s{S_VTILE}")
+                A(f"v_add_u32 v{V_DMAV_CUR}, s{t1}, v{V_DMAV}")
             A(f"s_cmp_eq_u32 s{S_R0}, 0")
             A("s_cbranch_scc1 L_fast0_body_%=")
             A(f"s_cmp_eq_u32 s{S_R0}, {LDS_STAGE}")
@@ -1064,8 +1169,10 @@ DEFAULT_CFG = {
 }
 
 
-def clobbers(alibi=False):
+def clobbers(alibi=False, paged=False):
     c = ["memory", "vcc", "scc", "m0"]
+    if paged:
+        c += [f"s{i}" for i in (S_BLKK, S_BLKV, S_BLKN)]
     c += [f"v{i}" for i in range(37, 256) if not (alibi and i in (V_BK[0], V_BK[1], V_BETA))]      # (v16..v36 are inputs)
     c += [f"a{i}" for i in range(256)]
     c += [f"s{i}" for i in range(S_R0, S_LAST + 1)]
@@ -1092,10 +1199,10 @@ def main():
     print("// GENERATED by gen_fwd_asm.py - do not edit.  See that script for the schedule and the register map.")
     print("#pragma once")
     print(f"#define {prefix}_LDS_BYTES {6 * LDS_STAGE + (65536 if HD == 128 and cfg.get('stage_q', True) else 0)}")
-    for alibi in (False, True):
-        tag = "ALIBI_" if alibi else ""
+    for (alibi, paged) in ((False, False), (True, False)) + (((False, True),) if HD == 128 else ()):
+        tag = "ALIBI_" if alibi else ("PAGED_" if paged else "")
         for dt in ("bf16", "f16"):
-            g = Gen(dt, alibi=alibi)
+            g = Gen(dt, alibi=alibi, paged=paged)
             g.ko = ko
             body, report = g.gen_body(cfg)
             print(f"#define {prefix}_{tag}BODY_{dt.upper()} \\")
@@ -1104,7 +1211,7 @@ def main():
             print('    ""')
             for k, (st, n) in report.items():
                 print(f"// {dt} {tag}variant a0a1a2={k}: {n} lines, nop states {st['nop_states']}, lgkmcnt waits {st['lgkm_waits']}")
-        cl = ", ".join(f'"{c}"' for c in clobbers(alibi))
+        cl = ", ".join(f'"{c}"' for c in clobbers(alibi, paged))
         print(f"#define {prefix}_{tag}CLOBBERS {cl}")
 
 

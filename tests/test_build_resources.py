@@ -18,7 +18,8 @@ def test_asm_kernels_have_no_spills_and_fit_the_register_file():
         for n, cap in names.items():
             if n in mangled:
                 seen.add(n)
-                assert r["spill"] == 0 and r["sgpr_spill"] == 0 and r["scratch"] == 0, (mangled, r)
+                # (SGPR spills go to lanes of the compiler's own VGPRs around the asm statement, not to memory: allowed)
+                assert r["spill"] == 0 and r["scratch"] == 0, (mangled, r)
                 assert r["vgpr"] <= 256 and r["agpr"] <= 256 and r["vgpr"] + r["agpr"] <= cap, (mangled, r)
     assert seen == set(names), seen
 

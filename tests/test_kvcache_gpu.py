@@ -493,6 +493,58 @@ def test_kvcache_paged_chunk_prefill_general_path(lp_kind):
     assert_lse_close(f64(lse), lse_ref, "lse", atol=2e-2)
 
 
+@pytest.mark.parametrize("B,Tq,Hq,Hk,page,lens,dt,contig", [
+    (2, 256, 8, 2, 256, [700, 1], "bf16", False),          # one 256-row block per sequence, ragged cache lengths
+    (3, 512, 4, 4, 64, [0, 333, 2048], "fp16", False),     # two paired blocks, 64-token pages, an EMPTY cache entry
+    (1, 640, 8, 1, 128, [1500], "bf16", False),            # MQA, three 256-row blocks (last half empty), 128-token pages
+    (2, 320, 4, 2, 512, [4096, 77], "fp16", False),        # 512-token pages: eight tiles per page
+    (2, 384, 8, 2, 0, [900, 5], "bf16", True),             # contiguous cache through the same kv-cache geometry
+])
+def test_kvcache_chunked_prefill_on_the_hand_scheduled_forward(B, Tq, Hq, Hk, page, lens, dt, contig):
+    """Chunked prefill (T_q >= 192 new tokens over a 16-bit cache, D = 128, no rotary): the kv-cache op takes the hand-scheduled
+    forward - paged caches through its PAGED bodies (per-tile descriptors from the block table, gen_fwd_asm.py; reference:
+    the paged path is the contiguous kernel, fused_mha_forward_varlen.cu:184-193), contiguous caches with the per-sequence key
+    count.  The unused tails of the pages are poisoned with NaN: rows past a sequence's end must read as zeros (V!), never
+    as what the pool holds.  Output and LSE against the oracle; FA_ASM_FORCE makes sure the 256-row kernel is taken."""
+    import os
+    fa = _fa()
+    D = 128
+    cap = max(lens) + Tq
+    g = torch.Generator().manual_seed(7)
+    q = rand16((B, Tq, Hq, D), dt, 1)
+    knew = rand16((B, Tq, Hk, D), dt, 4); vnew = rand16((B, Tq, Hk, D), dt, 5)
+    seqlens = torch.tensor(lens, dtype=torch.int32)
+    if contig:
+        kc = rand16((B, cap, Hk, D), dt, 2); vc = rand16((B, cap, Hk, D), dt, 3)
+        for b in range(B):
+            kc[b, lens[b] + Tq:] = float("nan"); vc[b, lens[b] + Tq:] = float("nan")
+        bt = None
+    else:
+        pps = (cap + page - 1) // page
+        nblk = B * pps + 2
+        kc = rand16((nblk, page, Hk, D), dt, 2); vc = rand16((nblk, page, Hk, D), dt, 3)
+        bt = torch.randperm(nblk, generator=g)[: B * pps].reshape(B, pps).to(torch.int32)
+        for b in range(B):                                   # poison everything past the sequence's final length
+            end = lens[b] + Tq
+            for j in range(pps):
+                lo = max(0, end - j * page)
+                if lo < page:
+                    kc[int(bt[b, j]), lo:] = float("nan"); vc[int(bt[b, j]), lo:] = float("nan")
+    kc_ref, vc_ref = f64(kc).copy(), f64(vc).copy()
+    os.environ["FA_ASM_FORCE"] = "1"
+    try:
+        out, lse = fa.flash_attn_with_kvcache(q, kc, vc, k=knew, v=vnew, cache_seqlens=seqlens.cuda(),
+                                              block_table=None if bt is None else bt.cuda(), causal=True, return_softmax_lse=True)
+    finally:
+        del os.environ["FA_ASM_FORCE"]
+    assert not torch.isnan(out).any() and not torch.isnan(lse).any()
+    o_ref, lse_ref = oracle.kvcache_fwd(f64(q), np.nan_to_num(kc_ref), np.nan_to_num(vc_ref), k=f64(knew), v=f64(vnew),
+                                        cache_seqlens=seqlens.numpy(), block_table=None if bt is None else bt.numpy(),
+                                        causal=True, io_dtype=dt)
+    assert_close(f64(out), o_ref, dt, "out", mult=1.5)
+    assert_lse_close(f64(lse), lse_ref, "lse", atol=2e-3)
+
+
 def test_kvcache_edge_cases():
     """Empty cache (no keys: O = 0, LSE = -inf), append to an empty cache (O = v_new), mixed lengths with more
     splits requested than tiles, and a sliding window on decode."""

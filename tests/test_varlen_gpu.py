@@ -89,6 +89,44 @@ def test_varlen_paged_kv(page, D):
     assert_lse_close(f64(lse), lse_ref, "lse")
 
 
+@pytest.mark.parametrize("page,causal,use_seqused", [(64, True, False), (256, True, True), (128, False, False)])
+def test_varlen_paged_prefill_on_the_hand_scheduled_forward(page, causal, use_seqused):
+    """Packed prefill over a paged 16-bit cache at D = 128 with an average of >= 256 rows per sequence: the flat work list of
+    256-row blocks on the hand-scheduled forward's PAGED bodies (FA_ASM_FORCE=1), page tails poisoned with NaN; oracle."""
+    import os
+    lens_q, lens_k = [300, 700, 257], [300, 1100, 900]
+    Hq, Hk, D, dt = 4, 2, 128, "bf16"
+    B = len(lens_q)
+    used = [l - 13 if use_seqused and i == 1 else l for i, l in enumerate(lens_k)]
+    nblk_per_seq = [(l + page - 1) // page for l in lens_k]
+    total_blocks = sum(nblk_per_seq) + 3
+    perm = torch.randperm(total_blocks, generator=torch.Generator().manual_seed(5)).tolist()
+    block_table = torch.zeros((B, max(nblk_per_seq)), dtype=torch.int32)
+    it = iter(perm)
+    kp = rand16((total_blocks, page, Hk, D), dt, 11); vp = rand16((total_blocks, page, Hk, D), dt, 12)
+    for b in range(B):
+        for j in range(nblk_per_seq[b]):
+            block_table[b, j] = next(it)
+            lo = max(0, used[b] - j * page)
+            if lo < page:
+                kp[int(block_table[b, j]), lo:] = float("nan"); vp[int(block_table[b, j]), lo:] = float("nan")
+    q = rand16((sum(lens_q), Hq, D), dt, 13)
+    cu_q, cu_k = _cu(lens_q), _cu(lens_k)
+    su = torch.tensor(used, dtype=torch.int32).cuda() if use_seqused else None
+    os.environ["FA_ASM_FORCE"] = "1"
+    try:
+        out, lse, _ = _fa().flash_attn_varlen_func(q, kp, vp, cu_q, cu_k, max(lens_q), max(lens_k), causal=causal,
+                                                   return_attn_probs=True, block_table=block_table.cuda(), seqused_k=su)
+    finally:
+        del os.environ["FA_ASM_FORCE"]
+    assert not torch.isnan(out).any()
+    o_ref, lse_ref = oracle.varlen_fwd(f64(q), np.nan_to_num(f64(kp)), np.nan_to_num(f64(vp)), cu_q.cpu().numpy(), cu_k.cpu().numpy(),
+                                       max(lens_q), max(lens_k), D ** -0.5, causal=causal, block_table=block_table.numpy(),
+                                       seqused_k=None if su is None else su.cpu().numpy())
+    assert_close(f64(out), o_ref, dt, "out", mult=1.5)
+    assert_lse_close(f64(lse), lse_ref, "lse")
+
+
 @pytest.mark.parametrize("Tq,Hq,Hk,D,dt,page,use_seqused,causal,window,softcap,alibi", [
     (1, 32, 8, 128, "bf16", 256, True, True, (-1, -1), 0.0, False),      # the vLLM-style decode step: token-major kernel
     (1, 8, 8, 128, "fp16", 64, False, True, (-1, -1), 0.0, False),       # lengths from cu_seqlens_k only
