@@ -85,6 +85,16 @@ V_HI = 226                      # owned: v20..v35 + 65536 (ring slots 4, 5 lie p
 V_EP = 212                      # epilogue: eight 4-register entries v212..v243 (the loop's owned registers are dead by then)
 V_TM = 244                      # measurement build: four time stamps
 V_T = 44                        # temps v44..v63
+# causal ALiBi variant (one q-head per kv-head): bias(q, key) = slope (key - off - q) in raw score units (sv = slope / softmax_scale)
+# enters the S accumulator by ONE extra MFMA per stage (the compiler kernels' form, fa_common.h: alibi_pos_operand /
+# alibi_lane_operand): A = row position and ones (lane constant), B = -sv, sv * key position (constant per pass) and the stage's
+# tile term sv (kw0 - off - q0) split three ways (recomputed per stage: 10 VALU)
+V_AA = 212                      # in: 4 regs, A operand (row position l31 in slots 0, 1; ones in slots 2 .. 6; lanes >= 32: zero)
+V_AB01 = 216                    # in: 2 regs, B slots 0 .. 3: head / tail of -sv and of sv * l31 (lanes >= 32: zero)
+V_SVL = 218                     # in: sv in lanes 0 .. 31, 0 in lanes 32 .. 63
+V_AB = (220, 248)               # owned: B operand of the stage whose S is computed next, per buffer parity (4 regs each)
+V_AX = 242                      # owned: two temps of the split
+S_TT0 = 59                      # in: kw0 - off (integer): the stage's tile term is TT0 - 32 * tile
 A_DK, A_DV, A_K, A_V = 0, 64, 128, 160
 A_RR = 192                      # row-fragment ring (8 x 4)
 A_TRR = 224                     # transposed-fragment ring (8 x 4)
@@ -92,6 +102,10 @@ NFR = 8
 
 
 class DKV(Gen):
+    def __init__(self, dtype, alibi=False):
+        Gen.__init__(self, dtype)
+        self.alibi_kv = alibi
+
     def reset_dkv(self):
         self.now = 0
         self.last = {}
@@ -116,12 +130,39 @@ class DKV(Gen):
                 if off >= 65536:
                     off, adr = off - 65536, V_HI + ks
                 rd = Ins(f"ds_read_b128 {ar(ring, 4)}, v{adr} offset:{off}", "lds", [f"v{adr}"], rl("a", ring, 4))
-                mf = self.mfma("v", acc, "a", ring, "a", bfrag + 4 * ks, ks == 0)
+                mf = self.mfma("v", acc, "a", ring, "a", bfrag + 4 * ks, ks == 0 and not (self.alibi_kv and tens == 0))
                 if ks == 0 and tens == 1:          # dP = dO V^T - D: the accumulator starts from the -D rows
                     mf = Ins(f"{self.mf} {vr(acc, 16)}, {ar(ring, 4)}, {ar(bfrag, 4)}, {vr(V_D, 16)}", "mfma",
                              rl("a", ring, 4) + rl("a", bfrag, 4) + rl("v", V_D, 16), rl("v", acc, 16))
                 items.append((rd, mf))
+        if self.alibi_kv:           # S starts from the bias: one MFMA in front of the chain (no LDS operand)
+            acc, b = V_S[par], V_AB[par]
+            bias = Ins(f"{self.mf} {vr(acc, 16)}, {vr(V_AA, 4)}, {vr(b, 4)}, 0", "mfma", rl("v", V_AA, 4) + rl("v", b, 4), rl("v", acc, 16))
+            items.insert(0, ([], bias))
         return items
+
+    def alibi_valu(self, par):
+        """B slots 4 .. 6 of the stage it + 1 (its S MFMAs run in this iteration): x = sv (TT0 - 32 tile) as head + middle + tail in
+        the io type.  The tile index is mt0 + it + 1 (one q-head per kv-head: no wrap).  Lanes >= 32 compute zeros."""
+        b, x, r = V_AB[par], V_AX, V_AX + 1
+        t = S_T
+        up = (lambda d, src: f"v_lshlrev_b32 v{d}, 16, v{src}") if self.dtype == "bf16" else (lambda d, src: f"v_cvt_f32_f16 v{d}, v{src}")
+        V = lambda txt, rd, wr: Ins(txt, "valu", rd, wr)
+        o = [Ins(f"s_add_u32 s{t}, s{S_MT0}, s{S_IT}", "salu", [], [f"s{t}", "scc"]),
+             Ins(f"s_lshl_b32 s{t}, s{t}, 5", "salu", [f"s{t}"], [f"s{t}", "scc"]),
+             Ins(f"s_sub_u32 s{t}, s{S_TT0}, s{t}", "salu", [f"s{t}"], [f"s{t}", "scc"]),
+             Ins(f"s_sub_u32 s{t}, s{t}, 32", "salu", [f"s{t}"], [f"s{t}", "scc"]),
+             V(f"v_cvt_f32_i32 v{x}, s{t}", [f"s{t}"], [f"v{x}"]),
+             V(f"v_mul_f32 v{x}, v{x}, v{V_SVL}", [f"v{x}", f"v{V_SVL}"], [f"v{x}"]),
+             V(f"{self.cvt} v{b + 2}, v{x}, 0", [f"v{x}"], [f"v{b + 2}"]),                # head (low half)
+             V(up(r, b + 2), [f"v{b + 2}"], [f"v{r}"]),
+             V(f"v_sub_f32 v{x}, v{x}, v{r}", [f"v{x}", f"v{r}"], [f"v{x}"]),           # x - head
+             V(f"{self.cvt} v{b + 3}, v{x}, 0", [f"v{x}"], [f"v{b + 3}"]),                # middle
+             V(up(b + 3, b + 3), [f"v{b + 3}"], [f"v{b + 3}"]),
+             V(f"v_sub_f32 v{x}, v{x}, v{b + 3}", [f"v{x}", f"v{b + 3}"], [f"v{x}"]),   # tail
+             V(f"{self.cvt} v{b + 2}, v{r}, v{b + 3}", [f"v{r}", f"v{b + 3}"], [f"v{b + 2}"]),   # slots 4, 5: head, middle (exact)
+             V(f"{self.cvt} v{b + 3}, v{x}, 0", [f"v{x}"], [f"v{b + 3}"])]                # slot 6: tail, slot 7: 0
+        return o
 
     def dvdk_stream(self, stage_slot, par):
         """dV, dK of stage it-1: transposed fragments through a 4-entry ring; B operands = packed P / dS"""
@@ -258,7 +299,7 @@ class DKV(Gen):
         sdp = self.sdp_stream(sl_next, par_oth)
         dvdk = self.dvdk_stream(sl_prev, par_oth)
         d_reads, l_reads = self.stats_reads(sl_next, par_oth)
-        valu = self.valu_stream(par_cur)
+        valu = (self.alibi_valu(par_oth) if self.alibi_kv else []) + self.valu_stream(par_cur)
         dma, dma_st = self.dma_stream(sl_dma, c, fast)
         # ---- interleave: 32 MFMAs = dV/dK of stage it-1 first (their operands are oldest), then S/dP of stage it+1
         mf_items = [("t", x) for x in dvdk] + [("r", x) for x in sdp]
@@ -470,6 +511,12 @@ class DKV(Gen):
                 A(f"v_mov_b32 v{V_DS[par] + r}, 0")
             for r in range(16):
                 A(f"v_mov_b32 v{V_LSE[par] + r}, 0")
+        if self.alibi_kv:
+            for par in (0, 1):
+                A(f"v_mov_b32 v{V_AB[par]}, v{V_AB01}")
+                A(f"v_mov_b32 v{V_AB[par] + 1}, v{V_AB01 + 1}")
+                A(f"v_mov_b32 v{V_AB[par] + 2}, 0")
+                A(f"v_mov_b32 v{V_AB[par] + 3}, 0")
         A(f"s_mov_b32 s{S_IT}, -1")
         A(f"s_mov_b32 s{S_VMT}, s{S_MT0}")
         A(f"s_sub_u32 s{S_VMT}, s{S_VMT}, 1")                      # stage -1 (virtual): advanced to mt0 before stage 0
@@ -553,6 +600,7 @@ class DKV(Gen):
         A("s_waitcnt vmcnt(0) lgkmcnt(0)")
         stamp(2)
         A("s_barrier")                                            # every wave is done with the stage ring
+        ep0 = V_EP + (8 if self.alibi_kv else 0)      # (the ALiBi variant's INPUTS v212..v218 must survive: a workgroup may run two passes)
         # ---- epilogue: dK * softmax_scale, dV -> 16 bit; through a wave-private LDS image so that the stores cover
         # whole 256-byte rows (4 rows per instruction) instead of 8-byte shreds of 32 rows
         T = V_T
@@ -589,7 +637,7 @@ class DKV(Gen):
                     if scale:
                         for e in range(4):
                             A(f"v_mul_f32 v{tt + e}, s{S_SCALE}, v{tt + e}")
-                    pk = V_EP + 2 * ((4 * d + r4) % 8)
+                    pk = ep0 + 2 * ((4 * d + r4) % 8)
                     A(f"{self.cvt} v{pk}, v{tt}, v{tt + 1}")
                     A(f"{self.cvt} v{pk + 1}, v{tt + 2}, v{tt + 3}")
                     A(f"ds_write_b64 v{T + 5}, {vr(pk, 2)} offset:{ti * EP_T + 64 * d + 16 * r4}")
@@ -597,10 +645,10 @@ class DKV(Gen):
         for ti, (voff, rs, step) in enumerate(((T + 7, S_DKRS, t + 1), (T + 8, S_DVRS, t + 2))):
             A(f"s_mov_b32 s{t + 4}, 0")
             for j in range(8):
-                A(f"ds_read_b128 {vr(V_EP + 4 * j, 4)}, v{T + 6} offset:{ti * EP_T + 4 * EP_PITCH * j}")
+                A(f"ds_read_b128 {vr(ep0 + 4 * j, 4)}, v{T + 6} offset:{ti * EP_T + 4 * EP_PITCH * j}")
             for j in range(8):
                 A(f"s_waitcnt lgkmcnt({7 - j})")
-                A(f"buffer_store_dwordx4 {vr(V_EP + 4 * j, 4)}, v{voff}, {sr(rs, 4)}, s{t + 4} offen")
+                A(f"buffer_store_dwordx4 {vr(ep0 + 4 * j, 4)}, v{voff}, {sr(rs, 4)}, s{t + 4} offen")
                 A(f"s_add_u32 s{t + 4}, s{t + 4}, s{step}")
             A("s_nop 1")
         if timers:
@@ -619,9 +667,10 @@ class DKV(Gen):
         return L, report
 
 
-def clobbers():
+def clobbers(alibi=False):
     c = ["memory", "vcc", "scc", "m0"]
-    c += [f"v{i}" for i in range(44, 256) if i not in (V_DKRB, V_DVRB, V_KW0)]
+    keep = (V_DKRB, V_DVRB, V_KW0) + (tuple(range(V_AA, V_SVL + 1)) if alibi else ())
+    c += [f"v{i}" for i in range(44, 256) if i not in keep]
     c += [f"a{i}" for i in range(256)]
     c += [f"s{i}" for i in range(S_IT, S_LAST + 1)]
     return c
@@ -640,18 +689,20 @@ def main():
     print("#pragma once")
     print(f"#define FA_BWD_ASM_LDS_BYTES {LDS_TOTAL}")
     print(f"#define FA_BWD_ASM_STATS_OFF {STATS}")
-    for dt in ("bf16", "f16"):
-        g = DKV(dt)
-        g.ko = ko
-        body, report = g.gen_body(cfg)
-        print(f"#define FA_BWD_DKDV_ASM_BODY_{dt.upper()} \\")
-        for ln in body:
-            print(f'    "{ln}\\n" \\')
-        print('    ""')
-        for k, (st, n) in report.items():
-            print(f"// {dt} copy {k}: {n} lines, nop states {st['nop_states']}, lgkmcnt waits {st['lgkm_waits']}")
-    cl = ", ".join(f'"{c}"' for c in clobbers())
-    print(f"#define FA_BWD_DKDV_ASM_CLOBBERS {cl}")
+    for alibi in (False, True):
+        tag = "ALIBI_" if alibi else ""
+        for dt in ("bf16", "f16"):
+            g = DKV(dt, alibi=alibi)
+            g.ko = ko
+            body, report = g.gen_body(cfg)
+            print(f"#define FA_BWD_DKDV_ASM_{tag}BODY_{dt.upper()} \\")
+            for ln in body:
+                print(f'    "{ln}\\n" \\')
+            print('    ""')
+            for k, (st, n) in report.items():
+                print(f"// {dt} {tag}copy {k}: {n} lines, nop states {st['nop_states']}, lgkmcnt waits {st['lgkm_waits']}")
+        cl = ", ".join(f'"{c}"' for c in clobbers(alibi))
+        print(f"#define FA_BWD_DKDV_ASM_{tag}CLOBBERS {cl}")
 
 
 if __name__ == "__main__":
