@@ -771,11 +771,13 @@ __global__ void __launch_bounds__(BWD_THREADS, 1) fa_bwd_dkdv_kernel(const KArgs
 #ifndef FA_DKV2_OCC64
 #define FA_DKV2_OCC64 3
 #endif
-constexpr int DKV2_BQ = 32;
 template <int D> struct Dkv2Smem {
+    // rows per stage: 64 at D <= 64 (two 32-row sub-tiles per barrier / DMA issue / bookkeeping round - at BASELINE config 3 that
+    // skeleton was 1211 of a stage's 2725 cycles, profiles/r05_config3_backward.txt), 32 at D = 128 (LDS: two workgroups per CU)
+    static constexpr int BQ = D <= 64 ? 64 : 32;
     static constexpr int KT = DKV_BN * D * 2;            // K tile
-    static constexpr int QT = DKV2_BQ * D * 2;           // Q (or dO) stage
-    static constexpr int STG = 2 * QT + 256;             // Q, dO, 64 row statistics
+    static constexpr int QT = BQ * D * 2;                // Q (or dO) stage
+    static constexpr int STG = 2 * QT + 8 * BQ;          // Q, dO, row statistics: lse2[BQ] | -D[BQ]
     static constexpr int TOTAL = KT + 2 * STG;           // K tile + two stages (V fragments in registers)
 };
 
@@ -793,7 +795,9 @@ __global__ void __launch_bounds__(BWD_THREADS, D <= 64 ? FA_DKV2_OCC64 : 2) fa_b
     constexpr int STG = Dkv2Smem<D>::STG;
     constexpr int ROWS_PI = 64 / CPR;                        // rows per 1-KiB DMA instruction
     constexpr int K_INSTS = DKV_BN / ROWS_PI / 4;            // per wave, per tensor
-    constexpr int Q_INSTS = DKV2_BQ / ROWS_PI / 4;
+    constexpr int BQ = Dkv2Smem<D>::BQ;
+    constexpr int NSUB = BQ / 32;
+    constexpr int Q_INSTS = BQ / ROWS_PI / 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const ks_base = smem;                              // K tile   [128][D]  swzt (row reads)
     char* const stg_base = smem + KT;                        // two stages: Q [32][D] swzt (row + transposed reads), dO, statistics
@@ -881,7 +885,7 @@ __global__ void __launch_bounds__(BWD_THREADS, D <= 64 ? FA_DKV2_OCC64 : 2) fa_b
     for (int h2 = 0; h2 < 2; ++h2)
 #pragma unroll
         for (int d = 0; d < DBLKS; ++d) t_rp[h2][d] = lds_pin(stg_base + swzt_row_off<D>(4 * g + rr + 8 * h2, d * 64 + cb));
-    const lds_char* st_rp = lds_pin(stg_base + 2 * QT + 16 * g);     // statistics: lse2[8 i + 4 g ..], -D 128 bytes further
+    const lds_char* st_rp = lds_pin(stg_base + 2 * QT + 16 * g);     // statistics: lse2[8 i + 4 g ..], -D 4 BQ bytes further
     const u32x4 alibi_a = alibi_pos_operand<T>(lane);
 
     const int n_pass = (pair && (n_kblocks - 1 - nb0) != nb0) ? 2 : 1;
@@ -914,8 +918,8 @@ __global__ void __launch_bounds__(BWD_THREADS, D <= 64 ? FA_DKV2_OCC64 : 2) fa_b
         if (wr >= 0) { const int t = n0 - off - wr; m_lo = t > 0 ? t : 0; }
         if (wl >= 0) { const int t = n_last - off + wl + 1; m_hi = t < m_hi ? t : m_hi; }
     }
-    const int mt0 = m_lo / DKV2_BQ;
-    const int mt1 = m_hi > m_lo ? (m_hi + DKV2_BQ - 1) / DKV2_BQ : mt0;
+    const int mt0 = m_lo / BQ;
+    const int mt1 = m_hi > m_lo ? (m_hi + BQ - 1) / BQ : mt0;
     const int n_tiles = mt1 - mt0;
     const int n_iter = n_tiles * group;
     // the mask of a sub-tile as two lane constants (see fa_fwd.hip): masked <=> (cpos - lo_t) >u width, lo_t = lo_l - q0
@@ -948,16 +952,20 @@ __global__ void __launch_bounds__(BWD_THREADS, D <= 64 ? FA_DKV2_OCC64 : 2) fa_b
         for (int r = 0; r < 16; ++r) { dk_acc[d][r] = 0.f; dv_acc[d][r] = 0.f; }
 
     // Per-q-head state of the stage stream (rebuilt when the stream wraps to the next head of a GQA group): the Q / dO
-    // descriptors and, on wave 0 only, the lane's statistics row (lanes 0..31: lse, 32..63: softmax_d)
+    // descriptors and, on the waves that fetch statistics, the lane's statistics row.  32-row stages: wave 0, lanes 0..31 lse and
+    // 32..63 softmax_d; 64-row stages: wave 0 lse and wave 1 softmax_d, one row per lane
     __amdgpu_buffer_rsrc_t q_rsrc, do_rsrc;
     const float* stat_row = nullptr;
+    const bool stat_wave = BQ == 64 ? wave < 2 : wave == 0;
+    const bool stat_is_d = BQ == 64 ? wave == 1 : g == 1;
+    const int stat_lrow = BQ == 64 ? lane : l31;
     auto set_head = [&](int gq) {
         const int h = hk * group + gq;
         q_rsrc = make_rsrc(q_base + (int64_t)h * p.q_head_stride, p.q_row_stride, sg.seqlen_q, dv);
         do_rsrc = make_rsrc(do_base + (int64_t)h * p.do_head_stride, p.do_row_stride, sg.seqlen_q, dv);
-        if (wave == 0) stat_row = (g ? dsum_base : lse_base) + (int64_t)h * p.lse_head_stride;
+        if (stat_wave) stat_row = (stat_is_d ? dsum_base : lse_base) + (int64_t)h * p.lse_head_stride;
     };
-    const uint32_t q_step = (uint32_t)(DKV2_BQ * p.q_row_stride * 2), do_step = (uint32_t)(DKV2_BQ * p.do_row_stride * 2);
+    const uint32_t q_step = (uint32_t)(BQ * p.q_row_stride * 2), do_step = (uint32_t)(BQ * p.do_row_stride * 2);
     // stage stream being fetched: tile mt_n of head gq_n
     int gq_n = 0, mt_n = mt0;
     uint32_t q_soff = (uint32_t)mt0 * q_step, do_soff = (uint32_t)mt0 * do_step;
@@ -970,8 +978,8 @@ __global__ void __launch_bounds__(BWD_THREADS, D <= 64 ? FA_DKV2_OCC64 : 2) fa_b
             buf_load_lds_b128(q_rsrc, qd + (wave * Q_INSTS + i) * 1024, q_voff[i], q_soff);
             buf_load_lds_b128(do_rsrc, qd + QT + (wave * Q_INSTS + i) * 1024, do_voff[i], do_soff);
         }
-        if (wave == 0) {
-            const int qi = mt_n * DKV2_BQ + l31;
+        if (stat_wave) {
+            const int qi = mt_n * BQ + stat_lrow;
             const int qc = qi < sg.seqlen_q ? qi : (sg.seqlen_q > 0 ? sg.seqlen_q - 1 : 0);
             // the raw value: any arithmetic on it here would put an s_waitcnt vmcnt(0) - the latency of the tile loads issued
             // just above - at the top of the stage; publish_stats() fixes it up where it is consumed, a stage later
@@ -981,9 +989,9 @@ __global__ void __launch_bounds__(BWD_THREADS, D <= 64 ? FA_DKV2_OCC64 : 2) fa_b
     // statistics of the stage that was just fetched -> LDS behind its buffer: lse log2 e (rows past the sequence: 0) and -D
     auto publish_stats = [&](auto par_c, int mt_x) {
         constexpr int PAR = decltype(par_c)::value;
-        if (wave == 0) {
-            const float x = mt_x * DKV2_BQ + l31 < sg.seqlen_q ? (g ? -stat_next : stat_next * kLog2e) : 0.f;
-            reinterpret_cast<float*>(stg_base + PAR * STG + 2 * QT)[lane] = x;
+        if (stat_wave) {
+            const float x = mt_x * BQ + stat_lrow < sg.seqlen_q ? (stat_is_d ? -stat_next : stat_next * kLog2e) : 0.f;
+            reinterpret_cast<float*>(stg_base + PAR * STG + 2 * QT)[(stat_is_d ? BQ : 0) + stat_lrow] = x;
         }
     };
     auto advance_n = [&]() {
@@ -1005,7 +1013,7 @@ __global__ void __launch_bounds__(BWD_THREADS, D <= 64 ? FA_DKV2_OCC64 : 2) fa_b
     auto stage = [&](auto par_c, int it) {
         constexpr int PAR = decltype(par_c)::value;
         constexpr int SB = PAR * STG;                          // byte offset of the stage buffer: an immediate of every read
-        const int q0 = mt * DKV2_BQ;
+        const int q0_stage = mt * BQ;
         const int h = hk * group + gq;
         (void)h;
         __syncthreads();                                     // stage it landed (vmcnt(0) before the barrier) and
@@ -1015,6 +1023,11 @@ __global__ void __launch_bounds__(BWD_THREADS, D <= 64 ? FA_DKV2_OCC64 : 2) fa_b
         const int mt_pub = mt_n;
         if (++mt == mt1) { mt = mt0; ++gq; }
 
+#pragma unroll
+        for (int sub = 0; sub < NSUB; ++sub) {               // the stage's 32-row sub-tiles, one after the other (same registers)
+        const int q0 = q0_stage + 32 * sub;
+        const int SO = SB + sub * 32 * D * 2;                // (an immediate after unrolling)
+        const int ST = SB + sub * 128;
         const bool active = wave_has_keys && (q0 <= w_qhi_max) && (q0 + 31 >= w_qlo_min);
         if (active) {
         // ---- S = Q K^T, dP = dO V^T - D ----
@@ -1023,7 +1036,7 @@ __global__ void __launch_bounds__(BWD_THREADS, D <= 64 ? FA_DKV2_OCC64 : 2) fa_b
         for (int r = 0; r < 16; ++r) s_acc[r] = 0.f;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const f32x4 d4 = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(st_rp + (SB + 128 + 32 * i));
+            const f32x4 d4 = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(st_rp + (ST + 4 * BQ + 32 * i));
 #pragma unroll
             for (int e = 0; e < 4; ++e) dp_acc[4 * i + e] = DROPOUT ? 0.f : d4[e];       // the accumulator starts from -D
         }
@@ -1031,7 +1044,7 @@ __global__ void __launch_bounds__(BWD_THREADS, D <= 64 ? FA_DKV2_OCC64 : 2) fa_b
         if (DROPOUT) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                dneg[i] = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(st_rp + (SB + 128 + 32 * i));
+                dneg[i] = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(st_rp + (ST + 4 * BQ + 32 * i));
         }
         if (BIAS == 2) {
             const float slope = p.alibi_slopes[b * p.alibi_batch_stride + h];
@@ -1040,9 +1053,9 @@ __global__ void __launch_bounds__(BWD_THREADS, D <= 64 ? FA_DKV2_OCC64 : 2) fa_b
         }
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks) {
-            const u32x4 qa = lds_read_b128(q_rp[ks] + SB);
+            const u32x4 qa = lds_read_b128(q_rp[ks] + SO);
             const u32x4 kb2 = lds_read_b128(k_rp[ks]);
-            const u32x4 da = lds_read_b128(q_rp[ks] + (SB + QT));
+            const u32x4 da = lds_read_b128(q_rp[ks] + (SO + QT));
             s_acc = E::mfma(qa, kb2, s_acc);
             dp_acc = E::mfma(da, vf[ks], dp_acc);
         }
@@ -1075,7 +1088,7 @@ __global__ void __launch_bounds__(BWD_THREADS, D <= 64 ? FA_DKV2_OCC64 : 2) fa_b
         }
         f32x4 l4[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) l4[i] = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(st_rp + (SB + 32 * i));
+        for (int i = 0; i < 4; ++i) l4[i] = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(st_rp + (ST + 32 * i));
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const float l2 = l4[r >> 2][r & 3];
@@ -1137,7 +1150,7 @@ __global__ void __launch_bounds__(BWD_THREADS, D <= 64 ? FA_DKV2_OCC64 : 2) fa_b
             constexpr int NBK = 4 * DBLKS;
             auto tread = [&](int i) {
                 const int t = i / (2 * DBLKS), d = (i >> 1) % DBLKS;
-                const int o = SB + ((i & 1) ? 0 : QT) + 16 * t * D * 2;
+                const int o = SO + ((i & 1) ? 0 : QT) + 16 * t * D * 2;
                 const u32x2 a0 = lds_read_tr16_nw(t_rp[0][d], o);
                 const u32x2 a1 = lds_read_tr16_nw(t_rp[1][d], o);
                 return u32x4{a0[0], a0[1], a1[0], a1[1]};
@@ -1157,6 +1170,7 @@ __global__ void __launch_bounds__(BWD_THREADS, D <= 64 ? FA_DKV2_OCC64 : 2) fa_b
             }
         }
         }   // active
+        }   // sub
         if (has_next) publish_stats(std::integral_constant<int, PAR ^ 1>{}, mt_pub);
     };
 #pragma unroll 1
