@@ -32,6 +32,11 @@ Structure (one wave per SIMD, 512 registers, 4 waves x 64 query rows = 256-row w
   * prologue: Q -> AGPRs, dO and O -> registers, D = rowsum(dO o O) in fp32 (the fused preprocess: this kernel runs
     first and leaves softmax_d and the statistics planes of the asm dK/dV kernel behind), dO -> AGPRs;
   * epilogue: dQ * softmax_scale -> 16 bit through a per-wave LDS image so that each store covers four whole rows.
+Causal-like ALiBi variant (DQ(alibi=True)): bias(q, key) = slope (key - off - q) needs no operand here - a lane owns ONE query and
+a register ONE key row of the sub-tile, so in log2 units
+        S c + slope2 (n0 + kr + 4g - off - q) - lse2  =  S c + slope2 kr - L',    L' = [lse2 + slope2 (off + q - 4g)] - slope2 n0
+with kr = (r & 3) + 8 (r >> 2) a literal per register: L' is one v_fma per q-block and stage, the kr term one v_fmamk per element
+(15 per q-block and stage, in the MFMAs' shadow: the matrix pipe bounds this kernel); four more registers, no LDS, no MFMA.
 
 Run:  python gen_bwd_dq_asm.py > fa_bwd_dq_asm_gen.h
 """
@@ -95,12 +100,21 @@ V_KR = 152                      # K-row fragments [ks] x 4
 V_VR = 184                      # V-row fragments [ks] x 4
 V_KT = 216                      # K^T fragments [t][d] x 4           (.. v247)
 V_TM = 248                      # measurement build: time stamps (v248..v251)
+# causal-like ALiBi variant (no measurement build of it)
+V_SL = 51                       # in (uniform): slope * log2(e)
+S_OFF = 67                      # in: seqlen_k - seqlen_q
+V_LP = (248, 249)               # owned: L' of the stage whose gradients are computed (V_LSE2 holds the bracket above)
+V_N0F = 250                     # owned: float(n0)
 A_DQ = (0, 64)
 A_Q = (128, 160)
 A_DO = (192, 224)
 
 
 class DQ(Gen):
+    def __init__(self, dtype, alibi=False):
+        Gen.__init__(self, dtype)
+        self.alibi_dq = alibi
+
     def reset_dq(self, mfma_age=8):
         self.now = 0
         self.last = {}
@@ -145,16 +159,28 @@ class DQ(Gen):
     # ---- VALU stream: P = exp2(S c - lse2), dS = P (dP - D), pack ----
     def grad(self, qb):
         S, DP, DS = V_S[qb], V_DP[qb], V_DS[qb]
-        l2 = f"v{V_LSE2[qb]}"
+        al = self.alibi_dq
+        l2 = f"v{V_LP[qb]}" if al else f"v{V_LSE2[qb]}"
         out = []
-        for r in range(16 + 3):
+        if al:      # L' of this stage (first key S_N0)
+            out.append(Ins(f"v_cvt_f32_i32 v{V_N0F}, s{S_N0}", "valu", [f"s{S_N0}"], [f"v{V_N0F}"]))
+            out.append(Ins(f"v_fma_f32 {l2}, v{V_N0F}, -v{V_SL}, v{V_LSE2[qb]}", "valu", [f"v{V_N0F}", f"v{V_SL}", f"v{V_LSE2[qb]}"], [l2]))
+        d = 1 if al else 0          # the ALiBi variant has one more step in front of the exponential
+        for r in range(16 + 3 + d):
             if r < 16:
                 out.append(Ins(f"v_fma_f32 v{S + r}, v{S + r}, s{S_C}, -{l2}", "valu", [f"v{S + r}", l2], [f"v{S + r}"]))
-            if 0 <= r - 1 < 16:
+            if al and 0 <= r - 1 < 16:
                 q = r - 1
+                kr = (q & 3) + 8 * (q >> 2)
+                if kr:
+                    import struct
+                    lit = struct.unpack("<I", struct.pack("<f", float(kr)))[0]
+                    out.append(Ins(f"v_fmamk_f32 v{S + q}, v{V_SL}, 0x{lit:08x}, v{S + q}", "valu", [f"v{S + q}", f"v{V_SL}"], [f"v{S + q}"]))
+            if 0 <= r - 1 - d < 16:
+                q = r - 1 - d
                 out.append(Ins(f"v_exp_f32 v{S + q}, v{S + q}", "trans", [f"v{S + q}"], [f"v{S + q}"], w=1.6))
-            if 0 <= r - 3 < 16:
-                q = r - 3
+            if 0 <= r - 3 - d < 16:
+                q = r - 3 - d
                 out.append(Ins(f"v_mul_f32 v{DP + q}, v{S + q}, v{DP + q}", "valu", [f"v{S + q}", f"v{DP + q}"], [f"v{DP + q}"]))
                 if q % 2 == 1:
                     e = q // 2
@@ -440,6 +466,23 @@ class DQ(Gen):
                 A(f"v_mov_b32 v{V_ONE + 3}, 0")
             for i in range(32):
                 A(f"v_accvgpr_write_b32 a{A_DO[qb] + i}, v{DOT[qb] + i}")
+        if self.alibi_dq:
+            # V_LSE2 := lse2 + slope2 (off + q - 4g) (the statistics stores above have read lse2; rows past the sequence carry the
+            # out-of-range marker as their offset: a huge bracket, P = 0 - they are masked anyway)
+            assert not timers
+            A(f"v_mbcnt_lo_u32_b32 v{T}, -1, 0")
+            A(f"v_mbcnt_hi_u32_b32 v{T}, -1, v{T}")
+            A(f"v_lshrrev_b32 v{T}, 5, v{T}")
+            A(f"v_lshlrev_b32 v{T}, 2, v{T}")                           # 4g
+            A("s_nop 1")
+            for qb in range(2):
+                A(f"v_lshrrev_b32 v{T + 1}, 2, v{V_LSEOFF[qb]}")        # q
+                A(f"v_add_u32 v{T + 1}, s{S_OFF}, v{T + 1}")
+                A(f"v_sub_u32 v{T + 1}, v{T + 1}, v{T}")
+                A(f"v_cvt_f32_i32 v{T + 1}, v{T + 1}")
+                A(f"v_fma_f32 v{V_LSE2[qb]}, v{T + 1}, v{V_SL}, v{V_LSE2[qb]}")
+                A(f"v_mov_b32 v{V_LP[qb]}, v{V_LSE2[qb]}")
+            A(f"v_mov_b32 v{V_N0F}, 0")
         # ---- state: virtual fragments / scores / gradients 0 (these registers held dO / O and the prologue's addresses)
         for qb in range(2):
             for r in range(16):
@@ -575,9 +618,9 @@ DEFAULT_CFG = {
 }
 
 
-def clobbers():
+def clobbers(alibi=False):
     c = ["memory", "vcc", "scc", "m0"]
-    c += [f"v{i}" for i in range(V_ORB + 1, 256)]
+    c += [f"v{i}" for i in range(V_ORB + 1 + (1 if alibi else 0), 256)]
     c += [f"a{i}" for i in range(256)]
     c += [f"s{i}" for i in range(S_J, S_LAST + 1)]
     return c
@@ -597,19 +640,20 @@ def main():
     print("// GENERATED by gen_bwd_dq_asm.py - do not edit.  See that script for the schedule and the register map.")
     print("#pragma once")
     print(f"#define FA_BWD_DQ_ASM_LDS_BYTES {LDS_TOTAL}")
-    for dt in ("bf16", "f16"):
-        g = DQ(dt)
-        g.ko = ko
-        body, report = g.gen_body(cfg)
-        print(f"#define FA_BWD_DQ_ASM_BODY_{dt.upper()} \\")
-        for ln in body:
-            print(f'    "{ln}\\n" \\')
-        print('    ""')
-        for k, (st, n) in report.items():
-            print(f"// {dt} copy {k}: {n} lines, nop states {st['nop_states']}, lgkmcnt waits {st['lgkm_waits']}")
-    cl = ", ".join(f'"{c}"' for c in clobbers())
-    print(f"#define FA_BWD_DQ_ASM_CLOBBERS {cl}")
-
+    for alibi in (False, True):
+        tag = "ALIBI_" if alibi else ""
+        for dt in ("bf16", "f16"):
+            g = DQ(dt, alibi=alibi)
+            g.ko = ko
+            body, report = g.gen_body(cfg)
+            print(f"#define FA_BWD_DQ_ASM_{tag}BODY_{dt.upper()} \\")
+            for ln in body:
+                print(f'    "{ln}\\n" \\')
+            print('    ""')
+            for k, (st, n) in report.items():
+                print(f"// {dt} {tag}copy {k}: {n} lines, nop states {st['nop_states']}, lgkmcnt waits {st['lgkm_waits']}")
+        cl = ", ".join(f'"{c}"' for c in clobbers(alibi))
+        print(f"#define FA_BWD_DQ_ASM_{tag}CLOBBERS {cl}")
 
 if __name__ == "__main__":
     main()

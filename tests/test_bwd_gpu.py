@@ -69,6 +69,10 @@ CASES = [
     (1, 4, 4, 640, 640, 128, "bf16", False, (200, 0), 0.0, True),     # window_right == 0
     (1, 4, 4, 320, 320, 128, "bf16", False, (-1, -1), 0.0, True),     # general path (keys right of the diagonal)
     (1, 2, 2, 1500, 1500, 128, "fp16", True, (-1, -1), 0.0, True),    # long distances: tile term split three ways
+    # ... and in the hand-scheduled dQ kernel the bias is part of the exponent's arithmetic (a lane owns one query)
+    (1, 4, 4, 300, 520, 128, "fp16", True, (-1, -1), 0.0, True),      # Sq < Sk (off > 0), rows past the last 256-row block
+    (1, 4, 2, 1024, 1024, 128, "bf16", False, (300, 0), 0.0, True),   # GQA (per q-head slope) + left window
+    (2, 2, 2, 2304, 2304, 128, "bf16", True, (-1, -1), 0.0, True),    # nine 256-row blocks: mirrored pairs + the middle one
     # hand-scheduled dK/dV kernel (D = 128, no bias): edges of its stage pipeline, masks and key-block pairing
     (1, 2, 2, 520, 300, 128, "bf16", True, (-1, -1), 0.0, False),     # Sq > Sk: rows without keys, key blocks without rows
     (1, 2, 2, 300, 520, 128, "fp16", True, (-1, -1), 0.0, False),     # Sq < Sk: shifted diagonal
