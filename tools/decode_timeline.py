@@ -11,9 +11,9 @@ if pmc:
     for r in rows:
         if r.get("Counter_Name") == "FETCH_SIZE" and "fa::" in r["Kernel_Name"]:
             acc[(short(r["Kernel_Name"]), r.get("Grid_Size", ""))].append(float(r["Counter_Value"]))
-    print(f"{'kernel':92s} {'grid':>9s} {'calls':>5s} {'FETCH_SIZE median (x 32 B... see rocpd_summary)':>20s}")
+    print(f"{'kernel':92s} {'grid':>9s} {'calls':>5s}   FETCH_SIZE median (KiB)   bytes fetched (x 2: gfx950 counts a 128-B request as 64 B)")
     for (k, g), v in sorted(acc.items(), key=lambda x: -st.median(x[1])):
-        print(f"{k:92s} {g:>9s} {len(v):5d} {st.median(v):14.0f} KB-units  = {st.median(v) * 1024 / 1e6:9.1f} MB if the unit is KiB")
+        print(f"{k:92s} {g:>9s} {len(v):5d} {st.median(v):14.0f} KiB  = {2 * st.median(v) * 1024 / 1e6:9.1f} MB")
     sys.exit(0)
 ks = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"])) for r in rows if "fa::" in r["Kernel_Name"] or "at::" in r["Kernel_Name"]]
 ks.sort()
