@@ -81,6 +81,13 @@ CASES = [
     (1, 2, 2, 31, 1000, 128, "bf16", True, (-1, -1), 0.0, False),     # less than one stage of rows, eight key blocks
     (1, 4, 1, 1000, 1000, 128, "fp16", False, (64, 32), 0.0, False),  # two-sided window, four q-heads per kv-head
     (1, 2, 2, 1300, 1300, 128, "bf16", True, (-1, -1), 0.0, False),   # 11 key blocks: mirrored pairs + the middle one
+    # head dim 256 without bias / dropout: two waves per key block (one computes P and dV, the other dP, dS and dK)
+    (1, 2, 2, 300, 520, 256, "bf16", True, (-1, -1), 0.0, False),     # Sq < Sk, ragged tails
+    (1, 2, 2, 520, 300, 256, "fp16", True, (-1, -1), 0.0, False),     # Sq > Sk: rows without keys, key blocks without rows
+    (2, 4, 1, 700, 700, 256, "bf16", False, (-1, -1), 0.0, False),    # MQA group of four, no mask
+    (1, 2, 2, 1000, 1000, 256, "fp16", False, (64, 32), 0.0, False),  # two-sided window
+    (1, 2, 2, 1300, 1300, 256, "bf16", True, (-1, -1), 0.0, False),   # 11 key blocks: mirrored pairs + the middle one
+    (1, 2, 2, 31, 1000, 256, "bf16", True, (-1, -1), 0.0, False),     # less than one stage of rows
     # softcap only (constants-folded variant in all kernels; Gemma-2 style)
     (2, 8, 2, 333, 333, 128, "bf16", True, (-1, -1), 50.0, False),
     (1, 4, 4, 200, 450, 64, "fp16", True, (128, 0), 20.0, False),
