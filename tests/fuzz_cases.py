@@ -392,7 +392,10 @@ if __name__ == "__main__":
     ap.add_argument("--n", type=int, default=100)
     ap.add_argument("--kinds", default="dense,varlen,kvcache")
     ap.add_argument("-v", action="store_true")
+    ap.add_argument("--head-dims", default="", help="comma list: draw the dense / varlen head dims from these only")
     a = ap.parse_args()
+    if a.head_dims:
+        HEAD_DIMS = tuple(int(x) for x in a.head_dims.split(","))
     bad = 0
     for kind in a.kinds.split(","):
         t0 = time.time()
