@@ -1226,12 +1226,14 @@ template <int D> struct DkvSplitSmem {
 };
 constexpr int SPLIT_THREADS = 512;
 
-template <typename T, int D>
+// DV: columns that can be non-zero (192: head dims 129 .. 192 run on the 256-wide images - the DMA reads the missing columns as
+// zeros - but skip the k-steps and the accumulator blocks that would only see them: 24 MFMAs per wave and sub-tile instead of 32)
+template <typename T, int D, int DV>
 __global__ void __launch_bounds__(SPLIT_THREADS, 1) fa_bwd_dkdv_split_kernel(const KArgs a) {
     using E = Elem<T>;
-    static_assert(D == 256, "two waves per key block: the D = 256 form");
-    constexpr int KSTEPS = D / 16;
-    constexpr int DBLKS = D / 32;
+    static_assert(D == 256 && (DV == 256 || DV == 192), "two waves per key block: the D = 256 form");
+    constexpr int KSTEPS = DV / 16;
+    constexpr int DBLKS = DV / 32;
     constexpr int CPR = D / 8;
     constexpr int QT = DkvSplitSmem<D>::QT;
     constexpr int STG = DkvSplitSmem<D>::STG;
@@ -2225,10 +2227,16 @@ static int launch_bwd_td(const KArgs& a, hipStream_t stream) {
                     a2.flat_kblocks = p.total_k / DKV_BN + p.batch;
                     grid2 = a2.flat_kblocks * p.nheads_k;
                 }
-                auto kern = fa_bwd_dkdv_split_kernel<T, D>;
                 const size_t smem3 = DkvSplitSmem<D>::TOTAL;
-                FA_SET_LDS_ONCE(kern, smem3);
-                hipLaunchKernelGGL(kern, dim3(grid2), dim3(SPLIT_THREADS), smem3, stream, a2);
+                if (valid_cols(p) <= 192) {
+                    auto kern = fa_bwd_dkdv_split_kernel<T, D, 192>;
+                    FA_SET_LDS_ONCE(kern, smem3);
+                    hipLaunchKernelGGL(kern, dim3(grid2), dim3(SPLIT_THREADS), smem3, stream, a2);
+                } else {
+                    auto kern = fa_bwd_dkdv_split_kernel<T, D, 256>;
+                    FA_SET_LDS_ONCE(kern, smem3);
+                    hipLaunchKernelGGL(kern, dim3(grid2), dim3(SPLIT_THREADS), smem3, stream, a2);
+                }
                 done = true;
             }
         }

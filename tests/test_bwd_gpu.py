@@ -88,6 +88,11 @@ CASES = [
     (1, 2, 2, 1000, 1000, 256, "fp16", False, (64, 32), 0.0, False),  # two-sided window
     (1, 2, 2, 1300, 1300, 256, "bf16", True, (-1, -1), 0.0, False),   # 11 key blocks: mirrored pairs + the middle one
     (1, 2, 2, 31, 1000, 256, "bf16", True, (-1, -1), 0.0, False),     # less than one stage of rows
+    # ... head dims 129 .. 192 on the same kernel without the k-steps / accumulator blocks of the zero columns
+    (1, 2, 2, 300, 520, 192, "bf16", True, (-1, -1), 0.0, False),
+    (2, 4, 2, 513, 513, 160, "fp16", True, (-1, -1), 0.0, False),
+    (1, 2, 1, 700, 900, 136, "bf16", False, (200, 50), 0.0, False),
+    (1, 2, 2, 600, 600, 200, "fp16", True, (-1, -1), 0.0, False),     # 193 .. 256: the full width
     # softcap only (constants-folded variant in all kernels; Gemma-2 style)
     (2, 8, 2, 333, 333, 128, "bf16", True, (-1, -1), 50.0, False),
     (1, 4, 4, 200, 450, 64, "fp16", True, (128, 0), 20.0, False),
