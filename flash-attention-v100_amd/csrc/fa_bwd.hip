@@ -1567,11 +1567,13 @@ template <int D> struct DqSmem {
     static constexpr int TOTAL = 2 * STAGE;
 };
 
-template <typename T, int D, int BIAS, int OCC, bool DROPOUT>
+// DV: columns that can be non-zero (D = 256 only: head dims 129 .. 192 skip the k-steps and accumulator blocks of the zero columns)
+template <typename T, int D, int BIAS, int OCC, bool DROPOUT, int DV = D>
 __global__ void __launch_bounds__(BWD_THREADS, OCC) fa_bwd_dq_kernel(const KArgs a) {
     using E = Elem<T>;
-    constexpr int KSTEPS = D / 16;
-    constexpr int DBLKS = D / 32;
+    static_assert(DV == D || (D == 256 && DV == 192), "narrow form: 192 of 256 columns");
+    constexpr int KSTEPS = DV / 16;
+    constexpr int DBLKS = DV / 32;
     constexpr int CPR = D / 8;
     constexpr int CHUNKS = DQ_BN * CPR / BWD_THREADS;
     constexpr int TILE = DqSmem<D>::TILE;
@@ -2268,9 +2270,15 @@ static int launch_bwd_td(const KArgs& a, hipStream_t stream) {
 #define FA_LAUNCH_DQ(BIAS, DROP)                                                                                  \
         do {                                                                                                      \
             /* dropout needs the Philox registers: two waves per SIMD spill 84 of them (4.0 ms), one wave none */ \
-            auto kern = fa_bwd_dq_kernel<T, D, BIAS, (DROP) ? 1 : OCC, DROP>;                                     \
-            FA_SET_LDS_ONCE(kern, smem); \
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(BWD_THREADS), smem, stream, a);                             \
+            if (D == 256 && valid_cols(p) <= 192) {                                                               \
+                auto kern = fa_bwd_dq_kernel<T, D, BIAS, (DROP) ? 1 : OCC, DROP, (D == 256 ? 192 : D)>;           \
+                FA_SET_LDS_ONCE(kern, smem);                                                                      \
+                hipLaunchKernelGGL(kern, dim3(grid), dim3(BWD_THREADS), smem, stream, a);                         \
+            } else {                                                                                              \
+                auto kern = fa_bwd_dq_kernel<T, D, BIAS, (DROP) ? 1 : OCC, DROP>;                                 \
+                FA_SET_LDS_ONCE(kern, smem);                                                                      \
+                hipLaunchKernelGGL(kern, dim3(grid), dim3(BWD_THREADS), smem, stream, a);                         \
+            }                                                                                                     \
         } while (0)
         if (grid > 0) {
             if (drop) { if (a.has_bias) FA_LAUNCH_DQ(1, true); else FA_LAUNCH_DQ(0, true); }
