@@ -475,6 +475,22 @@ struct KArgs {
     int fuse_pre;                  // the dQ kernel computes D = rowsum(dO o O) itself, runs first and writes softmax_d + stats_ws
 };
 
+// ---- backward: geometry of one sequence, key-block size of the dK/dV kernels ----
+constexpr int DKV_BN = 128;     // keys per workgroup (32 per wave)
+struct SeqGeom {
+    int seqlen_q, seqlen_k, off;
+    int64_t q_row0, k_row0;
+};
+__device__ __forceinline__ SeqGeom seq_geom(const fa_params& p, int b) {
+    SeqGeom s;
+    s.seqlen_q = p.seqlen_q; s.seqlen_k = p.seqlen_k; s.q_row0 = 0; s.k_row0 = 0;
+    if (p.cu_seqlens_q) { s.q_row0 = p.cu_seqlens_q[b]; s.seqlen_q = p.cu_seqlens_q[b + 1] - (int)s.q_row0; }
+    if (p.cu_seqlens_k) { s.k_row0 = p.cu_seqlens_k[b]; s.seqlen_k = p.cu_seqlens_k[b + 1] - (int)s.k_row0; }
+    s.off = s.seqlen_k - s.seqlen_q;
+    return s;
+}
+
+
 // ---- ALiBi through the matrix pipe (causal-like masks: every visible key is at or left of the diagonal) ----
 // bias(q, key) = slope (key - off - q) is split into three small terms relative to the 32 x 32 sub-tile,
 //   slope * [ +-pos(register)  +  lane term  +  tile term ],
