@@ -90,8 +90,12 @@ static int check_common(const fa_params& p, bool need_out) {
                  "head_dim_v must be a multiple of 8 in [0, head_dim]");
         const bool narrow = p.head_dim_v > 0 && p.head_dim_v < p.head_dim;
         const int64_t lim = (int64_t)1 << (narrow ? 31 : 32);
-        FA_CHECK(rows_q * p.q_row_stride * 2 < lim && rows_k * p.k_row_stride * 2 < lim && rows_k * p.v_row_stride * 2 < lim,
-                 "one (batch, head) slice of q/k/v spans more than 4 GiB: not addressable by the gfx950 kernels");
+        // q: 2 GiB - its rows are fetched through one descriptor whose offset 0x80000000 must lie OUTSIDE the slice (rows past the
+        // sequence and columns past the valid width come back as zeros from the range check)
+        FA_CHECK(rows_q * p.q_row_stride * 2 < ((int64_t)1 << 31),
+                 "one (batch, head) slice of q spans more than 2 GiB: not addressable by the gfx950 kernels");
+        FA_CHECK(rows_k * p.k_row_stride * 2 < lim && rows_k * p.v_row_stride * 2 < lim,
+                 "one (batch, head) slice of k/v spans more than 4 GiB: not addressable by the gfx950 kernels");
     }
     return FA_OK;
 }

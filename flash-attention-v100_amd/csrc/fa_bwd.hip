@@ -772,11 +772,13 @@ template <int D> struct Dkv2Smem {
 #ifndef FA_DKV2_PF
 #define FA_DKV2_PF 3                                    // transposed dO / Q fragments in flight ahead of their MFMA
 #endif
-template <typename T, int D, int BIAS, bool DROPOUT>
+// DV: columns that can be non-zero (D = 128 only: head dims 65 .. 96 skip the k-steps and accumulator blocks of the zero columns)
+template <typename T, int D, int BIAS, bool DROPOUT, int DV = D>
 __global__ void __launch_bounds__(BWD_THREADS, D <= 64 ? FA_DKV2_OCC64 : 2) fa_bwd_dkdv2_kernel(const KArgs a) {
     using E = Elem<T>;
-    constexpr int KSTEPS = D / 16;
-    constexpr int DBLKS = D / 32;
+    static_assert(DV == D || (D == 128 && DV == 96), "narrow form: 96 of 128 columns");
+    constexpr int KSTEPS = DV / 16;
+    constexpr int DBLKS = DV / 32;
     constexpr int CPR = D / 8;
     constexpr int KT = Dkv2Smem<D>::KT;
     constexpr int QT = Dkv2Smem<D>::QT;
@@ -1217,7 +1219,7 @@ template <int D> struct DqSmem {
 template <typename T, int D, int BIAS, int OCC, bool DROPOUT, int DV = D>
 __global__ void __launch_bounds__(BWD_THREADS, OCC) fa_bwd_dq_kernel(const KArgs a) {
     using E = Elem<T>;
-    static_assert(DV == D || (D == 256 && DV == 192), "narrow form: 192 of 256 columns");
+    static_assert(DV == D || (D == 256 && DV == 192) || (D == 128 && DV == 96), "narrow forms: 192 of 256, 96 of 128 columns");
     constexpr int KSTEPS = DV / 16;
     constexpr int DBLKS = DV / 32;
     constexpr int CPR = D / 8;
@@ -1854,9 +1856,15 @@ static int launch_bwd_td(const KArgs& a, hipStream_t stream) {
                 }
 #define FA_LAUNCH_DKV2(BIAS, DROP)                                                                                \
                 do {                                                                                              \
-                    auto kern = fa_bwd_dkdv2_kernel<T, D, BIAS, DROP>;                                            \
-                    FA_SET_LDS_ONCE(kern, smem2); \
-                    hipLaunchKernelGGL(kern, dim3(grid2), dim3(BWD_THREADS), smem2, stream, a2);                  \
+                    if (D == 128 && valid_cols(p) <= 96) {                                                        \
+                        auto kern = fa_bwd_dkdv2_kernel<T, D, BIAS, DROP, (D == 128 ? 96 : D)>;                   \
+                        FA_SET_LDS_ONCE(kern, smem2);                                                             \
+                        hipLaunchKernelGGL(kern, dim3(grid2), dim3(BWD_THREADS), smem2, stream, a2);              \
+                    } else {                                                                                      \
+                        auto kern = fa_bwd_dkdv2_kernel<T, D, BIAS, DROP>;                                        \
+                        FA_SET_LDS_ONCE(kern, smem2);                                                             \
+                        hipLaunchKernelGGL(kern, dim3(grid2), dim3(BWD_THREADS), smem2, stream, a2);              \
+                    }                                                                                             \
                 } while (0)
                 if (a.has_bias && lin_alibi) FA_LAUNCH_DKV2(2, false);
                 else if (a.has_bias) FA_LAUNCH_DKV2(3, false);
@@ -1908,8 +1916,8 @@ static int launch_bwd_td(const KArgs& a, hipStream_t stream) {
 #define FA_LAUNCH_DQ(BIAS, DROP)                                                                                  \
         do {                                                                                                      \
             /* dropout needs the Philox registers: two waves per SIMD spill 84 of them (4.0 ms), one wave none */ \
-            if (D == 256 && valid_cols(p) <= 192) {                                                               \
-                auto kern = fa_bwd_dq_kernel<T, D, BIAS, (DROP) ? 1 : OCC, DROP, (D == 256 ? 192 : D)>;           \
+            if ((D == 256 && valid_cols(p) <= 192) || (D == 128 && valid_cols(p) <= 96)) {                          \
+                auto kern = fa_bwd_dq_kernel<T, D, BIAS, (DROP) ? 1 : OCC, DROP, (D == 256 ? 192 : (D == 128 ? 96 : D))>; \
                 FA_SET_LDS_ONCE(kern, smem);                                                                      \
                 hipLaunchKernelGGL(kern, dim3(grid), dim3(BWD_THREADS), smem, stream, a);                         \
             } else {                                                                                              \

@@ -54,12 +54,12 @@ template <int D> struct FwdSmem {
 // KV8: the K / V rows are fp8-e4m3 (KV cache): a tile is fetched to registers (16 codes per chunk), dequantised with the
 //      packed converts of fa_common.h and written to the same LDS images - ONCE per 128 query rows (chunked prefill over an
 //      fp8 cache); `k_descale` folds into the softmax scale, `v_descale` into the final normalisation.
-// DV:  columns that can be non-zero (D = 256 only: head dims 129 .. 192 run on the 256-wide LDS images - the missing columns are
-//      read as zeros - but skip the k-steps of S and the accumulator blocks of O that would only see them)
+// DV:  columns that can be non-zero (head dims 129 .. 192 run on the 256-wide LDS images, 65 .. 96 on the 128-wide ones - the missing
+//      columns are read as zeros - but skip the k-steps of S and the accumulator blocks of O that would only see them)
 template <typename T, int D, int BIAS, bool PAGED, bool DROPOUT, bool KV8 = false, int DV = D>
 __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : FA_FWD_OCC)) fa_fwd_kernel(const KArgs a) {
     using E = Elem<T>;
-    static_assert(DV == D || (D == 256 && DV == 192), "narrow form: 192 of 256 columns");
+    static_assert(DV == D || (D == 256 && DV == 192) || (D == 128 && DV == 96), "narrow forms: 192 of 256, 96 of 128 columns");
     constexpr int KSTEPS = DV / 16;
     constexpr int DBLKS = DV / 32;
     constexpr int CPR = D / 8;                          // 16-B chunks per row
@@ -803,11 +803,14 @@ static int launch_fwd_td(const KArgs& a, bool paged, hipStream_t stream) {
                                    : work_grid(a.p.batch, a.p.nheads_q, a.p.nheads_k, a.n_qblocks);   // n_qblocks = grid-level count
     const size_t smem = FwdSmem<D>::TOTAL;
     if (grid == 0) return 0;
-    const bool narrow192 = D == 256 && valid_cols(a.p) <= 192;
+#ifndef FA_FWD_NARROW96
+#define FA_FWD_NARROW96 1
+#endif
+    const bool narrow192 = (D == 256 && valid_cols(a.p) <= 192) || (FA_FWD_NARROW96 && D == 128 && valid_cols(a.p) <= 96);
 #define FA_LAUNCH(BIAS, PAGED, DROP)                                                            \
     do {                                                                                        \
         if (narrow192) {                                                                        \
-            auto kern = fa_fwd_kernel<T, D, BIAS, PAGED, DROP, false, (D == 256 ? 192 : D)>;    \
+            auto kern = fa_fwd_kernel<T, D, BIAS, PAGED, DROP, false, (D == 256 ? 192 : (D == 128 ? 96 : D))>; \
             FA_SET_LDS_ONCE(kern, smem);                                                        \
             hipLaunchKernelGGL(kern, dim3(grid), dim3(FWD_THREADS), smem, stream, a);           \
         } else {                                                                                \
