@@ -1876,8 +1876,8 @@ static int launch_bwd_td(const KArgs& a, hipStream_t stream) {
             }
         }
         if constexpr (D == 256) {
-            // no bias, no dropout: two waves per key block (fa_bwd_dkdv_split_kernel), one sweep instead of two
-            if (!a.has_bias && !drop && !a.ds_ws && grid > 0) {
+            // no bias or softcap only, no dropout: two waves per key block (fa_bwd_dkdv_split_kernel), one sweep instead of two
+            if ((!a.has_bias || (p.softcap > 0.f && !p.alibi_slopes)) && !drop && !a.ds_ws && grid > 0) {
                 KArgs a2 = a;
                 int grid2 = grid;
                 if (a.flat_blocks && p.cu_seqlens_k && p.total_k > 0) {

@@ -1,5 +1,5 @@
 // fa_bwd_d256.hip - dK / dV of the backward at head dim 256 (and, DV = 192, head dims 129 .. 192) without bias / dropout:
-// the two GEMM pairs of a 32 x 32 sub-tile on TWO waves.  Replaces the reference's uniform-in-D loop
+// (softcap-only scores included) the two GEMM pairs of a 32 x 32 sub-tile on TWO waves.  Replaces the reference's uniform-in-D loop
 // kernel/fused_mha_backward.cu:367-474 for D > 128 (everything else at that width stays on fa_bwd_dkdv_kernel in fa_bwd.hip).
 #include <type_traits>
 #include "fa_common.h"
@@ -27,7 +27,9 @@ constexpr int SPLIT_THREADS = 512;
 
 // DV: columns that can be non-zero (192: head dims 129 .. 192 run on the 256-wide images - the DMA reads the missing columns as
 // zeros - but skip the k-steps and the accumulator blocks that would only see them: 24 MFMAs per wave and sub-tile instead of 32)
-template <typename T, int D, int DV>
+// CAP: softcap without ALiBi (Gemma-2's head dim 256 form): the scores pass through cap tanh(s scale / cap) - only the P wave changes:
+//      it keeps P for its dV and hands P (1 - tanh^2) to the dS wave (the chain-rule factor belongs to dS alone)
+template <typename T, int D, int DV, bool CAP = false>
 __global__ void __launch_bounds__(SPLIT_THREADS, 1) fa_bwd_dkdv_split_kernel(const KArgs a) {
     using E = Elem<T>;
     static_assert(D == 256 && (DV == 256 || DV == 192), "two waves per key block: the D = 256 form");
@@ -71,6 +73,8 @@ __global__ void __launch_bounds__(SPLIT_THREADS, 1) fa_bwd_dkdv_split_kernel(con
     const int wl = p.window_left;
     const int wr = p.is_causal ? 0 : p.window_right;
     const float c = a.scale_log2e;
+    // softcap: cap tanh(s scale / cap) = cap (1 - 2 / (1 + exp2(s k1))) in log2 units (as in fa_bwd_dkdv2_kernel, BIAS == 3)
+    const float cap_k1 = CAP ? 2.0f * a.scale_log2e / p.softcap : 0.f, cap_c2 = CAP ? p.softcap * kLog2e : 0.f;
     const int dv = valid_cols(p);
 
     uint32_t q_voff[Q_INSTS], do_voff[Q_INSTS];
@@ -260,24 +264,34 @@ __global__ void __launch_bounds__(SPLIT_THREADS, 1) fa_bwd_dkdv_split_kernel(con
             }
             if (role == 0) {
                 const bool need_mask = key_tail || (q0 < w_qlo_max) || (q0 + 31 > w_qhi_min);
+                // P (kept in x: this wave's dV operand) and what the dS wave multiplies its dP - D with (-> LDS).  Edge tiles: each wave
+                // masks its own product below (both waves own the same keys: the same lane constants)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const f32x4 l4 = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(st_rp + (SB + 32 * i));
+                    f32x4 w4;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) x[4 * i + e] = fast_exp2(fmaf(x[4 * i + e], c, -l4[e]));
+                    for (int e = 0; e < 4; ++e) {
+                        const int r = 4 * i + e;
+                        float pr, chain = 1.0f;
+                        if (CAP) {
+                            const float rr1 = fast_rcp(1.0f + fast_exp2(x[r] * cap_k1));
+                            const float t = fmaf(rr1, -2.0f, 1.0f);
+                            pr = fast_exp2(fmaf(rr1, -2.0f * cap_c2, cap_c2) - l4[e]);
+                            chain = fmaf(-t, t, 1.0f);
+                        } else {
+                            pr = fast_exp2(fmaf(x[r], c, -l4[e]));
+                        }
+                        x[r] = pr;
+                        w4[e] = CAP ? pr * chain : pr;
+                    }
+                    *reinterpret_cast<__attribute__((address_space(3))) f32x4*>((lds_char*)(xb + 1024 * i)) = w4;
                 }
                 if (need_mask) {
                     const int lo_t = lo_l - q0;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int cpos = (r & 3) + 8 * (r >> 2);
-                        if ((uint32_t)(cpos - lo_t) > width) x[r] = 0.f;
-                    }
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const f32x4 v4 = {x[4 * i], x[4 * i + 1], x[4 * i + 2], x[4 * i + 3]};
-                    *reinterpret_cast<__attribute__((address_space(3))) f32x4*>((lds_char*)(xb + 1024 * i)) = v4;
+                    for (int r = 0; r < 16; ++r)
+                        if ((uint32_t)((r & 3) + 8 * (r >> 2) - lo_t) > width) x[r] = 0.f;
                 }
             }
         }
@@ -290,6 +304,12 @@ __global__ void __launch_bounds__(SPLIT_THREADS, 1) fa_bwd_dkdv_split_kernel(con
                     const f32x4 v4 = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>((const lds_char*)(xb + 1024 * i));
 #pragma unroll
                     for (int e = 0; e < 4; ++e) x[4 * i + e] *= v4[e];
+                }
+                if (key_tail || (q0 < w_qlo_max) || (q0 + 31 > w_qhi_min)) {      // (the P wave hands its tile over unmasked)
+                    const int lo_t = lo_l - q0;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if ((uint32_t)((r & 3) + 8 * (r >> 2) - lo_t) > width) x[r] = 0.f;
                 }
             }
 #pragma unroll
@@ -350,15 +370,16 @@ template <typename T>
 static int launch_split_t(const KArgs& a, int grid, hipStream_t stream) {
     constexpr int D = 256;
     const size_t smem = DkvSplitSmem<D>::TOTAL;
-    if (valid_cols(a.p) <= 192) {
-        auto kern = fa_bwd_dkdv_split_kernel<T, D, 192>;
-        FA_SET_LDS_ONCE(kern, smem);
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(SPLIT_THREADS), smem, stream, a);
-    } else {
-        auto kern = fa_bwd_dkdv_split_kernel<T, D, 256>;
-        FA_SET_LDS_ONCE(kern, smem);
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(SPLIT_THREADS), smem, stream, a);
-    }
+#define FA_LAUNCH_SPLIT(DV_, CAP_)                                                              \
+    do {                                                                                        \
+        auto kern = fa_bwd_dkdv_split_kernel<T, D, DV_, CAP_>;                                  \
+        FA_SET_LDS_ONCE(kern, smem);                                                            \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(SPLIT_THREADS), smem, stream, a);             \
+    } while (0)
+    const bool cap = a.p.softcap > 0.f;
+    if (valid_cols(a.p) <= 192) { if (cap) FA_LAUNCH_SPLIT(192, true); else FA_LAUNCH_SPLIT(192, false); }
+    else                        { if (cap) FA_LAUNCH_SPLIT(256, true); else FA_LAUNCH_SPLIT(256, false); }
+#undef FA_LAUNCH_SPLIT
     return 0;
 }
 

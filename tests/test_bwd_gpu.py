@@ -93,6 +93,10 @@ CASES = [
     (2, 4, 2, 513, 513, 160, "fp16", True, (-1, -1), 0.0, False),
     (1, 2, 1, 700, 900, 136, "bf16", False, (200, 50), 0.0, False),
     (1, 2, 2, 600, 600, 200, "fp16", True, (-1, -1), 0.0, False),     # 193 .. 256: the full width
+    # ... and with softcap only (Gemma-2's head dim 256 form): the P wave hands P (1 - tanh^2) over
+    (2, 4, 2, 700, 700, 256, "bf16", True, (-1, -1), 50.0, False),
+    (1, 2, 2, 520, 300, 256, "fp16", False, (300, 0), 30.0, False),   # sliding window, Sq > Sk
+    (1, 2, 1, 300, 520, 160, "bf16", True, (-1, -1), 20.0, False),
     # softcap only (constants-folded variant in all kernels; Gemma-2 style)
     (2, 8, 2, 333, 333, 128, "bf16", True, (-1, -1), 50.0, False),
     (1, 4, 4, 200, 450, 64, "fp16", True, (128, 0), 20.0, False),

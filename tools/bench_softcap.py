@@ -1,4 +1,4 @@
-"""softcap (Gemma-2 style) vs plain causal: forward and backward kernels (bf16 B8 H16 S4096 D128)."""
+"""softcap (Gemma-2 style) vs plain causal: forward and backward kernels (bf16 B8 S4096; H16 D128, or `python tools/bench_softcap.py 256`: H8 D256 - Gemma-2 9B's head dim)."""
 import os, sys
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, os.path.join(ROOT, "flash-attention-v100_amd")); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
@@ -6,6 +6,8 @@ import torch, flash_attn
 from _bwdsel import bwd_call
 from bench_configs import timeit
 B, S, H, D = 8, 4096, 16, 128
+if len(sys.argv) > 1 and sys.argv[1] == "256":
+    H, D = 8, 256
 q, k, v = (torch.randn(B, S, H, D, device="cuda", dtype=torch.bfloat16, requires_grad=True) for _ in range(3))
 do = torch.randn(B, S, H, D, device="cuda", dtype=torch.bfloat16)
 for cap in (0.0, 0.0, 50.0):
