@@ -859,6 +859,7 @@ class Gen:
         A = L.append
         timers = cfg.get("timers", 0)      # measurement build: s_memtime stamps land in the LSE rows r0 .. r0+4 of the wave
         self.timers_build = bool(timers)   # (its stamps live in v246..v251: no triangle block)
+        self.tri = self.tri and bool(cfg.get("tri", True))      # (--cfg={"tri":0}: the compare / select chain on every masked tile, A/B)
 
         def stamp(i):
             if timers:
