@@ -65,7 +65,7 @@ static int check_common(const fa_params& p, bool need_out) {
     FA_CHECK(p.q && (no_keys || (p.k && p.v)), "q, k, v must not be NULL");
     FA_CHECK(!need_out || (p.o && p.lse), "o and lse must not be NULL");
     FA_CHECK(p.dtype == FA_FP16 || p.dtype == FA_BF16, "q must be fp16 or bf16");
-    FA_CHECK((p.flags & ~FA_FLAG_KEEP_WINDOW) == 0, "fa_params::flags has unknown bits set (zero-initialise the struct)");
+    FA_CHECK((p.flags & ~(FA_FLAG_KEEP_WINDOW | FA_FLAG_NO_DKV_SPLIT)) == 0, "fa_params::flags has unknown bits set (zero-initialise the struct)");
     FA_CHECK(p.batch > 0, "batch size must be positive");
     FA_CHECK(p.head_dim <= 256, "head dimension must be <= 256");
     FA_CHECK(p.head_dim % 8 == 0, "head dimension must be multiple of 8");
@@ -207,7 +207,13 @@ size_t fa_fwd_workspace_bytes(const fa_params* p) {
     if (varlen_mixed_route(*p, d)) return fa::decode_workspace_bytes(d);
     return 0;
 }
-size_t fa_bwd_workspace_bytes(const fa_params* p) { return p ? fa::bwd_workspace_bytes(*p) : 0; }
+size_t fa_bwd_workspace_bytes(const fa_params* pp) {
+    if (!pp) return 0;
+    fa_params p = *pp;
+    // dense calls: the flags as fa_bwd will see them (the split of small dK/dV launches depends on the mask's shape)
+    if (!p.cu_seqlens_q && !p.cu_seqlens_k && p.seqlen_q > 0 && p.seqlen_k > 0) normalize(p, false);
+    return fa::bwd_workspace_bytes(p);
+}
 size_t fa_fwd_kvcache_workspace_bytes(const fa_params* pp) {
     if (!pp) return 0;
     fa_params p = *pp;                                   // what fa_fwd_kvcache launches with (the decode code reads these fields)

@@ -798,6 +798,8 @@ __global__ void __launch_bounds__(BWD_THREADS, D <= 64 ? FA_DKV2_OCC64 : 2) fa_b
     const int n_kb_grid = pair ? (n_kblocks + 1) / 2 : n_kblocks;
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, g = lane >> 5;
     int b, hk, nb0;
+    const int nsplit = a.dkv_split > 1 ? a.dkv_split : 1;    // dense launches only (dkv_split_factor)
+    int split = 0;
     if (a.flat_kblocks) {
         // varlen flat work list over key blocks (fa_common.h: flat_owner), early (for causal masks: heavy) blocks first
         const int id = blockIdx.x;
@@ -805,7 +807,9 @@ __global__ void __launch_bounds__(BWD_THREADS, D <= 64 ? FA_DKV2_OCC64 : 2) fa_b
         flat_owner(id / p.nheads_k, DKV_BN, p.batch, p.cu_seqlens_k, lane, b, nb0);
         if (b < 0) return;
     } else {
-        const int id = blockIdx.x, xcd = id & 7, j = id >> 3;
+        const int id = blockIdx.x, xcd = id & 7;
+        int j = id >> 3;
+        if (nsplit > 1) { split = j % nsplit; j /= nsplit; }       // the splits of a key block: neighbours on one XCD
         const int ul = j / n_kb_grid;
         nb0 = j - ul * n_kb_grid;
         const int unit = ul * 8 + xcd;
@@ -908,8 +912,9 @@ __global__ void __launch_bounds__(BWD_THREADS, D <= 64 ? FA_DKV2_OCC64 : 2) fa_b
         if (wr >= 0) { const int t = n0 - off - wr; m_lo = t > 0 ? t : 0; }
         if (wl >= 0) { const int t = n_last - off + wl + 1; m_hi = t < m_hi ? t : m_hi; }
     }
-    const int mt0 = m_lo / BQ;
-    const int mt1 = m_hi > m_lo ? (m_hi + BQ - 1) / BQ : mt0;
+    int mt0 = m_lo / BQ;
+    int mt1 = m_hi > m_lo ? (m_hi + BQ - 1) / BQ : mt0;
+    if (nsplit > 1) dkv_split_range(split, nsplit, mt0, mt1);         // this split's share of the pass's query tiles
     const int n_tiles = mt1 - mt0;
     const int n_iter = n_tiles * group;
     // the mask of a sub-tile as two lane constants (see fa_fwd.hip): masked <=> (cpos - lo_t) >u width, lo_t = lo_l - q0
@@ -1174,6 +1179,25 @@ __global__ void __launch_bounds__(BWD_THREADS, D <= 64 ? FA_DKV2_OCC64 : 2) fa_b
         const int64_t dvb = p.cu_seqlens_k ? 0 : (int64_t)b * p.dv_batch_stride;
         uint16_t* dkp = reinterpret_cast<uint16_t*>(p.dk) + dkb + (sg.k_row0 + my_key) * p.dk_row_stride + (int64_t)hk * p.dk_head_stride;
         uint16_t* dvp = reinterpret_cast<uint16_t*>(p.dv) + dvb + (sg.k_row0 + my_key) * p.dv_row_stride + (int64_t)hk * p.dv_head_stride;
+        if (nsplit > 1) {
+            // partial dK / dV of this split, fp32 [dK | dV][split][B][Sk][Hk][D]: the accumulators as they are (dK scaled, dV
+            // with the dropout factor) - dkv_reduce_kernel adds the splits and rounds once
+            const int64_t row = (int64_t)p.nheads_k * D, slab = (int64_t)p.batch * p.seqlen_k * row;
+            float* pk = reinterpret_cast<float*>(a.dkv_part) + split * slab + ((int64_t)b * p.seqlen_k + my_key) * row + (int64_t)hk * D;
+            float* pv = pk + nsplit * slab;
+            const float sc = p.softmax_scale, rp = DROPOUT ? a.rp_dropout : 1.0f;
+#pragma unroll
+            for (int d = 0; d < DBLKS; ++d)
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq) {
+                    if (d * 32 + 8 * rq + 4 * g < dv) {
+                        const f32x4 k4 = {dk_acc[d][4 * rq + 0] * sc, dk_acc[d][4 * rq + 1] * sc, dk_acc[d][4 * rq + 2] * sc, dk_acc[d][4 * rq + 3] * sc};
+                        const f32x4 v4 = {dv_acc[d][4 * rq + 0] * rp, dv_acc[d][4 * rq + 1] * rp, dv_acc[d][4 * rq + 2] * rp, dv_acc[d][4 * rq + 3] * rp};
+                        *reinterpret_cast<f32x4*>(pk + d * 32 + 8 * rq + 4 * g) = k4;
+                        *reinterpret_cast<f32x4*>(pv + d * 32 + 8 * rq + 4 * g) = v4;
+                    }
+                }
+        } else {
         const float sc = p.softmax_scale;
 #pragma unroll
         for (int d = 0; d < DBLKS; ++d)
@@ -1190,6 +1214,7 @@ __global__ void __launch_bounds__(BWD_THREADS, D <= 64 ? FA_DKV2_OCC64 : 2) fa_b
                     *reinterpret_cast<u32x2*>(dvp + d * 32 + 8 * rq + 4 * g) = v2;
                 }
             }
+        }
     }
     }   // pass
 }
@@ -1761,6 +1786,85 @@ bool bwd_asm_applicable(const KArgs& a);
 size_t bwd_asm_workspace_bytes(const fa_params& p);
 int launch_bwd_dkdv_asm(const KArgs& a, hipStream_t stream);
 
+// ---------------------------------------------------------------------------------------------
+// dK/dV launches smaller than the chip.  A dK/dV workgroup owns 128 keys of one (batch, kv-head) and walks every query
+// tile of every q-head of the GQA group: batch x kv-heads x key blocks workgroups - 128 of them for a Llama-3 layer at
+// micro-batch 1 and 4 k tokens (H 32/8, causal pairs) on 256 CUs, 64 for a cross-attention layer with 77 keys.  Such
+// launches divide the query tiles of each pass over `dkv_split` workgroups; every split leaves its fp32 accumulators (dK
+// scaled) in the workspace and dkv_reduce_kernel adds them in split order and rounds once: deterministic, and the same
+// value as the one-workgroup sum up to the order of the fp32 additions (the reference accumulates a GQA group in one
+// block too: kernel/fused_mha_backward.cu:351-474).
+// ---------------------------------------------------------------------------------------------
+constexpr int DKV_SPLIT_MAX = 8;
+constexpr int DKV_SPLIT_MIN_STAGES = 8;                  // query stages x q-heads a split should keep (a pass's prologue ~ 3-4 stages)
+
+// slots_per_cu: workgroups of the kernel a CU holds at once; stage_rows: query rows per stage of that kernel
+static int dkv_split_factor(const fa_params& p, int pair, int slots_per_cu, int stage_rows) {
+    if (p.cu_seqlens_q || p.cu_seqlens_k || p.seqlen_q < 1 || p.seqlen_k < 1 || p.nheads_k < 1) return 1;
+    if (p.flags & FA_FLAG_NO_DKV_SPLIT) return 1;
+    const int64_t n_kblocks = (p.seqlen_k + DKV_BN - 1) / DKV_BN;
+    const bool paired = pair && n_kblocks >= 2;
+    const int64_t wgs = (int64_t)p.batch * p.nheads_k * (paired ? (n_kblocks + 1) / 2 : n_kblocks);
+    const int64_t slots = (int64_t)fa_device_cu_count() * slots_per_cu;
+    if (wgs < 1 || wgs >= slots) return 1;               // a full round of workgroups: leave it alone
+    // stages of a workgroup (a causal pair walks about one full sequence in its two passes)
+    const int64_t stages = (int64_t)((p.seqlen_q + stage_rows - 1) / stage_rows) * (p.nheads_q / p.nheads_k);
+    int best = 1;
+    double best_cost = 1e30;
+    for (int s = 1; s <= DKV_SPLIT_MAX; ++s) {
+        if (s > 1 && stages / s < DKV_SPLIT_MIN_STAGES) break;
+        // rounds of workgroups x the length of one, + 4 % per extra split for the repeated K / V prologue and the partials
+        const double cost = (double)((wgs * s + slots - 1) / slots) / s * (1.0 + 0.04 * (s - 1));
+        if (cost < best_cost - 1e-9) { best_cost = cost; best = s; }
+    }
+    // the partial slabs are addressed like dk / dv: 31-bit byte offsets inside one (batch) slice
+    if ((int64_t)(p.seqlen_k + DKV_BN) * p.nheads_k * p.head_dim * 4 >= ((int64_t)1 << 31)) return 1;
+    return best;
+}
+static size_t dkv_split_bytes(const fa_params& p, int split) {
+    return split > 1 ? (size_t)2 * split * p.batch * p.seqlen_k * p.nheads_k * p.head_dim * sizeof(float) : 0;
+}
+
+// dk[b, key, hk, :] = sum over the splits of the fp32 partial rows (split order), rounded once; the same for dv; 8 columns per thread
+template <typename T>
+__global__ void __launch_bounds__(256) dkv_reduce_kernel(const KArgs a) {
+    using E = Elem<T>;
+    const fa_params& p = a.p;
+    const int D = p.head_dim, cpr = D / 8, dv = valid_cols(p);
+    const int64_t rows = (int64_t)p.batch * p.seqlen_k * p.nheads_k;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t row = idx / cpr;
+    const int cc = (int)(idx - row * cpr);
+    if (row >= rows || cc * 8 >= dv) return;
+    const int which = blockIdx.y;                            // 0: dK, 1: dV
+    const int64_t slab = rows * D;
+    const float* src = reinterpret_cast<const float*>(a.dkv_part) + (int64_t)which * a.dkv_split * slab + row * D + cc * 8;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int s = 0; s < a.dkv_split; ++s) {
+        const f32x4 x0 = *reinterpret_cast<const f32x4*>(src + (int64_t)s * slab);
+        const f32x4 x1 = *reinterpret_cast<const f32x4*>(src + (int64_t)s * slab + 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { acc[i] += x0[i]; acc[4 + i] += x1[i]; }
+    }
+    const int hk = (int)(row % p.nheads_k);
+    const int64_t bk = row / p.nheads_k;
+    const int key = (int)(bk % p.seqlen_k);
+    const int64_t b = bk / p.seqlen_k;
+    uint16_t* dst = which == 0
+        ? reinterpret_cast<uint16_t*>(p.dk) + b * p.dk_batch_stride + (int64_t)key * p.dk_row_stride + (int64_t)hk * p.dk_head_stride
+        : reinterpret_cast<uint16_t*>(p.dv) + b * p.dv_batch_stride + (int64_t)key * p.dv_row_stride + (int64_t)hk * p.dv_head_stride;
+    u32x4 o4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o4[i] = E::pack2(acc[2 * i], acc[2 * i + 1]);
+    *reinterpret_cast<u32x4*>(dst + cc * 8) = o4;
+}
+template <typename T>
+static void launch_dkv_reduce(const KArgs& a, hipStream_t stream) {
+    const fa_params& p = a.p;
+    const int64_t total = (int64_t)p.batch * p.seqlen_k * p.nheads_k * (p.head_dim / 8);
+    hipLaunchKernelGGL(dkv_reduce_kernel<T>, dim3((unsigned)((total + 255) / 256), 2), dim3(256), 0, stream, a);
+}
+
 static size_t bwd_ds_workspace_bytes(const fa_params& p) {
 #ifdef FA_MEASURE
     static const double max_gb = getenv("FA_BWD_DS_MAX_GB") ? atof(getenv("FA_BWD_DS_MAX_GB")) : 0.0;
@@ -1784,10 +1888,27 @@ static KArgs bwd_probe_args(const fa_params& p) {
     a.flat_blocks = p.cu_seqlens_q ? 1 : 0;           // (packed sequences run through the flat work lists unless FA_VARLEN_GRID=1)
     return a;
 }
+// which dK/dV kernel a dense call takes decides the slots per CU and the stage height behind dkv_split_factor
+static int bwd_dkv_split_for(const KArgs& a, bool asm_kernel) {
+    const fa_params& p = a.p;
+    const bool drop = p.p_dropout > 0.f;
+    const bool lin_alibi = p.alibi_slopes && p.softcap <= 0.f && (p.is_causal || p.window_right == 0);
+    const bool cap_only = p.softcap > 0.f && !p.alibi_slopes;
+    const int pair = ((p.is_causal || p.window_right >= 0) && p.window_left < 0) ? 1 : 0;     // (fa_api.hip: make_args)
+    if (asm_kernel) return p.alibi_slopes ? 1 : dkv_split_factor(p, pair, 1, 32);     // (the ALiBi bodies have no partial epilogue)
+    if (p.head_dim > 128 || a.ds_ws) return 1;
+    if (!(!a.has_bias || ((lin_alibi || cap_only) && !drop))) return 1;     // fa_bwd_dkdv_kernel: no split form
+    return p.head_dim <= 64 ? dkv_split_factor(p, pair, FA_DKV2_OCC64, 64) : dkv_split_factor(p, pair, 2, 32);
+}
+static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 size_t bwd_workspace_bytes(const fa_params& p) {
     const size_t ds = bwd_ds_workspace_bytes(p);
     if (ds > 0) return ds;
-    return bwd_asm_applicable(bwd_probe_args(p)) ? bwd_asm_workspace_bytes(p) : 0;
+    const KArgs a = bwd_probe_args(p);
+    const bool asm_kernel = bwd_asm_applicable(a);
+    const size_t stats = asm_kernel ? bwd_asm_workspace_bytes(p) : 0;
+    const size_t part = dkv_split_bytes(p, bwd_dkv_split_for(a, asm_kernel));
+    return part ? align256(stats) + part : stats;
 }
 #ifdef FA_TIMERS
 extern "C" int fa_debug_read_timers(unsigned long long* out, int n) {
@@ -1841,7 +1962,11 @@ static int launch_bwd_td(const KArgs& a, hipStream_t stream) {
 #endif
         bool done = false;
         if constexpr (D == 128) {
-            if (a.stats_ws && grid > 0) { launch_bwd_dkdv_asm(a, stream); done = true; }
+            if (a.stats_ws && grid > 0) {
+                launch_bwd_dkdv_asm(a, stream);             // (grid x a.dkv_split workgroups)
+                if (a.dkv_split > 1) launch_dkv_reduce<T>(a, stream);
+                done = true;
+            }
         }
         if constexpr (D <= 128) {
             if (done) {} else {
@@ -1853,6 +1978,8 @@ static int launch_bwd_td(const KArgs& a, hipStream_t stream) {
                 if (a.flat_blocks && p.cu_seqlens_k && p.total_k > 0) {
                     a2.flat_kblocks = p.total_k / DKV_BN + p.batch;
                     grid2 = a2.flat_kblocks * p.nheads_k;
+                } else if (a.dkv_split > 1) {
+                    grid2 = grid * a.dkv_split;           // the query tiles of a pass over dkv_split workgroups (dkv_split_factor)
                 }
 #define FA_LAUNCH_DKV2(BIAS, DROP)                                                                                \
                 do {                                                                                              \
@@ -1871,6 +1998,7 @@ static int launch_bwd_td(const KArgs& a, hipStream_t stream) {
                 else if (drop) FA_LAUNCH_DKV2(0, true);
                 else FA_LAUNCH_DKV2(0, false);
 #undef FA_LAUNCH_DKV2
+                if (a.dkv_split > 1) launch_dkv_reduce<T>(a, stream);
                 done = true;
             }
             }
@@ -1967,6 +2095,18 @@ int launch_bwd(const KArgs& a_in, hipStream_t stream) {
             // provides softmax_d and the statistics planes (dense layout only; packed sequences take the hipcc dK/dV kernel)
             a.fuse_pre = 0;
             if (a.p.cu_seqlens_q) a.stats_ws = nullptr;
+        }
+    }
+    // a dense dK/dV launch smaller than the chip: query tiles split over several workgroups + a reduction (dkv_split_factor)
+    a.dkv_split = 0;
+    a.dkv_part = nullptr;
+    if (a.p.dk && !a.ds_ws && !a.p.cu_seqlens_q && !a.p.cu_seqlens_k) {
+        const bool asm_kernel = a.p.head_dim == 128 && a.stats_ws != nullptr;
+        const int split = bwd_dkv_split_for(a, asm_kernel);
+        const size_t off = align256(bwd_asm_applicable(a) ? bwd_asm_workspace_bytes(a.p) : 0);      // as bwd_workspace_bytes lays it out
+        if (split > 1 && a.p.workspace && a.p.workspace_bytes >= off + dkv_split_bytes(a.p, split)) {
+            a.dkv_split = split;
+            a.dkv_part = reinterpret_cast<char*>(a.p.workspace) + off;
         }
     }
     const bool bf = a.p.dtype == FA_BF16;

@@ -473,7 +473,19 @@ struct KArgs {
     int rope_q;                    // kv-cache general path: fa_fwd_kernel rotates its Q fragments in registers (rotary_cos / sin at
                                    // position cache_seqlens[b] + leftpad (+ row under a causal / local mask), include/rotary.h:176-202)
     int fuse_pre;                  // the dQ kernel computes D = rowsum(dO o O) itself, runs first and writes softmax_d + stats_ws
+    // backward, dense dK/dV launches with fewer workgroups than the chip has slots (GQA at micro-batch 1, short-key
+    // cross-attention): the query tiles of every pass are divided over dkv_split workgroups, each leaves an fp32 partial
+    // dK / dV and dkv_reduce_kernel sums them (fa_bwd.hip: dkv_split_factor)
+    int dkv_split;                 // 0 / 1: one workgroup per key block
+    void* dkv_part;                // fp32 [dK | dV][dkv_split][B][Sk][Hk][head_dim]
 };
+
+// the query tiles [mt0, mt1) of a dK/dV pass that split `s` of `n` walks
+__device__ __forceinline__ void dkv_split_range(int s, int n, int& mt0, int& mt1) {
+    const int nt = mt1 - mt0;
+    const int lo = mt0 + (int)((int64_t)nt * s / n), hi = mt0 + (int)((int64_t)nt * (s + 1) / n);
+    mt0 = lo; mt1 = hi;
+}
 
 // ---- backward: geometry of one sequence, key-block size of the dK/dV kernels ----
 constexpr int DKV_BN = 128;     // keys per workgroup (32 per wave)

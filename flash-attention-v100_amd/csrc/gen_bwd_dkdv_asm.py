@@ -95,6 +95,8 @@ V_SVL = 218                     # in: sv in lanes 0 .. 31, 0 in lanes 32 .. 63
 V_AB = (220, 248)               # owned: B operand of the stage whose S is computed next, per buffer parity (4 regs each)
 V_AX = 242                      # owned: two temps of the split
 S_TT0 = 59                      # in: kw0 - off (integer): the stage's tile term is TT0 - 32 * tile
+S_P32 = 59                      # in (bodies without ALiBi): != 0: the pass leaves an fp32 PARTIAL dK / dV - its dK / dV descriptors and row
+                                # bytes describe [keys][kv-heads][128] fp32 rows of a split's slab (fa_bwd.hip: dkv_split_factor)
 A_DK, A_DV, A_K, A_V = 0, 64, 128, 160
 A_RR = 192                      # row-fragment ring (8 x 4)
 A_TRR = 224                     # transposed-fragment ring (8 x 4)
@@ -627,6 +629,9 @@ class DKV(Gen):
         A(f"s_lshl_b32 s{t + 1}, s{t + 1}, 2")                    # 4 rows further
         A(f"s_lshl_b32 s{t + 2}, s{t + 2}, 2")
         A("s_nop 7")
+        if not self.alibi_kv:
+            A(f"s_cmp_eq_u32 s{S_P32}, 0")
+            A("s_cbranch_scc0 L_ep32_%=")
         for ti, (acc, scale) in enumerate(((A_DK, True), (A_DV, False))):
             for d in range(4):
                 for r4 in range(4):
@@ -660,6 +665,33 @@ class DKV(Gen):
             A("s_mov_b64 exec, -1")
             A("s_waitcnt vmcnt(0)")
         A("s_branch L_end_%=")
+        if not self.alibi_kv:
+            # ---- epilogue of a split pass: the fp32 accumulators as they are (dK scaled), 16 bytes per lane straight from the
+            # registers: lane (key l31, g) holds columns 32 d + 8 r4 + 4 g .. + 3 of its key's row.  Rows past the sequence fall
+            # outside the descriptor.  (32-byte runs per row - the epilogue is ~3 % of a pass and these rows stay in L2 for the
+            # reduction kernel)
+            A("L_ep32_%=:")
+            A(f"v_add_u32 v{T + 1}, s{t + 3}, v{T + 1}")              # global key row of the lane's accumulator columns
+            A(f"s_lshr_b32 s{t + 1}, s{t + 1}, 2")                    # (undo the "4 rows further" shifts)
+            A(f"s_lshr_b32 s{t + 2}, s{t + 2}, 2")
+            A(f"v_lshlrev_b32 v{T + 2}, 4, v{T + 2}")                 # 16 g
+            A("s_nop 1")
+            A(f"v_mad_u32_u24 v{T + 7}, v{T + 1}, s{t + 1}, v{T + 2}")   # dK byte offset: row * row bytes + 16 g
+            A(f"v_mad_u32_u24 v{T + 8}, v{T + 1}, s{t + 2}, v{T + 2}")   # dV
+            for ti, (acc, scale, voff, rs) in enumerate(((A_DK, True, T + 7, S_DKRS), (A_DV, False, T + 8, S_DVRS))):
+                for d in range(4):
+                    for r4 in range(4):
+                        base = acc + 16 * d + 4 * r4
+                        tt = ep0 + 4 * ((4 * d + r4) % 8)
+                        for e in range(4):
+                            A(f"v_accvgpr_read_b32 v{tt + e}, a{base + e}")
+                        if scale:
+                            for e in range(4):
+                                A(f"v_mul_f32 v{tt + e}, s{S_SCALE}, v{tt + e}")
+                        else:
+                            A("s_nop 1")
+                        A(f"buffer_store_dwordx4 {vr(tt, 4)}, v{voff}, {sr(rs, 4)}, 0 offen offset:{128 * d + 32 * r4}")
+            A("s_branch L_end_%=")
         for par in (0, 1):
             A(f"L_mask{par}_%=:")
             L += self.gen_mask_routine(par)

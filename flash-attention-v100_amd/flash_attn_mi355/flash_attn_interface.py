@@ -252,6 +252,11 @@ def _dense_forward(q, k, v, dropout_p, softmax_scale, causal, window_size, softc
     return res, lse, dmask, (q_, k_, v_, out_), rng, softmax_scale
 
 
+# Small dense dK/dV launches (batch x kv-heads x key blocks < the CUs' slots) split their query rows over several workgroups
+# (include/fa_mi355.h: FA_FLAG_NO_DKV_SPLIT).  False: one workgroup per key block, bit-identical across batch sizes.
+DKV_SPLIT = True
+
+
 def _dense_backward(dout, q_, k_, v_, out_, lse, alibi_slopes, dropout_p, softmax_scale, causal,
                     window_size, softcap, rng, dq_, dk_, dv_, keep_window=False):
     """One fa_bwd call; dq_/dk_/dv_ are caller-allocated [B, S, H, dpad] views (written in place).  dq_ = None, or
@@ -278,6 +283,8 @@ def _dense_backward(dout, q_, k_, v_, out_, lse, alibi_slopes, dropout_p, softma
     p.seqlen_q, p.seqlen_k = M, N
     if keep_window:
         p.flags = _lib.FA_FLAG_KEEP_WINDOW
+    if not DKV_SPLIT:
+        p.flags |= _lib.FA_FLAG_NO_DKV_SPLIT
     _set_head_dim(p, dpad)
     _alibi(p, alibi_slopes, B, H_Q, q_.device)
     _philox(p, dropout_p, B, H_Q, q_.device, rng=rng)

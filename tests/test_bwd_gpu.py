@@ -293,3 +293,71 @@ def test_peaky_softmax_forward_and_backward(dt):
     assert np.abs(f64(lse) - lse_ref).max() <= 1e-4
     for name, a, b in zip(("dq", "dk", "dv"), g, g_ref):
         assert_close(t(a), b, dt, name, mult=2.0)
+
+
+# dK/dV launches smaller than the chip split their query rows over several workgroups and add fp32 partials
+# (fa_bwd.hip: dkv_split_factor / dkv_reduce_kernel; include/fa_mi355.h: FA_FLAG_NO_DKV_SPLIT).  Every small case above runs
+# that form; here: the shapes it was built for, both forms against the oracle and against each other.
+SPLIT_CASES = [
+    # B, Hq, Hk, Sq, Sk, D, dtype, causal, window
+    (1, 8, 2, 1024, 1024, 128, "bf16", True, (-1, -1)),     # GQA at micro-batch 1: hand-scheduled kernel, group of 4, mirrored pairs
+    (1, 4, 4, 1100, 1100, 128, "fp16", True, (-1, -1)),     # one q-head per kv-head: the fast copies start inside a split
+    (1, 16, 1, 600, 600, 128, "bf16", False, (-1, -1)),     # MQA group of 16, no mask
+    (2, 4, 4, 2048, 77, 64, "fp16", False, (-1, -1)),       # short-key cross-attention: one ragged key block
+    (2, 4, 4, 1500, 77, 40, "fp16", False, (-1, -1)),       # ... head dim 40 (valid columns only)
+    (1, 4, 2, 1024, 300, 96, "bf16", False, (-1, -1)),      # 128-wide compiler kernel, 96 valid columns
+    (1, 14, 2, 900, 900, 64, "bf16", True, (-1, -1)),       # group of 7 at head dim 64
+    (1, 4, 2, 1300, 1300, 128, "bf16", False, (200, 0)),    # left window: passes of different lengths
+    (1, 2, 2, 1100, 1500, 64, "fp16", True, (-1, -1)),      # Sq < Sk: key blocks without rows
+]
+
+
+def _split_bytes(B, Hq, Hk, Sq, Sk, D, dt, causal, window, flags):
+    from flash_attn_mi355 import _lib
+    import ctypes
+    p = _lib.FaParams()
+    p.batch, p.nheads_q, p.nheads_k, p.seqlen_q, p.seqlen_k = B, Hq, Hk, Sq, Sk
+    p.head_dim = 64 if D <= 64 else (128 if D <= 128 else 256)
+    p.head_dim_v = D if D != p.head_dim else 0
+    p.dtype = p.kv_dtype = _lib.FA_BF16 if dt == "bf16" else _lib.FA_FP16
+    p.is_causal, p.window_left, p.window_right = int(causal), window[0], window[1]
+    p.softmax_scale = D ** -0.5
+    p.q_row_stride = p.do_row_stride = Hq * D; p.q_head_stride = p.do_head_stride = D
+    p.k_row_stride = p.v_row_stride = p.dk_row_stride = p.dv_row_stride = Hk * D
+    p.flags = flags
+    return int(_lib.lib.fa_bwd_workspace_bytes(ctypes.byref(p)))
+
+
+@pytest.mark.parametrize("case", SPLIT_CASES, ids=lambda c: "-".join(map(str, c)))
+def test_small_dkdv_launches_split_their_query_rows(case, monkeypatch):
+    from flash_attn_mi355 import _lib, flash_attn_interface as fi
+    B, Hq, Hk, Sq, Sk, D, dt, causal, window = case
+    # the split is on for this shape: it asks for partial slabs on top of the unsplit call's workspace
+    assert _split_bytes(*case, 0) > _split_bytes(*case, _lib.FA_FLAG_NO_DKV_SPLIT)
+    q = rand16((B, Sq, Hq, D), dt, 521).requires_grad_(True)
+    k = rand16((B, Sk, Hk, D), dt, 522).requires_grad_(True)
+    v = rand16((B, Sk, Hk, D), dt, 523).requires_grad_(True)
+    do = rand16((B, Sq, Hq, D), dt, 524)
+    grads = {}
+    for on in (True, False):
+        monkeypatch.setattr(fi, "DKV_SPLIT", on)
+        out = _fa().flash_attn_func(q, k, v, causal=causal, window_size=window)
+        grads[on] = torch.autograd.grad(out, (q, k, v), do)
+        again = torch.autograd.grad(_fa().flash_attn_func(q, k, v, causal=causal, window_size=window), (q, k, v), do)
+        for a_, b_ in zip(grads[on], again):
+            assert torch.equal(a_, b_)                       # both forms are deterministic
+    assert torch.equal(grads[True][0], grads[False][0])      # dQ does not know about it
+    t = lambda x: f64(x).transpose(0, 2, 1, 3)
+    o_ref, lse_ref, _ = oracle.attn_fwd(t(q), t(k), t(v), D ** -0.5, causal=causal, window=window)
+    g = oracle.attn_bwd(t(do), t(q), t(k), t(v), o_ref, lse_ref.astype(np.float64), D ** -0.5, causal=causal, window=window)
+    for on in (True, False):
+        assert_close(t(grads[on][1]), g[1], dt, f"dk split={on}", mult=2.0)
+        assert_close(t(grads[on][2]), g[2], dt, f"dv split={on}", mult=2.0)
+
+
+def test_a_full_round_of_dkdv_workgroups_is_not_split():
+    from flash_attn_mi355 import _lib
+    big = (8, 16, 16, 4096, 4096, 128, "bf16", True, (-1, -1))          # BASELINE config 2: 2048 workgroups
+    assert _split_bytes(*big, 0) == _split_bytes(*big, _lib.FA_FLAG_NO_DKV_SPLIT)
+    d256 = (1, 4, 2, 1024, 1024, 256, "bf16", True, (-1, -1))           # the two-waves-per-key-block kernel has no split form
+    assert _split_bytes(*d256, 0) == _split_bytes(*d256, _lib.FA_FLAG_NO_DKV_SPLIT)

@@ -34,14 +34,18 @@ def test_backward_statistics_workspace(lib):
     p = _dense(lib, 8, 4096, 16, 16, 128)
     assert q(ctypes.byref(p)) == 2 * 8 * 16 * 4096 * 4
     p = _dense(lib, 2, 777, 8, 2, 128)                       # GQA: statistics per q-head
+    p.flags = lib.FA_FLAG_NO_DKV_SPLIT
     assert q(ctypes.byref(p)) == 2 * 2 * 8 * 777 * 4
     p = _dense(lib, 2, 512, 8, 8, 64)                        # other head dims: compiler kernels, no workspace
+    p.flags = lib.FA_FLAG_NO_DKV_SPLIT
     assert q(ctypes.byref(p)) == 0
     p = _dense(lib, 2, 512, 8, 8, 128)
     p.p_dropout = 0.1
+    p.flags = lib.FA_FLAG_NO_DKV_SPLIT
     assert q(ctypes.byref(p)) == 0
     p = _dense(lib, 2, 512, 8, 8, 128)
     p.softcap = 30.0
+    p.flags = lib.FA_FLAG_NO_DKV_SPLIT
     assert q(ctypes.byref(p)) == 0
     # packed sequences: [H][total_q] planes
     p = _dense(lib, 3, 2048, 8, 4, 128)
@@ -49,6 +53,37 @@ def test_backward_statistics_workspace(lib):
     p.cu_seqlens_q = p.cu_seqlens_k = ctypes.addressof(cu)   # (host memory: the query only tests the pointers for NULL)
     p.total_q = p.total_k = 3348
     assert q(ctypes.byref(p)) == 2 * 8 * 3348 * 4
+
+
+def test_backward_split_workspace(lib):
+    """dK/dV launches smaller than the chip (batch x kv-heads x 128-key blocks, causal: mirrored pairs, < 256 CUs x the
+    kernel's workgroups per CU) add fp32 partial dK / dV slabs behind the statistics planes: 2 x splits x B x Sk x Hk x D
+    floats (fa_bwd.hip: dkv_split_factor; without a GPU the CU count defaults to 256)."""
+    q = lib.lib.fa_bwd_workspace_bytes
+    al = lambda x: (x + 255) & ~255
+    # Llama-3 layer at micro-batch 1: 8 kv-heads x 16 mirrored pairs = 128 workgroups of the hand-scheduled kernel -> 2 splits
+    p = _dense(lib, 1, 4096, 32, 8, 128)
+    assert q(ctypes.byref(p)) == al(2 * 32 * 4096 * 4) + 2 * 2 * 4096 * 8 * 128 * 4
+    p.flags = lib.FA_FLAG_NO_DKV_SPLIT
+    assert q(ctypes.byref(p)) == 2 * 32 * 4096 * 4
+    # ... at micro-batch 2 the launch fills the chip
+    p = _dense(lib, 2, 4096, 32, 8, 128)
+    assert q(ctypes.byref(p)) == 2 * 2 * 32 * 4096 * 4
+    # 16 workgroups, 25 stages x 4 q-heads: the most splits (8)
+    p = _dense(lib, 2, 777, 8, 2, 128)
+    assert q(ctypes.byref(p)) == al(2 * 2 * 8 * 777 * 4) + 2 * 8 * 2 * 777 * 2 * 128 * 4
+    # head dim 64: three workgroups per CU, 64-row stages; 2 x 8 x 2 = 32 workgroups, 8 stages each: no split keeps 8 stages
+    p = _dense(lib, 2, 512, 8, 8, 64)
+    assert q(ctypes.byref(p)) == 0
+    p = _dense(lib, 2, 2048, 8, 8, 64)                       # 2 x 8 x 8 pairs = 128 workgroups of 768 slots, 32 stages: 4 splits
+    assert q(ctypes.byref(p)) == 2 * 4 * 2 * 2048 * 8 * 64 * 4
+    # kernels without a split form: dropout with a bias (fa_bwd_dkdv_kernel), head dim 256
+    p = _dense(lib, 1, 2048, 8, 8, 128)
+    p.p_dropout = 0.1
+    p.softcap = 30.0
+    assert q(ctypes.byref(p)) == 0
+    p = _dense(lib, 1, 2048, 8, 8, 256)
+    assert q(ctypes.byref(p)) == 0
 
 
 def _decode(lib, B, H, Hk, L, kv8, num_splits=0):
