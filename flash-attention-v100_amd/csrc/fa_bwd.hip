@@ -1896,7 +1896,9 @@ static int bwd_dkv_split_for(const KArgs& a, bool asm_kernel) {
     const bool cap_only = p.softcap > 0.f && !p.alibi_slopes;
     const int pair = ((p.is_causal || p.window_right >= 0) && p.window_left < 0) ? 1 : 0;     // (fa_api.hip: make_args)
     if (asm_kernel) return p.alibi_slopes ? 1 : dkv_split_factor(p, pair, 1, 32);     // (the ALiBi bodies have no partial epilogue)
-    if (p.head_dim > 128 || a.ds_ws) return 1;
+    if (a.ds_ws) return 1;
+    if (p.head_dim > 128)                                  // two waves per key block (fa_bwd_d256.hip): one workgroup per CU
+        return ((!a.has_bias || cap_only) && !drop) ? dkv_split_factor(p, pair, 1, 32) : 1;
     if (!(!a.has_bias || ((lin_alibi || cap_only) && !drop))) return 1;     // fa_bwd_dkdv_kernel: no split form
     return p.head_dim <= 64 ? dkv_split_factor(p, pair, FA_DKV2_OCC64, 64) : dkv_split_factor(p, pair, 2, 32);
 }
@@ -2011,8 +2013,11 @@ static int launch_bwd_td(const KArgs& a, hipStream_t stream) {
                 if (a.flat_blocks && p.cu_seqlens_k && p.total_k > 0) {
                     a2.flat_kblocks = p.total_k / DKV_BN + p.batch;
                     grid2 = a2.flat_kblocks * p.nheads_k;
+                } else if (a.dkv_split > 1) {
+                    grid2 = grid * a.dkv_split;
                 }
                 launch_bwd_dkdv_split(a2, grid2, stream);         // fa_bwd_d256.hip
+                if (a.dkv_split > 1) launch_dkv_reduce<T>(a, stream);
                 done = true;
             }
         }

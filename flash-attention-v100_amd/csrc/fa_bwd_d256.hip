@@ -52,13 +52,17 @@ __global__ void __launch_bounds__(SPLIT_THREADS, 1) fa_bwd_dkdv_split_kernel(con
     const int n_kb_grid = pair ? (n_kblocks + 1) / 2 : n_kblocks;
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, g = lane >> 5;
     int b, hk, nb0;
+    const int nsplit = a.dkv_split > 1 ? a.dkv_split : 1;    // dense launches smaller than the chip (fa_bwd.hip: dkv_split_factor)
+    int split = 0;
     if (a.flat_kblocks) {
         const int id = blockIdx.x;
         hk = id % p.nheads_k;
         flat_owner(id / p.nheads_k, DKV_BN, p.batch, p.cu_seqlens_k, lane, b, nb0);
         if (b < 0) return;
     } else {
-        const int id = blockIdx.x, xcd = id & 7, j = id >> 3;
+        const int id = blockIdx.x, xcd = id & 7;
+        int j = id >> 3;
+        if (nsplit > 1) { split = j % nsplit; j /= nsplit; }
         const int ul = j / n_kb_grid;
         nb0 = j - ul * n_kb_grid;
         const int unit = ul * 8 + xcd;
@@ -146,8 +150,9 @@ __global__ void __launch_bounds__(SPLIT_THREADS, 1) fa_bwd_dkdv_split_kernel(con
         if (wr >= 0) { const int t = n0 - off - wr; m_lo = t > 0 ? t : 0; }
         if (wl >= 0) { const int t = n_last - off + wl + 1; m_hi = t < m_hi ? t : m_hi; }
     }
-    const int mt0 = m_lo / BQ;
-    const int mt1 = m_hi > m_lo ? (m_hi + BQ - 1) / BQ : mt0;
+    int mt0 = m_lo / BQ;
+    int mt1 = m_hi > m_lo ? (m_hi + BQ - 1) / BQ : mt0;
+    if (nsplit > 1) dkv_split_range(split, nsplit, mt0, mt1);         // this split's share of the pass's query tiles
     const int n_tiles = mt1 - mt0;
     const int n_iter = n_tiles * group;
     const bool empty = qhi < qlo;
@@ -352,6 +357,19 @@ __global__ void __launch_bounds__(SPLIT_THREADS, 1) fa_bwd_dkdv_split_kernel(con
                        (sg.k_row0 + my_key) * (role == 0 ? p.dv_row_stride : p.dk_row_stride) +
                        (int64_t)hk * (role == 0 ? p.dv_head_stride : p.dk_head_stride);
         const float sc = role == 0 ? 1.0f : p.softmax_scale;
+        if (nsplit > 1) {
+            // fp32 partial of this split, [dK | dV][split][B][Sk][Hk][D]: dkv_reduce_kernel adds the splits and rounds once
+            const int64_t row = (int64_t)p.nheads_k * D, slab = (int64_t)p.batch * p.seqlen_k * row;
+            float* pp = reinterpret_cast<float*>(a.dkv_part) + ((role == 0 ? nsplit : 0) + split) * slab +
+                        ((int64_t)b * p.seqlen_k + my_key) * row + (int64_t)hk * D;
+#pragma unroll
+            for (int d = 0; d < DBLKS; ++d)
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq) {
+                    const f32x4 o4 = {acc[d][4 * rq + 0] * sc, acc[d][4 * rq + 1] * sc, acc[d][4 * rq + 2] * sc, acc[d][4 * rq + 3] * sc};
+                    if (d * 32 + 8 * rq + 4 * g < dv) *reinterpret_cast<f32x4*>(pp + d * 32 + 8 * rq + 4 * g) = o4;
+                }
+        } else
 #pragma unroll
         for (int d = 0; d < DBLKS; ++d)
 #pragma unroll

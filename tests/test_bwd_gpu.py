@@ -309,6 +309,8 @@ SPLIT_CASES = [
     (1, 14, 2, 900, 900, 64, "bf16", True, (-1, -1)),       # group of 7 at head dim 64
     (1, 4, 2, 1300, 1300, 128, "bf16", False, (200, 0)),    # left window: passes of different lengths
     (1, 2, 2, 1100, 1500, 64, "fp16", True, (-1, -1)),      # Sq < Sk: key blocks without rows
+    (1, 4, 2, 1024, 1024, 256, "bf16", True, (-1, -1)),     # head dim 256: two waves per key block, each role stores its partial
+    (1, 2, 2, 900, 300, 192, "fp16", False, (-1, -1)),      # ... 192 valid columns
 ]
 
 
@@ -359,5 +361,5 @@ def test_a_full_round_of_dkdv_workgroups_is_not_split():
     from flash_attn_mi355 import _lib
     big = (8, 16, 16, 4096, 4096, 128, "bf16", True, (-1, -1))          # BASELINE config 2: 2048 workgroups
     assert _split_bytes(*big, 0) == _split_bytes(*big, _lib.FA_FLAG_NO_DKV_SPLIT)
-    d256 = (1, 4, 2, 1024, 1024, 256, "bf16", True, (-1, -1))           # the two-waves-per-key-block kernel has no split form
-    assert _split_bytes(*d256, 0) == _split_bytes(*d256, _lib.FA_FLAG_NO_DKV_SPLIT)
+    drop = (1, 4, 2, 1024, 1024, 128, "bf16", True, (-1, -1))
+    assert _split_bytes(*drop, 0) > _split_bytes(*drop, _lib.FA_FLAG_NO_DKV_SPLIT)

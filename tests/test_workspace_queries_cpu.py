@@ -77,12 +77,13 @@ def test_backward_split_workspace(lib):
     assert q(ctypes.byref(p)) == 0
     p = _dense(lib, 2, 2048, 8, 8, 64)                       # 2 x 8 x 8 pairs = 128 workgroups of 768 slots, 32 stages: 4 splits
     assert q(ctypes.byref(p)) == 2 * 4 * 2 * 2048 * 8 * 64 * 4
-    # kernels without a split form: dropout with a bias (fa_bwd_dkdv_kernel), head dim 256
+    # head dim 256 (two waves per key block, one workgroup per CU): 64 workgroups, 64 stages -> 4 splits
+    p = _dense(lib, 1, 2048, 8, 8, 256)
+    assert q(ctypes.byref(p)) == 2 * 4 * 1 * 2048 * 8 * 256 * 4
+    # a kernel without a split form: dropout with a bias (fa_bwd_dkdv_kernel)
     p = _dense(lib, 1, 2048, 8, 8, 128)
     p.p_dropout = 0.1
     p.softcap = 30.0
-    assert q(ctypes.byref(p)) == 0
-    p = _dense(lib, 1, 2048, 8, 8, 256)
     assert q(ctypes.byref(p)) == 0
 
 

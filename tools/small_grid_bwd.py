@@ -1,6 +1,6 @@
 """Backward on shapes whose dK/dV grid (batch x kv-heads x 128-key blocks) is smaller than the chip: GQA at micro-batch 1,
 short-key cross-attention.  Per shape: forward, dK/dV(+preprocess), dQ, full backward (medians of evented calls) and the
-number of dK/dV workgroups the unsplit launch would have.   python tools/small_grid_bwd.py [csv of shape indices]"""
+number of dK/dV workgroups the unsplit launch would have.   python tools/small_grid_bwd.py [csv of shape indices | all] [nosplit]"""
 import os, sys
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, os.path.join(ROOT, "flash-attention-v100_amd")); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
@@ -38,8 +38,14 @@ SHAPES = [
     ("SD-UNet x  B8 Sq1024 Sk77 H8 D80", 8, 1024, 77, 8, 8, 80, False, torch.float16),
     ("T5 cross   B4 Sq512 Sk128 H12 D64", 4, 512, 128, 12, 12, 64, False, torch.float16),
     ("cross      B2 Sq8192 Sk256 H16 D128", 2, 8192, 256, 16, 16, 128, False, torch.bfloat16),
+    ("Gemma-2    B1 S4096 H16/8 D256 causal", 1, 4096, 4096, 16, 8, 256, True, torch.bfloat16),
+    ("Gemma-2    B2 S4096 H16/8 D256 causal", 2, 4096, 4096, 16, 8, 256, True, torch.bfloat16),
 ]
-sel = [int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else range(len(SHAPES))
+sel = [int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 and sys.argv[1] != "all" else range(len(SHAPES))
+if len(sys.argv) > 2 and sys.argv[2] == "nosplit":           # A/B: one workgroup per key block (FA_FLAG_NO_DKV_SPLIT)
+    from flash_attn_mi355 import flash_attn_interface as fi
+    fi.DKV_SPLIT = False
+    print("(FA_FLAG_NO_DKV_SPLIT)")
 for i in sel:
     name, B, Sq, Sk, Hq, Hk, D, causal, dt = SHAPES[i]
     torch.manual_seed(i)
