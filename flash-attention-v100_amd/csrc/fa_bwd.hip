@@ -129,11 +129,10 @@ __global__ void __launch_bounds__(BWD_THREADS, 1) fa_bwd_dkdv_kernel(const KArgs
     const int n_kb_grid = pair ? (n_kblocks + 1) / 2 : n_kblocks;
     int b, hk, nb0;
     {
-        const int id = blockIdx.x, xcd = id & 7, j = id >> 3;
-        const int ul = j / n_kb_grid;
-        nb0 = j - ul * n_kb_grid;
-        const int unit = ul * 8 + xcd;
-        if (unit >= p.batch * p.nheads_k) return;
+        const UnitItem ui = decode_unit_item(blockIdx.x, p.batch * p.nheads_k, n_kb_grid);
+        if (!ui.valid) return;
+        nb0 = ui.item;
+        const int unit = ui.unit;
         b = unit / p.nheads_k; hk = unit - b * p.nheads_k;
     }
     const SeqGeom sg = seq_geom(p, b);
@@ -807,13 +806,12 @@ __global__ void __launch_bounds__(BWD_THREADS, D <= 64 ? FA_DKV2_OCC64 : 2) fa_b
         flat_owner(id / p.nheads_k, DKV_BN, p.batch, p.cu_seqlens_k, lane, b, nb0);
         if (b < 0) return;
     } else {
-        const int id = blockIdx.x, xcd = id & 7;
-        int j = id >> 3;
-        if (nsplit > 1) { split = j % nsplit; j /= nsplit; }       // the splits of a key block: neighbours on one XCD
-        const int ul = j / n_kb_grid;
-        nb0 = j - ul * n_kb_grid;
-        const int unit = ul * 8 + xcd;
-        if (unit >= p.batch * p.nheads_k) return;
+        // (the splits of a key block are neighbours: same XCD, K / V from its L2)
+        const UnitItem ui = decode_unit_item(blockIdx.x, p.batch * p.nheads_k, n_kb_grid * nsplit);
+        if (!ui.valid) return;
+        nb0 = ui.item / nsplit;
+        split = ui.item - nb0 * nsplit;
+        const int unit = ui.unit;
         b = unit / p.nheads_k; hk = unit - b * p.nheads_k;
     }
     const SeqGeom sg = seq_geom(p, b);
@@ -1796,30 +1794,38 @@ int launch_bwd_dkdv_asm(const KArgs& a, hipStream_t stream);
 // block too: kernel/fused_mha_backward.cu:351-474).
 // ---------------------------------------------------------------------------------------------
 constexpr int DKV_SPLIT_MAX = 8;
-constexpr int DKV_SPLIT_MIN_STAGES = 8;                  // query stages x q-heads a split should keep (a pass's prologue ~ 3-4 stages)
+constexpr int DKV_SPLIT_MIN_STAGES = 8;                  // query stages x q-heads a split should keep
 
-// slots_per_cu: workgroups of the kernel a CU holds at once; stage_rows: query rows per stage of that kernel
-static int dkv_split_factor(const fa_params& p, int pair, int slots_per_cu, int stage_rows) {
+// slots_per_cu: workgroups of the kernel a CU holds at once; stage_rows: query rows per stage of that kernel; pass_stages: what a
+// pass costs besides its stages (work item, K / V tiles, first stage's latency, epilogue), in stage times: 9.2 k + 3.4 k cycles
+// against 2.7 k per 64-row stage at D = 64 (phase stamps, profiles/r05_config3_backward.txt section 4) -> 4; the same latencies
+// against a 32-row stage of ~1.3-1.5 k cycles in the D = 128 / 256 kernels -> 8.
+// Model: the workgroups of a dense launch take equal time (mirrored pairs under a causal mask), so the launch takes
+// rounds(workgroups / slots) x (stages / split + passes x pass_stages); the split with the smallest product wins if it beats the
+// unsplit launch by 15 % (the partial slabs and the reduction launch are not in the model).  Launches of many rounds never
+// split: the second factor grows with the split, the first does not shrink.
+static int dkv_split_factor(const fa_params& p, int pair, int slots_per_cu, int stage_rows, int pass_stages) {
     if (p.cu_seqlens_q || p.cu_seqlens_k || p.seqlen_q < 1 || p.seqlen_k < 1 || p.nheads_k < 1) return 1;
     if (p.flags & FA_FLAG_NO_DKV_SPLIT) return 1;
     const int64_t n_kblocks = (p.seqlen_k + DKV_BN - 1) / DKV_BN;
     const bool paired = pair && n_kblocks >= 2;
     const int64_t wgs = (int64_t)p.batch * p.nheads_k * (paired ? (n_kblocks + 1) / 2 : n_kblocks);
     const int64_t slots = (int64_t)fa_device_cu_count() * slots_per_cu;
-    if (wgs < 1 || wgs >= slots) return 1;               // a full round of workgroups: leave it alone
+    if (wgs < 1 || wgs >= 4 * slots) return 1;
     // stages of a workgroup (a causal pair walks about one full sequence in its two passes)
     const int64_t stages = (int64_t)((p.seqlen_q + stage_rows - 1) / stage_rows) * (p.nheads_q / p.nheads_k);
-    int best = 1;
-    double best_cost = 1e30;
-    for (int s = 1; s <= DKV_SPLIT_MAX; ++s) {
-        if (s > 1 && stages / s < DKV_SPLIT_MIN_STAGES) break;
-        // rounds of workgroups x the length of one, + 4 % per extra split for the repeated K / V prologue and the partials
-        const double cost = (double)((wgs * s + slots - 1) / slots) / s * (1.0 + 0.04 * (s - 1));
-        if (cost < best_cost - 1e-9) { best_cost = cost; best = s; }
-    }
+    const int64_t fixed = (int64_t)pass_stages * (paired ? 2 : 1);
     // the partial slabs are addressed like dk / dv: 31-bit byte offsets inside one (batch) slice
     if ((int64_t)(p.seqlen_k + DKV_BN) * p.nheads_k * p.head_dim * 4 >= ((int64_t)1 << 31)) return 1;
-    return best;
+    int best = 1;
+    double best_cost = 0.0, cost1 = 0.0;
+    for (int s = 1; s <= DKV_SPLIT_MAX; ++s) {
+        if (s > 1 && stages / s < DKV_SPLIT_MIN_STAGES) break;
+        const double cost = (double)((wgs * s + slots - 1) / slots) * ((double)stages / s + (double)fixed);
+        if (s == 1) { cost1 = best_cost = cost; continue; }
+        if (cost < best_cost - 1e-9) { best_cost = cost; best = s; }
+    }
+    return best_cost <= 0.85 * cost1 ? best : 1;
 }
 static size_t dkv_split_bytes(const fa_params& p, int split) {
     return split > 1 ? (size_t)2 * split * p.batch * p.seqlen_k * p.nheads_k * p.head_dim * sizeof(float) : 0;
@@ -1895,12 +1901,12 @@ static int bwd_dkv_split_for(const KArgs& a, bool asm_kernel) {
     const bool lin_alibi = p.alibi_slopes && p.softcap <= 0.f && (p.is_causal || p.window_right == 0);
     const bool cap_only = p.softcap > 0.f && !p.alibi_slopes;
     const int pair = ((p.is_causal || p.window_right >= 0) && p.window_left < 0) ? 1 : 0;     // (fa_api.hip: make_args)
-    if (asm_kernel) return p.alibi_slopes ? 1 : dkv_split_factor(p, pair, 1, 32);     // (the ALiBi bodies have no partial epilogue)
+    if (asm_kernel) return p.alibi_slopes ? 1 : dkv_split_factor(p, pair, 1, 32, 8);     // (the ALiBi bodies have no partial epilogue)
     if (a.ds_ws) return 1;
     if (p.head_dim > 128)                                  // two waves per key block (fa_bwd_d256.hip): one workgroup per CU
-        return ((!a.has_bias || cap_only) && !drop) ? dkv_split_factor(p, pair, 1, 32) : 1;
+        return ((!a.has_bias || cap_only) && !drop) ? dkv_split_factor(p, pair, 1, 32, 8) : 1;
     if (!(!a.has_bias || ((lin_alibi || cap_only) && !drop))) return 1;     // fa_bwd_dkdv_kernel: no split form
-    return p.head_dim <= 64 ? dkv_split_factor(p, pair, FA_DKV2_OCC64, 64) : dkv_split_factor(p, pair, 2, 32);
+    return p.head_dim <= 64 ? dkv_split_factor(p, pair, FA_DKV2_OCC64, 64, 4) : dkv_split_factor(p, pair, 2, 32, 8);
 }
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 size_t bwd_workspace_bytes(const fa_params& p) {
@@ -1948,7 +1954,7 @@ static int launch_bwd_td(const KArgs& a, hipStream_t stream) {
         const int n_kblocks = (p.seqlen_k + DKV_BN - 1) / DKV_BN;
         const int n_kb_grid = (a.pair_qblocks && n_kblocks >= 2) ? (n_kblocks + 1) / 2 : n_kblocks;
         const int units = p.batch * p.nheads_k;
-        const int grid = 8 * ((units + 7) / 8) * n_kb_grid;
+        const int grid = unit_grid(units, n_kb_grid);
         const size_t smem = DkvSmem<D>::TOTAL;
 #define FA_LAUNCH_DKV(BIAS, DROP)                                                                                 \
         do {                                                                                                      \
@@ -1981,7 +1987,7 @@ static int launch_bwd_td(const KArgs& a, hipStream_t stream) {
                     a2.flat_kblocks = p.total_k / DKV_BN + p.batch;
                     grid2 = a2.flat_kblocks * p.nheads_k;
                 } else if (a.dkv_split > 1) {
-                    grid2 = grid * a.dkv_split;           // the query tiles of a pass over dkv_split workgroups (dkv_split_factor)
+                    grid2 = unit_grid(units, n_kb_grid * a.dkv_split);   // the query tiles of a pass over dkv_split workgroups (dkv_split_factor)
                 }
 #define FA_LAUNCH_DKV2(BIAS, DROP)                                                                                \
                 do {                                                                                              \
@@ -2014,7 +2020,7 @@ static int launch_bwd_td(const KArgs& a, hipStream_t stream) {
                     a2.flat_kblocks = p.total_k / DKV_BN + p.batch;
                     grid2 = a2.flat_kblocks * p.nheads_k;
                 } else if (a.dkv_split > 1) {
-                    grid2 = grid * a.dkv_split;
+                    grid2 = unit_grid(units, n_kb_grid * a.dkv_split);
                 }
                 launch_bwd_dkdv_split(a2, grid2, stream);         // fa_bwd_d256.hip
                 if (a.dkv_split > 1) launch_dkv_reduce<T>(a, stream);

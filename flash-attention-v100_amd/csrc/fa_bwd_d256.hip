@@ -60,13 +60,12 @@ __global__ void __launch_bounds__(SPLIT_THREADS, 1) fa_bwd_dkdv_split_kernel(con
         flat_owner(id / p.nheads_k, DKV_BN, p.batch, p.cu_seqlens_k, lane, b, nb0);
         if (b < 0) return;
     } else {
-        const int id = blockIdx.x, xcd = id & 7;
-        int j = id >> 3;
-        if (nsplit > 1) { split = j % nsplit; j /= nsplit; }
-        const int ul = j / n_kb_grid;
-        nb0 = j - ul * n_kb_grid;
-        const int unit = ul * 8 + xcd;
-        if (unit >= p.batch * p.nheads_k) return;
+        // (the splits of a key block are neighbours: same XCD, K / V from its L2)
+        const UnitItem ui = decode_unit_item(blockIdx.x, p.batch * p.nheads_k, n_kb_grid * nsplit);
+        if (!ui.valid) return;
+        nb0 = ui.item / nsplit;
+        split = ui.item - nb0 * nsplit;
+        const int unit = ui.unit;
         b = unit / p.nheads_k; hk = unit - b * p.nheads_k;
     }
     const SeqGeom sg = seq_geom(p, b);

@@ -276,27 +276,50 @@ __device__ __forceinline__ bool dropout_keep1(const DropCtx& dc, uint64_t flat) 
     return v <= dc.thr;
 }
 
-// Work decomposition shared by forward-like kernels: 1-D grid, block id -> XCD-aware
-// (kv-head unit, q-head in group, q-block heavy-first).  Blocks observed to land on XCD
-// id % 8 (speed only, never correctness): all q-blocks of the q-heads sharing a kv-head
-// run on one XCD so K/V stay in that XCD's L2.
+// Work decomposition shared by all dense kernels: 1-D grid, block id -> XCD-aware.  A "unit" is one (batch, kv-head): its
+// K / V (forward, dQ) or Q / dO stream (dK/dV) is shared by its `per_unit` items (q-blocks x q-heads of the group; key blocks x
+// splits), and blocks are observed to land on XCD id % 8 (speed only, never correctness) - so unit u of a round of eight goes to
+// XCD u % 8 and its items stay in that XCD's L2.  Units past the last full round of eight (batch x kv-heads = 1 for a
+// tensor-parallel shard of a GQA model, 2-4 for MQA / Qwen2-style models at small batch) would leave XCDs empty that way:
+// their items are laid end to end instead and cut into eight equal runs, one per XCD (an XCD then serves one or two units).
+struct UnitItem { int unit, item; bool valid; };
+__host__ __device__ __forceinline__ int unit_grid(int units, int per_unit) {
+    const int full8 = units & ~7, tail = units - full8;
+    return full8 * per_unit + (tail ? 8 * (int)(((int64_t)tail * per_unit + 7) / 8) : 0);
+}
+__device__ __forceinline__ UnitItem decode_unit_item(int id, int units, int per_unit) {
+    UnitItem w;
+    const int full8 = units & ~7;
+    const int head_ids = full8 * per_unit;
+    if (id < head_ids) {
+        const int xcd = id & 7, j = id >> 3;
+        const int ul = j / per_unit;
+        w.item = j - ul * per_unit;
+        w.unit = ul * 8 + xcd;
+        w.valid = true;
+    } else {
+        const int tail_items = (units - full8) * per_unit;
+        const int chunk = (tail_items + 7) >> 3;
+        const int id2 = id - head_ids;
+        const int lin = (id2 & 7) * chunk + (id2 >> 3);
+        w.valid = (id2 >> 3) < chunk && lin < tail_items;
+        const int u = lin / per_unit;
+        w.item = lin - u * per_unit;
+        w.unit = full8 + u;
+    }
+    return w;
+}
 struct WorkItem { int b, h, hk, qb; bool valid; };
 __device__ __forceinline__ WorkItem decode_work(int id, int batch, int nheads_q, int nheads_k,
                                                 int n_qblocks) {
     WorkItem w;
     const int group = nheads_q / nheads_k;
-    const int units = batch * nheads_k;
-    const int xcd = id & 7;
-    const int j = id >> 3;
-    const int per_unit = group * n_qblocks;
-    const int ul = j / per_unit;
-    const int rem = j - ul * per_unit;
-    const int gq = rem / n_qblocks;
-    const int unit = ul * 8 + xcd;
-    w.valid = unit < units;
-    w.qb = n_qblocks - 1 - (rem - gq * n_qblocks);
-    w.b = unit / nheads_k;
-    w.hk = unit - w.b * nheads_k;
+    const UnitItem ui = decode_unit_item(id, batch * nheads_k, group * n_qblocks);
+    const int gq = ui.item / n_qblocks;
+    w.valid = ui.valid;
+    w.qb = n_qblocks - 1 - (ui.item - gq * n_qblocks);
+    w.b = ui.unit / nheads_k;
+    w.hk = ui.unit - w.b * nheads_k;
     w.h = w.hk * group + gq;
     return w;
 }
@@ -330,9 +353,7 @@ __device__ __forceinline__ WorkItem decode_work_flat(int id, int flat_blocks, in
     return w;
 }
 static inline int work_grid(int batch, int nheads_q, int nheads_k, int n_qblocks) {
-    const int units = batch * nheads_k;
-    const int upx = (units + 7) / 8;
-    return 8 * upx * (nheads_q / nheads_k) * n_qblocks;
+    return unit_grid(batch * nheads_k, (nheads_q / nheads_k) * n_qblocks);
 }
 
 // 16 x fp8-e4m3 -> 16 x 16-bit with gfx950's packed converts: one VALU op per TWO elements

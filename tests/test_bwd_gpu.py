@@ -363,3 +363,24 @@ def test_a_full_round_of_dkdv_workgroups_is_not_split():
     assert _split_bytes(*big, 0) == _split_bytes(*big, _lib.FA_FLAG_NO_DKV_SPLIT)
     drop = (1, 4, 2, 1024, 1024, 128, "bf16", True, (-1, -1))
     assert _split_bytes(*drop, 0) > _split_bytes(*drop, _lib.FA_FLAG_NO_DKV_SPLIT)
+
+
+@pytest.mark.parametrize("B,Hq,Hk", [(1, 4, 1), (1, 6, 3), (1, 5, 5), (3, 6, 3), (1, 11, 11), (2, 12, 6), (1, 26, 13)])
+@pytest.mark.parametrize("D,dt,causal", [(128, "bf16", True), (64, "fp16", False)])
+def test_units_that_do_not_fill_a_round_of_xcds(B, Hq, Hk, D, dt, causal):
+    """batch x kv-heads = 1, 3, 5, 9, 11, 12, 13: the units past the last full round of eight are laid end to end and cut into
+    eight runs (fa_common.h: decode_unit_item) in the forward, dQ and dK/dV grids - every (unit, item) exactly once."""
+    S = 600
+    q = rand16((B, S, Hq, D), dt, 31).requires_grad_(True)
+    k = rand16((B, S, Hk, D), dt, 32).requires_grad_(True)
+    v = rand16((B, S, Hk, D), dt, 33).requires_grad_(True)
+    do = rand16((B, S, Hq, D), dt, 34)
+    out = _fa().flash_attn_func(q, k, v, causal=causal)
+    dq, dk, dv = torch.autograd.grad(out, (q, k, v), do)
+    t = lambda x: f64(x).transpose(0, 2, 1, 3)
+    o_ref, lse_ref, _ = oracle.attn_fwd(t(q), t(k), t(v), D ** -0.5, causal=causal)
+    g = oracle.attn_bwd(t(do), t(q), t(k), t(v), o_ref, lse_ref.astype(np.float64), D ** -0.5, causal=causal)
+    assert_close(t(out), o_ref, dt, "out")
+    assert_close(t(dq), g[0], dt, "dq", mult=2.0)
+    assert_close(t(dk), g[1], dt, "dk", mult=2.0)
+    assert_close(t(dv), g[2], dt, "dv", mult=2.0)

@@ -29,6 +29,7 @@ SHAPES = [
     ("Llama3-8B  B1 S2048 H32/8 D128 causal", 1, 2048, 2048, 32, 8, 128, True, torch.bfloat16),
     ("Llama3-8B  B1 S8192 H32/8 D128 causal", 1, 8192, 8192, 32, 8, 128, True, torch.bfloat16),
     ("Llama3-8B  B2 S4096 H32/8 D128 causal", 2, 4096, 4096, 32, 8, 128, True, torch.bfloat16),
+    ("Llama3-8B  B3 S4096 H32/8 D128 causal", 3, 4096, 4096, 32, 8, 128, True, torch.bfloat16),
     ("MHA        B1 S4096 H8 D128 causal", 1, 4096, 4096, 8, 8, 128, True, torch.bfloat16),
     ("MQA        B4 S4096 H32/1 D128 causal", 4, 4096, 4096, 32, 1, 128, True, torch.bfloat16),
     ("Qwen2-0.5B B2 S4096 H14/2 D64 causal", 2, 4096, 4096, 14, 2, 64, True, torch.bfloat16),
@@ -38,6 +39,12 @@ SHAPES = [
     ("SD-UNet x  B8 Sq1024 Sk77 H8 D80", 8, 1024, 77, 8, 8, 80, False, torch.float16),
     ("T5 cross   B4 Sq512 Sk128 H12 D64", 4, 512, 128, 12, 12, 64, False, torch.float16),
     ("cross      B2 Sq8192 Sk256 H16 D128", 2, 8192, 256, 16, 16, 128, False, torch.bfloat16),
+    # batch x kv-heads not a multiple of the 8 XCDs (the last round of units is spread over all of them)
+    ("70B / TP8  B1 S8192 H8/1 D128 causal", 1, 8192, 8192, 8, 1, 128, True, torch.bfloat16),
+    ("70B / TP8  B2 S4096 H8/1 D128 causal", 2, 4096, 4096, 8, 1, 128, True, torch.bfloat16),
+    ("Qwen2.5-7B B1 S4096 H28/4 D128 causal", 1, 4096, 4096, 28, 4, 128, True, torch.bfloat16),
+    ("GQA        B3 S4096 H16/4 D128 causal", 3, 4096, 4096, 16, 4, 128, True, torch.bfloat16),
+    ("MHA        B1 S2048 H12 D64", 1, 2048, 2048, 12, 12, 64, False, torch.float16),
     ("Gemma-2    B1 S4096 H16/8 D256 causal", 1, 4096, 4096, 16, 8, 256, True, torch.bfloat16),
     ("Gemma-2    B2 S4096 H16/8 D256 causal", 2, 4096, 4096, 16, 8, 256, True, torch.bfloat16),
 ]
