@@ -772,7 +772,9 @@ template <int D> struct Dkv2Smem {
 #define FA_DKV2_PF 3                                    // transposed dO / Q fragments in flight ahead of their MFMA
 #endif
 // DV: columns that can be non-zero (D = 128 only: head dims 65 .. 96 skip the k-steps and accumulator blocks of the zero columns)
-template <typename T, int D, int BIAS, bool DROPOUT, int DV = D>
+// PART: the launch is a split one (dkv_split_factor): this workgroup walks a share of each pass's query tiles and leaves an fp32
+//       partial dK / dV (its own instantiation - the unsplit kernel keeps its registers: one more live value costs a spill at D = 64)
+template <typename T, int D, int BIAS, bool DROPOUT, int DV = D, bool PART = false>
 __global__ void __launch_bounds__(BWD_THREADS, D <= 64 ? FA_DKV2_OCC64 : 2) fa_bwd_dkdv2_kernel(const KArgs a) {
     using E = Elem<T>;
     static_assert(DV == D || (D == 128 && DV == 96), "narrow form: 96 of 128 columns");
@@ -797,7 +799,7 @@ __global__ void __launch_bounds__(BWD_THREADS, D <= 64 ? FA_DKV2_OCC64 : 2) fa_b
     const int n_kb_grid = pair ? (n_kblocks + 1) / 2 : n_kblocks;
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, g = lane >> 5;
     int b, hk, nb0;
-    const int nsplit = a.dkv_split > 1 ? a.dkv_split : 1;    // dense launches only (dkv_split_factor)
+    const int nsplit = PART ? a.dkv_split : 1;               // dense launches only (dkv_split_factor)
     int split = 0;
     if (a.flat_kblocks) {
         // varlen flat work list over key blocks (fa_common.h: flat_owner), early (for causal masks: heavy) blocks first
@@ -912,7 +914,7 @@ __global__ void __launch_bounds__(BWD_THREADS, D <= 64 ? FA_DKV2_OCC64 : 2) fa_b
     }
     int mt0 = m_lo / BQ;
     int mt1 = m_hi > m_lo ? (m_hi + BQ - 1) / BQ : mt0;
-    if (nsplit > 1) dkv_split_range(split, nsplit, mt0, mt1);         // this split's share of the pass's query tiles
+    if (PART) dkv_split_range(split, nsplit, mt0, mt1);               // this split's share of the pass's query tiles
     const int n_tiles = mt1 - mt0;
     const int n_iter = n_tiles * group;
     // the mask of a sub-tile as two lane constants (see fa_fwd.hip): masked <=> (cpos - lo_t) >u width, lo_t = lo_l - q0
@@ -1177,7 +1179,7 @@ __global__ void __launch_bounds__(BWD_THREADS, D <= 64 ? FA_DKV2_OCC64 : 2) fa_b
         const int64_t dvb = p.cu_seqlens_k ? 0 : (int64_t)b * p.dv_batch_stride;
         uint16_t* dkp = reinterpret_cast<uint16_t*>(p.dk) + dkb + (sg.k_row0 + my_key) * p.dk_row_stride + (int64_t)hk * p.dk_head_stride;
         uint16_t* dvp = reinterpret_cast<uint16_t*>(p.dv) + dvb + (sg.k_row0 + my_key) * p.dv_row_stride + (int64_t)hk * p.dv_head_stride;
-        if (nsplit > 1) {
+        if (PART) {
             // partial dK / dV of this split, fp32 [dK | dV][split][B][Sk][Hk][D]: the accumulators as they are (dK scaled, dV
             // with the dropout factor) - dkv_reduce_kernel adds the splits and rounds once
             const int64_t row = (int64_t)p.nheads_k * D, slab = (int64_t)p.batch * p.seqlen_k * row;
@@ -1905,7 +1907,7 @@ static int bwd_dkv_split_for(const KArgs& a, bool asm_kernel) {
     if (a.ds_ws) return 1;
     if (p.head_dim > 128)                                  // two waves per key block (fa_bwd_d256.hip): one workgroup per CU
         return ((!a.has_bias || cap_only) && !drop) ? dkv_split_factor(p, pair, 1, 32, 8) : 1;
-    if (!(!a.has_bias || ((lin_alibi || cap_only) && !drop))) return 1;     // fa_bwd_dkdv_kernel: no split form
+    if (a.has_bias || drop) return 1;                      // the split (PART) instantiations: the plain scores
     return p.head_dim <= 64 ? dkv_split_factor(p, pair, FA_DKV2_OCC64, 64, 4) : dkv_split_factor(p, pair, 2, 32, 8);
 }
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -1991,7 +1993,17 @@ static int launch_bwd_td(const KArgs& a, hipStream_t stream) {
                 }
 #define FA_LAUNCH_DKV2(BIAS, DROP)                                                                                \
                 do {                                                                                              \
-                    if (D == 128 && valid_cols(p) <= 96) {                                                        \
+                    if (BIAS == 0 && !(DROP) && a.dkv_split > 1) {         /* split launch: the PART instantiations */ \
+                        if (D == 128 && valid_cols(p) <= 96) {                                                    \
+                            auto kern = fa_bwd_dkdv2_kernel<T, D, 0, false, (D == 128 ? 96 : D), true>;           \
+                            FA_SET_LDS_ONCE(kern, smem2);                                                         \
+                            hipLaunchKernelGGL(kern, dim3(grid2), dim3(BWD_THREADS), smem2, stream, a2);          \
+                        } else {                                                                                  \
+                            auto kern = fa_bwd_dkdv2_kernel<T, D, 0, false, D, true>;                             \
+                            FA_SET_LDS_ONCE(kern, smem2);                                                         \
+                            hipLaunchKernelGGL(kern, dim3(grid2), dim3(BWD_THREADS), smem2, stream, a2);          \
+                        }                                                                                         \
+                    } else if (D == 128 && valid_cols(p) <= 96) {                                                 \
                         auto kern = fa_bwd_dkdv2_kernel<T, D, BIAS, DROP, (D == 128 ? 96 : D)>;                   \
                         FA_SET_LDS_ONCE(kern, smem2);                                                             \
                         hipLaunchKernelGGL(kern, dim3(grid2), dim3(BWD_THREADS), smem2, stream, a2);              \

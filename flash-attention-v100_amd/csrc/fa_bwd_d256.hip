@@ -29,7 +29,9 @@ constexpr int SPLIT_THREADS = 512;
 // zeros - but skip the k-steps and the accumulator blocks that would only see them: 24 MFMAs per wave and sub-tile instead of 32)
 // CAP: softcap without ALiBi (Gemma-2's head dim 256 form): the scores pass through cap tanh(s scale / cap) - only the P wave changes:
 //      it keeps P for its dV and hands P (1 - tanh^2) to the dS wave (the chain-rule factor belongs to dS alone)
-template <typename T, int D, int DV, bool CAP = false>
+// PART: a launch smaller than the chip (fa_bwd.hip: dkv_split_factor): the workgroup walks a share of each pass's query tiles and
+//       leaves an fp32 partial (its own instantiation: the full launch keeps its 9 spilled registers, this one has 13)
+template <typename T, int D, int DV, bool CAP = false, bool PART = false>
 __global__ void __launch_bounds__(SPLIT_THREADS, 1) fa_bwd_dkdv_split_kernel(const KArgs a) {
     using E = Elem<T>;
     static_assert(D == 256 && (DV == 256 || DV == 192), "two waves per key block: the D = 256 form");
@@ -52,7 +54,7 @@ __global__ void __launch_bounds__(SPLIT_THREADS, 1) fa_bwd_dkdv_split_kernel(con
     const int n_kb_grid = pair ? (n_kblocks + 1) / 2 : n_kblocks;
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, g = lane >> 5;
     int b, hk, nb0;
-    const int nsplit = a.dkv_split > 1 ? a.dkv_split : 1;    // dense launches smaller than the chip (fa_bwd.hip: dkv_split_factor)
+    const int nsplit = PART ? a.dkv_split : 1;               // dense launches smaller than the chip (fa_bwd.hip: dkv_split_factor)
     int split = 0;
     if (a.flat_kblocks) {
         const int id = blockIdx.x;
@@ -151,7 +153,7 @@ __global__ void __launch_bounds__(SPLIT_THREADS, 1) fa_bwd_dkdv_split_kernel(con
     }
     int mt0 = m_lo / BQ;
     int mt1 = m_hi > m_lo ? (m_hi + BQ - 1) / BQ : mt0;
-    if (nsplit > 1) dkv_split_range(split, nsplit, mt0, mt1);         // this split's share of the pass's query tiles
+    if (PART) dkv_split_range(split, nsplit, mt0, mt1);               // this split's share of the pass's query tiles
     const int n_tiles = mt1 - mt0;
     const int n_iter = n_tiles * group;
     const bool empty = qhi < qlo;
@@ -356,7 +358,7 @@ __global__ void __launch_bounds__(SPLIT_THREADS, 1) fa_bwd_dkdv_split_kernel(con
                        (sg.k_row0 + my_key) * (role == 0 ? p.dv_row_stride : p.dk_row_stride) +
                        (int64_t)hk * (role == 0 ? p.dv_head_stride : p.dk_head_stride);
         const float sc = role == 0 ? 1.0f : p.softmax_scale;
-        if (nsplit > 1) {
+        if (PART) {
             // fp32 partial of this split, [dK | dV][split][B][Sk][Hk][D]: dkv_reduce_kernel adds the splits and rounds once
             const int64_t row = (int64_t)p.nheads_k * D, slab = (int64_t)p.batch * p.seqlen_k * row;
             float* pp = reinterpret_cast<float*>(a.dkv_part) + ((role == 0 ? nsplit : 0) + split) * slab +
@@ -389,9 +391,15 @@ static int launch_split_t(const KArgs& a, int grid, hipStream_t stream) {
     const size_t smem = DkvSplitSmem<D>::TOTAL;
 #define FA_LAUNCH_SPLIT(DV_, CAP_)                                                              \
     do {                                                                                        \
-        auto kern = fa_bwd_dkdv_split_kernel<T, D, DV_, CAP_>;                                  \
-        FA_SET_LDS_ONCE(kern, smem);                                                            \
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(SPLIT_THREADS), smem, stream, a);             \
+        if (a.dkv_split > 1) {                                                                  \
+            auto kern = fa_bwd_dkdv_split_kernel<T, D, DV_, CAP_, true>;                        \
+            FA_SET_LDS_ONCE(kern, smem);                                                        \
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(SPLIT_THREADS), smem, stream, a);         \
+        } else {                                                                                \
+            auto kern = fa_bwd_dkdv_split_kernel<T, D, DV_, CAP_>;                              \
+            FA_SET_LDS_ONCE(kern, smem);                                                        \
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(SPLIT_THREADS), smem, stream, a);         \
+        }                                                                                       \
     } while (0)
     const bool cap = a.p.softcap > 0.f;
     if (valid_cols(a.p) <= 192) { if (cap) FA_LAUNCH_SPLIT(192, true); else FA_LAUNCH_SPLIT(192, false); }

@@ -281,7 +281,8 @@ __device__ __forceinline__ bool dropout_keep1(const DropCtx& dc, uint64_t flat) 
 // splits), and blocks are observed to land on XCD id % 8 (speed only, never correctness) - so unit u of a round of eight goes to
 // XCD u % 8 and its items stay in that XCD's L2.  Units past the last full round of eight (batch x kv-heads = 1 for a
 // tensor-parallel shard of a GQA model, 2-4 for MQA / Qwen2-style models at small batch) would leave XCDs empty that way:
-// their items are laid end to end instead and cut into eight equal runs, one per XCD (an XCD then serves one or two units).
+// their items are laid end to end instead and cut into eight runs whose lengths differ by at most one, one per XCD (an XCD then
+// serves one or two units).
 struct UnitItem { int unit, item; bool valid; };
 __host__ __device__ __forceinline__ int unit_grid(int units, int per_unit) {
     const int full8 = units & ~7, tail = units - full8;
@@ -299,10 +300,10 @@ __device__ __forceinline__ UnitItem decode_unit_item(int id, int units, int per_
         w.valid = true;
     } else {
         const int tail_items = (units - full8) * per_unit;
-        const int chunk = (tail_items + 7) >> 3;
-        const int id2 = id - head_ids;
-        const int lin = (id2 & 7) * chunk + (id2 >> 3);
-        w.valid = (id2 >> 3) < chunk && lin < tail_items;
+        const int id2 = id - head_ids, x = id2 & 7;
+        const int lo = (int)(((int64_t)tail_items * x) >> 3), hi = (int)(((int64_t)tail_items * (x + 1)) >> 3);   // XCD x: items [lo, hi)
+        const int lin = lo + (id2 >> 3);
+        w.valid = lin < hi;
         const int u = lin / per_unit;
         w.item = lin - u * per_unit;
         w.unit = full8 + u;
