@@ -210,8 +210,8 @@ size_t fa_fwd_workspace_bytes(const fa_params* p) {
 size_t fa_bwd_workspace_bytes(const fa_params* pp) {
     if (!pp) return 0;
     fa_params p = *pp;
-    // dense calls: the flags as fa_bwd will see them (the split of small dK/dV launches depends on the mask's shape)
-    if (!p.cu_seqlens_q && !p.cu_seqlens_k && p.seqlen_q > 0 && p.seqlen_k > 0) normalize(p, false);
+    // the flags as fa_bwd / fa_varlen_bwd will see them (the split of small dK/dV launches depends on the mask's shape)
+    if (p.seqlen_q > 0 && p.seqlen_k > 0) normalize(p, false);
     return fa::bwd_workspace_bytes(p);
 }
 size_t fa_fwd_kvcache_workspace_bytes(const fa_params* pp) {

@@ -803,7 +803,8 @@ __global__ void __launch_bounds__(BWD_THREADS, D <= 64 ? FA_DKV2_OCC64 : 2) fa_b
     int split = 0;
     if (a.flat_kblocks) {
         // varlen flat work list over key blocks (fa_common.h: flat_owner), early (for causal masks: heavy) blocks first
-        const int id = blockIdx.x;
+        int id = blockIdx.x;
+        if (PART) { split = id % nsplit; id /= nsplit; }
         hk = id % p.nheads_k;
         flat_owner(id / p.nheads_k, DKV_BN, p.batch, p.cu_seqlens_k, lane, b, nb0);
         if (b < 0) return;
@@ -1182,8 +1183,10 @@ __global__ void __launch_bounds__(BWD_THREADS, D <= 64 ? FA_DKV2_OCC64 : 2) fa_b
         if (PART) {
             // partial dK / dV of this split, fp32 [dK | dV][split][B][Sk][Hk][D]: the accumulators as they are (dK scaled, dV
             // with the dropout factor) - dkv_reduce_kernel adds the splits and rounds once
-            const int64_t row = (int64_t)p.nheads_k * D, slab = (int64_t)p.batch * p.seqlen_k * row;
-            float* pk = reinterpret_cast<float*>(a.dkv_part) + split * slab + ((int64_t)b * p.seqlen_k + my_key) * row + (int64_t)hk * D;
+            const int64_t row = (int64_t)p.nheads_k * D;
+            const int64_t slab = (p.cu_seqlens_k ? (int64_t)p.total_k : (int64_t)p.batch * p.seqlen_k) * row;
+            const int64_t krow = p.cu_seqlens_k ? sg.k_row0 + my_key : (int64_t)b * p.seqlen_k + my_key;
+            float* pk = reinterpret_cast<float*>(a.dkv_part) + split * slab + krow * row + (int64_t)hk * D;
             float* pv = pk + nsplit * slab;
             const float sc = p.softmax_scale, rp = DROPOUT ? a.rp_dropout : 1.0f;
 #pragma unroll
@@ -1806,19 +1809,30 @@ constexpr int DKV_SPLIT_MIN_STAGES = 8;                  // query stages x q-hea
 // rounds(workgroups / slots) x (stages / split + passes x pass_stages); the split with the smallest product wins if it beats the
 // unsplit launch by 15 % (the partial slabs and the reduction launch are not in the model).  Launches of many rounds never
 // split: the second factor grows with the split, the first does not shrink.
+// Packed sequences (flat list of key blocks, no mirrored pairs: the host does not see the lengths): the same model on the AVERAGE
+// pass - total_k / 128 + batch key blocks per kv-head, total_q / batch rows per sequence, half of them under a causal-like mask.
 static int dkv_split_factor(const fa_params& p, int pair, int slots_per_cu, int stage_rows, int pass_stages) {
-    if (p.cu_seqlens_q || p.cu_seqlens_k || p.seqlen_q < 1 || p.seqlen_k < 1 || p.nheads_k < 1) return 1;
+    if (p.seqlen_q < 1 || p.seqlen_k < 1 || p.nheads_k < 1 || p.batch < 1) return 1;
     if (p.flags & FA_FLAG_NO_DKV_SPLIT) return 1;
+    const bool varlen = p.cu_seqlens_q || p.cu_seqlens_k;
+    if (varlen && (!p.cu_seqlens_q || !p.cu_seqlens_k || p.total_q < 1 || p.total_k < 1)) return 1;
     const int64_t n_kblocks = (p.seqlen_k + DKV_BN - 1) / DKV_BN;
-    const bool paired = pair && n_kblocks >= 2;
-    const int64_t wgs = (int64_t)p.batch * p.nheads_k * (paired ? (n_kblocks + 1) / 2 : n_kblocks);
+    const bool paired = !varlen && pair && n_kblocks >= 2;
+    const int64_t wgs = varlen ? ((int64_t)p.total_k / DKV_BN + p.batch) * p.nheads_k
+                               : (int64_t)p.batch * p.nheads_k * (paired ? (n_kblocks + 1) / 2 : n_kblocks);
     const int64_t slots = (int64_t)fa_device_cu_count() * slots_per_cu;
     if (wgs < 1 || wgs >= 4 * slots) return 1;
     // stages of a workgroup (a causal pair walks about one full sequence in its two passes)
-    const int64_t stages = (int64_t)((p.seqlen_q + stage_rows - 1) / stage_rows) * (p.nheads_q / p.nheads_k);
+    int64_t stages = (int64_t)((p.seqlen_q + stage_rows - 1) / stage_rows) * (p.nheads_q / p.nheads_k);
+    if (varlen) {
+        const int64_t avg_q = (p.total_q + p.batch - 1) / p.batch;
+        stages = ((avg_q + stage_rows - 1) / stage_rows) * (p.nheads_q / p.nheads_k);
+        if (pair) stages = (stages + 1) / 2;
+    }
     const int64_t fixed = (int64_t)pass_stages * (paired ? 2 : 1);
     // the partial slabs are addressed like dk / dv: 31-bit byte offsets inside one (batch) slice
-    if ((int64_t)(p.seqlen_k + DKV_BN) * p.nheads_k * p.head_dim * 4 >= ((int64_t)1 << 31)) return 1;
+    const int64_t slice_rows = varlen ? (int64_t)p.total_k : (int64_t)p.seqlen_k;
+    if ((slice_rows + DKV_BN) * p.nheads_k * p.head_dim * 4 >= ((int64_t)1 << 31)) return 1;
     int best = 1;
     double best_cost = 0.0, cost1 = 0.0;
     for (int s = 1; s <= DKV_SPLIT_MAX; ++s) {
@@ -1830,7 +1844,8 @@ static int dkv_split_factor(const fa_params& p, int pair, int slots_per_cu, int 
     return best_cost <= 0.85 * cost1 ? best : 1;
 }
 static size_t dkv_split_bytes(const fa_params& p, int split) {
-    return split > 1 ? (size_t)2 * split * p.batch * p.seqlen_k * p.nheads_k * p.head_dim * sizeof(float) : 0;
+    const size_t rows = p.cu_seqlens_k ? (size_t)p.total_k : (size_t)p.batch * p.seqlen_k;
+    return split > 1 ? (size_t)2 * split * rows * p.nheads_k * p.head_dim * sizeof(float) : 0;
 }
 
 // dk[b, key, hk, :] = sum over the splits of the fp32 partial rows (split order), rounded once; the same for dv; 8 columns per thread
@@ -1839,11 +1854,14 @@ __global__ void __launch_bounds__(256) dkv_reduce_kernel(const KArgs a) {
     using E = Elem<T>;
     const fa_params& p = a.p;
     const int D = p.head_dim, cpr = D / 8, dv = valid_cols(p);
-    const int64_t rows = (int64_t)p.batch * p.seqlen_k * p.nheads_k;
+    const bool varlen = p.cu_seqlens_k != nullptr;
+    const int64_t rows = (varlen ? (int64_t)p.total_k : (int64_t)p.batch * p.seqlen_k) * p.nheads_k;
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t row = idx / cpr;
     const int cc = (int)(idx - row * cpr);
     if (row >= rows || cc * 8 >= dv) return;
+    // packed sequences: rows past the last sequence belong to nobody (no workgroup wrote their partials; dk / dv keep what they hold)
+    if (varlen && row / p.nheads_k >= p.cu_seqlens_k[p.batch]) return;
     const int which = blockIdx.y;                            // 0: dK, 1: dV
     const int64_t slab = rows * D;
     const float* src = reinterpret_cast<const float*>(a.dkv_part) + (int64_t)which * a.dkv_split * slab + row * D + cc * 8;
@@ -1856,11 +1874,11 @@ __global__ void __launch_bounds__(256) dkv_reduce_kernel(const KArgs a) {
     }
     const int hk = (int)(row % p.nheads_k);
     const int64_t bk = row / p.nheads_k;
-    const int key = (int)(bk % p.seqlen_k);
-    const int64_t b = bk / p.seqlen_k;
+    const int64_t key = varlen ? bk : bk % p.seqlen_k;          // (packed: the row of the [total_k, Hk, D] tensor)
+    const int64_t b = varlen ? 0 : bk / p.seqlen_k;
     uint16_t* dst = which == 0
-        ? reinterpret_cast<uint16_t*>(p.dk) + b * p.dk_batch_stride + (int64_t)key * p.dk_row_stride + (int64_t)hk * p.dk_head_stride
-        : reinterpret_cast<uint16_t*>(p.dv) + b * p.dv_batch_stride + (int64_t)key * p.dv_row_stride + (int64_t)hk * p.dv_head_stride;
+        ? reinterpret_cast<uint16_t*>(p.dk) + b * p.dk_batch_stride + key * p.dk_row_stride + (int64_t)hk * p.dk_head_stride
+        : reinterpret_cast<uint16_t*>(p.dv) + b * p.dv_batch_stride + key * p.dv_row_stride + (int64_t)hk * p.dv_head_stride;
     u32x4 o4;
 #pragma unroll
     for (int i = 0; i < 4; ++i) o4[i] = E::pack2(acc[2 * i], acc[2 * i + 1]);
@@ -1869,7 +1887,8 @@ __global__ void __launch_bounds__(256) dkv_reduce_kernel(const KArgs a) {
 template <typename T>
 static void launch_dkv_reduce(const KArgs& a, hipStream_t stream) {
     const fa_params& p = a.p;
-    const int64_t total = (int64_t)p.batch * p.seqlen_k * p.nheads_k * (p.head_dim / 8);
+    const int64_t rows = p.cu_seqlens_k ? (int64_t)p.total_k : (int64_t)p.batch * p.seqlen_k;
+    const int64_t total = rows * p.nheads_k * (p.head_dim / 8);
     hipLaunchKernelGGL(dkv_reduce_kernel<T>, dim3((unsigned)((total + 255) / 256), 2), dim3(256), 0, stream, a);
 }
 
@@ -1987,7 +2006,7 @@ static int launch_bwd_td(const KArgs& a, hipStream_t stream) {
                 int grid2 = grid;
                 if (a.flat_blocks && p.cu_seqlens_k && p.total_k > 0) {
                     a2.flat_kblocks = p.total_k / DKV_BN + p.batch;
-                    grid2 = a2.flat_kblocks * p.nheads_k;
+                    grid2 = a2.flat_kblocks * p.nheads_k * (a.dkv_split > 1 ? a.dkv_split : 1);
                 } else if (a.dkv_split > 1) {
                     grid2 = unit_grid(units, n_kb_grid * a.dkv_split);   // the query tiles of a pass over dkv_split workgroups (dkv_split_factor)
                 }
@@ -2030,7 +2049,7 @@ static int launch_bwd_td(const KArgs& a, hipStream_t stream) {
                 int grid2 = grid;
                 if (a.flat_blocks && p.cu_seqlens_k && p.total_k > 0) {
                     a2.flat_kblocks = p.total_k / DKV_BN + p.batch;
-                    grid2 = a2.flat_kblocks * p.nheads_k;
+                    grid2 = a2.flat_kblocks * p.nheads_k * (a.dkv_split > 1 ? a.dkv_split : 1);
                 } else if (a.dkv_split > 1) {
                     grid2 = unit_grid(units, n_kb_grid * a.dkv_split);
                 }
@@ -2123,7 +2142,8 @@ int launch_bwd(const KArgs& a_in, hipStream_t stream) {
     // a dense dK/dV launch smaller than the chip: query tiles split over several workgroups + a reduction (dkv_split_factor)
     a.dkv_split = 0;
     a.dkv_part = nullptr;
-    if (a.p.dk && !a.ds_ws && !a.p.cu_seqlens_q && !a.p.cu_seqlens_k) {
+    const bool packed = a.p.cu_seqlens_q || a.p.cu_seqlens_k;
+    if (a.p.dk && !a.ds_ws && (!packed || (a.flat_blocks && a.p.cu_seqlens_q && a.p.cu_seqlens_k))) {
         const bool asm_kernel = a.p.head_dim == 128 && a.stats_ws != nullptr;
         const int split = bwd_dkv_split_for(a, asm_kernel);
         const size_t off = align256(bwd_asm_applicable(a) ? bwd_asm_workspace_bytes(a.p) : 0);      // as bwd_workspace_bytes lays it out

@@ -57,7 +57,8 @@ __global__ void __launch_bounds__(SPLIT_THREADS, 1) fa_bwd_dkdv_split_kernel(con
     const int nsplit = PART ? a.dkv_split : 1;               // dense launches smaller than the chip (fa_bwd.hip: dkv_split_factor)
     int split = 0;
     if (a.flat_kblocks) {
-        const int id = blockIdx.x;
+        int id = blockIdx.x;
+        if (PART) { split = id % nsplit; id /= nsplit; }
         hk = id % p.nheads_k;
         flat_owner(id / p.nheads_k, DKV_BN, p.batch, p.cu_seqlens_k, lane, b, nb0);
         if (b < 0) return;
@@ -360,9 +361,10 @@ __global__ void __launch_bounds__(SPLIT_THREADS, 1) fa_bwd_dkdv_split_kernel(con
         const float sc = role == 0 ? 1.0f : p.softmax_scale;
         if (PART) {
             // fp32 partial of this split, [dK | dV][split][B][Sk][Hk][D]: dkv_reduce_kernel adds the splits and rounds once
-            const int64_t row = (int64_t)p.nheads_k * D, slab = (int64_t)p.batch * p.seqlen_k * row;
-            float* pp = reinterpret_cast<float*>(a.dkv_part) + ((role == 0 ? nsplit : 0) + split) * slab +
-                        ((int64_t)b * p.seqlen_k + my_key) * row + (int64_t)hk * D;
+            const int64_t row = (int64_t)p.nheads_k * D;
+            const int64_t slab = (p.cu_seqlens_k ? (int64_t)p.total_k : (int64_t)p.batch * p.seqlen_k) * row;
+            const int64_t krow = p.cu_seqlens_k ? sg.k_row0 + my_key : (int64_t)b * p.seqlen_k + my_key;
+            float* pp = reinterpret_cast<float*>(a.dkv_part) + ((role == 0 ? nsplit : 0) + split) * slab + krow * row + (int64_t)hk * D;
 #pragma unroll
             for (int d = 0; d < DBLKS; ++d)
 #pragma unroll

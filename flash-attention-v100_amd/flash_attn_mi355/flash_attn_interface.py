@@ -568,6 +568,8 @@ def _varlen_backward(dout, q_, k_, v_, out_, lse, cu_seqlens_q, cu_seqlens_k, al
     _set_head_dim(p, dpad)
     p.cu_seqlens_q, p.cu_seqlens_k = _ptr(cu_seqlens_q), _ptr(cu_seqlens_k)
     p.total_q, p.total_k = T_Q, k_.shape[0]
+    if not DKV_SPLIT:
+        p.flags |= _lib.FA_FLAG_NO_DKV_SPLIT
     _alibi(p, alibi_slopes, B, H_Q, q_.device)
     _philox(p, dropout_p, B, H_Q, q_.device, rng=rng)
     ws = _workspace(_lib.lib.fa_bwd_workspace_bytes(ctypes.byref(p)), q_.device)

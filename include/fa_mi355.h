@@ -37,7 +37,7 @@ extern "C" {
  * mask of a context-parallel shard (all queries over a slice of the keys).  FA_FLAG_KEEP_WINDOW keeps such a window; it is an
  * extension for this library's own sharding wrapper and never set by the drop-in Python API. */
 #define FA_FLAG_KEEP_WINDOW 1
-/* fa_bwd only.  A dense dK/dV launch with fewer workgroups than the GPU has room for (batch x kv-heads x 128-key blocks: GQA at
+/* fa_bwd / fa_varlen_bwd.  A dK/dV launch with fewer workgroups than the GPU has room for (batch x kv-heads x 128-key blocks: GQA at
  * micro-batch 1, short-key cross-attention) divides the query rows of each key block over several workgroups and adds their
  * 16-bit partial dK / dV in fp32 (deterministic; needs the workspace fa_bwd_workspace_bytes() reports).  dK / dV then differ in
  * the last bit from the one-workgroup-per-key-block result.  FA_FLAG_NO_DKV_SPLIT keeps one workgroup per key block. */

@@ -465,3 +465,52 @@ def test_varlen_flat_work_list_many_sequences(monkeypatch):
     assert_close(f64(flat[2]), dq_r, dt, "dq", mult=2.0)
     assert_close(f64(flat[3]), dk_r, dt, "dk", mult=2.0)
     assert_close(f64(flat[4]), dv_r, dt, "dv", mult=2.0)
+
+
+# packed launches whose flat list of key blocks x kv-heads is smaller than the chip split their query tiles like the dense
+# ones (fa_bwd.hip: dkv_split_factor on the average pass; partial slabs [total_k, Hk, D], the reduction skips rows past the last sequence)
+VSPLIT = [
+    # lens_q, lens_k, Hq, Hk, D, dtype, causal, window
+    ([900, 1300, 257], None, 8, 1, 128, "bf16", True, (-1, -1)),          # hand-scheduled kernel, group of 8
+    ([2048, 3, 0, 1400], None, 8, 2, 64, "fp16", True, (-1, -1)),         # D 64: empty and tiny sequences next to long ones
+    ([1500, 600], [300, 2000], 4, 4, 128, "fp16", False, (-1, -1)),       # Sq != Sk, no mask
+    ([800, 800, 800], None, 6, 3, 96, "bf16", True, (300, 0)),            # 96 valid columns, left window
+    ([1200, 900], None, 4, 2, 256, "bf16", True, (-1, -1)),               # head dim 256: each role stores its partial
+]
+
+
+@pytest.mark.parametrize("case", VSPLIT, ids=lambda c: "-".join(map(str, c)))
+def test_small_packed_dkdv_launches_split_their_query_rows(case, monkeypatch):
+    from flash_attn_mi355 import flash_attn_interface as fi
+    lens_q, lens_k, Hq, Hk, D, dt, causal, window = case
+    lens_k = lens_k or lens_q
+    Tq, Tk = sum(lens_q), sum(lens_k)
+    pad = 37                                                # rows past the last sequence: nobody's (dk / dv keep what they hold)
+    q = rand16((Tq, Hq, D), dt, 61).requires_grad_(True)
+    k = rand16((Tk + pad, Hk, D), dt, 62).requires_grad_(True)
+    v = rand16((Tk + pad, Hk, D), dt, 63).requires_grad_(True)
+    do = rand16((Tq, Hq, D), dt, 64)
+    cu_q, cu_k = _cu(lens_q), _cu(lens_k)
+    mq, mk = max(lens_q), max(lens_k)
+    grads, ws = {}, {}
+    real = fi._workspace
+    for on in (True, False):
+        monkeypatch.setattr(fi, "DKV_SPLIT", on)
+        seen = []
+        monkeypatch.setattr(fi, "_workspace", lambda n, dev: (seen.append(n), real(n, dev))[1])
+        out = _fa().flash_attn_varlen_func(q, k, v, cu_q, cu_k, mq, mk, causal=causal, window_size=window)
+        grads[on] = torch.autograd.grad(out, (q, k, v), do)
+        ws[on] = max(seen)
+        again = torch.autograd.grad(_fa().flash_attn_varlen_func(q, k, v, cu_q, cu_k, mq, mk, causal=causal, window_size=window),
+                                    (q, k, v), do)
+        for a_, b_ in zip(grads[on], again):
+            assert torch.equal(a_[:Tk] if a_.shape[0] == Tk + pad else a_, b_[:Tk] if b_.shape[0] == Tk + pad else b_)
+    assert ws[True] > ws[False]                              # the split form ran: it asked for the partial slabs
+    assert torch.equal(grads[True][0], grads[False][0])
+    cq, ck = cu_q.cpu().numpy(), cu_k.cpu().numpy()
+    kw = dict(causal=causal, window=window)
+    o_ref, lse_ref = oracle.varlen_fwd(f64(q), f64(k[:Tk]), f64(v[:Tk]), cq, ck, mq, mk, D ** -0.5, **kw)
+    g = oracle.varlen_bwd(f64(do), f64(q), f64(k[:Tk]), f64(v[:Tk]), o_ref, lse_ref.astype(np.float64), cq, ck, mq, mk, D ** -0.5, **kw)
+    for on in (True, False):
+        assert_close(f64(grads[on][1][:Tk]), g[1], dt, f"dk split={on}", mult=2.0)
+        assert_close(f64(grads[on][2][:Tk]), g[2], dt, f"dv split={on}", mult=2.0)

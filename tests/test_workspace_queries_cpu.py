@@ -52,7 +52,11 @@ def test_backward_statistics_workspace(lib):
     cu = (ctypes.c_int32 * 4)(0, 1000, 1300, 3348)
     p.cu_seqlens_q = p.cu_seqlens_k = ctypes.addressof(cu)   # (host memory: the query only tests the pointers for NULL)
     p.total_q = p.total_k = 3348
+    p.flags = lib.FA_FLAG_NO_DKV_SPLIT
     assert q(ctypes.byref(p)) == 2 * 8 * 3348 * 4
+    # ... (26 + 3) key blocks x 4 kv-heads = 116 workgroups, 35 stages of the average causal pass: 2 splits, slabs of total_k rows
+    p.flags = 0
+    assert q(ctypes.byref(p)) == ((2 * 8 * 3348 * 4 + 255) & ~255) + 2 * 2 * 3348 * 4 * 128 * 4
 
 
 def test_backward_split_workspace(lib):
