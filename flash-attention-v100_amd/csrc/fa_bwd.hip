@@ -1821,7 +1821,10 @@ static int dkv_split_factor(const fa_params& p, int pair, int slots_per_cu, int 
     const int64_t wgs = varlen ? ((int64_t)p.total_k / DKV_BN + p.batch) * p.nheads_k
                                : (int64_t)p.batch * p.nheads_k * (paired ? (n_kblocks + 1) / 2 : n_kblocks);
     const int64_t slots = (int64_t)fa_device_cu_count() * slots_per_cu;
-    if (wgs < 1 || wgs >= 4 * slots) return 1;
+    // packed passes differ in length and the heavy key blocks come first in the flat list: past ~1.5 waves of workgroups the
+    // dispatcher's own balancing leaves nothing for a split to win (3 sequences / 8 k tokens, 536 workgroups: +6 % with a split,
+    // profiles/r05_small_grid.txt section 7); dense launches of equal workgroups lose whole rounds up to a few waves
+    if (wgs < 1 || wgs >= (varlen ? 3 * slots / 2 : 4 * slots)) return 1;
     // stages of a workgroup (a causal pair walks about one full sequence in its two passes)
     int64_t stages = (int64_t)((p.seqlen_q + stage_rows - 1) / stage_rows) * (p.nheads_q / p.nheads_k);
     if (varlen) {
