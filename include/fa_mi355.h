@@ -169,6 +169,9 @@ const char* fa_build_info(void);           /* arch, compiler, kernel variants */
  * K / V) or a mixed batch whose sequences are mostly short (decode sequences next to a prefill chunk) - with the workspace
  * the split-KV decode kernels serve the short sequences, without it the general kernel serves everything (same results). */
 size_t fa_fwd_workspace_bytes(const fa_params* p);
+/* fa_bwd_workspace_bytes: the row-statistics planes of the hand-scheduled D = 128 dK/dV kernel (2 x rows x heads x 4 bytes) and, for
+ * dK/dV launches smaller than the GPU (see FA_FLAG_NO_DKV_SPLIT), fp32 partial dK / dV slabs behind them.  A smaller or NULL workspace
+ * is legal: the kernels that need no workspace run (same results up to the order of fp32 additions). */
 size_t fa_bwd_workspace_bytes(const fa_params* p);
 size_t fa_fwd_kvcache_workspace_bytes(const fa_params* p);
 
