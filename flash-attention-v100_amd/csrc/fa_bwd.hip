@@ -1807,8 +1807,9 @@ constexpr int DKV_SPLIT_MIN_STAGES = 8;                  // query stages x q-hea
 // against a 32-row stage of ~1.3-1.5 k cycles in the D = 128 / 256 kernels -> 8.
 // Model: the workgroups of a dense launch take equal time (mirrored pairs under a causal mask), so the launch takes
 // rounds(workgroups / slots) x (stages / split + passes x pass_stages); the split with the smallest product wins if it beats the
-// unsplit launch by 15 % (the partial slabs and the reduction launch are not in the model).  Launches of many rounds never
-// split: the second factor grows with the split, the first does not shrink.
+// unsplit launch by 15 % (the partial slabs and the reduction launch are not in the model).  The model's choices against forced
+// splits of 2 / 3 / 4 / 8 (build.py --variant ... FA_DKV_SPLIT_FORCE=n, tools/split_factor_sweep.py): it picks the measured best or
+// second best on every underfilled shape tried (128 workgroups: 2; 64: 4; D 64, 192 workgroups of 768 slots: 4).
 // Packed sequences (flat list of key blocks, no mirrored pairs: the host does not see the lengths): the same model on the AVERAGE
 // pass - total_k / 128 + batch key blocks per kv-head, total_q / batch rows per sequence, half of them under a causal-like mask.
 static int dkv_split_factor(const fa_params& p, int pair, int slots_per_cu, int stage_rows, int pass_stages) {
@@ -1821,10 +1822,15 @@ static int dkv_split_factor(const fa_params& p, int pair, int slots_per_cu, int 
     const int64_t wgs = varlen ? ((int64_t)p.total_k / DKV_BN + p.batch) * p.nheads_k
                                : (int64_t)p.batch * p.nheads_k * (paired ? (n_kblocks + 1) / 2 : n_kblocks);
     const int64_t slots = (int64_t)fa_device_cu_count() * slots_per_cu;
-    // packed passes differ in length and the heavy key blocks come first in the flat list: past ~1.5 waves of workgroups the
-    // dispatcher's own balancing leaves nothing for a split to win (3 sequences / 8 k tokens, 536 workgroups: +6 % with a split,
-    // profiles/r05_small_grid.txt section 7); dense launches of equal workgroups lose whole rounds up to a few waves
-    if (wgs < 1 || wgs >= (varlen ? 3 * slots / 2 : 4 * slots)) return 1;
+    // Only launches that leave slots EMPTY split.  Past one full wave of workgroups the "rounds" of this model do not show on the
+    // clock: the socket runs at its power limit, a half-empty second round runs at a higher clock, and the split's own prologues and
+    // partials are pure cost - forced splits measured 13-27 % SLOWER at 384 equal workgroups (B 3 x 8 heads, S 4096) and level at best
+    // elsewhere (profiles/r05_small_grid.txt section 8).  Packed launches get 1.5 waves: their heavy key blocks come first and
+    // a 264-296 workgroup list still ends with a few long passes (+9-13 % there, section 7), at 536 the dispatcher has balanced them.
+    if (wgs < 1 || wgs >= (varlen ? 3 * slots / 2 : slots)) return 1;
+#ifdef FA_DKV_SPLIT_FORCE                                  // measurement builds (build.py --variant): calibrate the model below
+    return FA_DKV_SPLIT_FORCE;
+#endif
     // stages of a workgroup (a causal pair walks about one full sequence in its two passes)
     int64_t stages = (int64_t)((p.seqlen_q + stage_rows - 1) / stage_rows) * (p.nheads_q / p.nheads_k);
     if (varlen) {
