@@ -80,12 +80,13 @@ static int check_common(const fa_params& p, bool need_out) {
              (reinterpret_cast<uintptr_t>(p.v) & 15) == 0, "q/k/v must be 16-byte aligned");
     if (!supported_head_dim(p.head_dim))
         return fail(FA_ERR_UNSUPPORTED, "head dimension %d has no gfx950 kernel in this build (64, 128, 256)", p.head_dim);
-    // The kernels address one (batch, head) slice through a buffer descriptor: 32-bit byte offsets.
-    // (varlen tensors are one slice of total_q / total_k rows; paged caches one page.)
+    // The kernels address one (batch, head) slice through a buffer descriptor: 32-bit byte offsets.  Packed (varlen) tensors:
+    // every kernel rebases its pointers at the sequence's first row in 64-bit arithmetic (q_row0 / k_row0 x row stride - the
+    // reference offsets with size_t, include/template.h:199-217), so the slice is ONE SEQUENCE (max_seqlen rows), not the
+    // total_q / total_k rows of the packed tensor; paged caches: one page.
     {
-        const int64_t rows_q = p.cu_seqlens_q ? (p.total_q > 0 ? p.total_q : p.seqlen_q) : p.seqlen_q;
-        const int64_t rows_k = p.block_table ? p.page_block_size
-                                             : (p.cu_seqlens_k ? (p.total_k > 0 ? p.total_k : p.seqlen_k) : p.seqlen_k);
+        const int64_t rows_q = p.seqlen_q;
+        const int64_t rows_k = p.block_table ? p.page_block_size : p.seqlen_k;
         FA_CHECK(p.head_dim_v >= 0 && p.head_dim_v <= p.head_dim && p.head_dim_v % 8 == 0,
                  "head_dim_v must be a multiple of 8 in [0, head_dim]");
         const bool narrow = p.head_dim_v > 0 && p.head_dim_v < p.head_dim;
@@ -93,9 +94,9 @@ static int check_common(const fa_params& p, bool need_out) {
         // q: 2 GiB - its rows are fetched through one descriptor whose offset 0x80000000 must lie OUTSIDE the slice (rows past the
         // sequence and columns past the valid width come back as zeros from the range check)
         FA_CHECK(rows_q * p.q_row_stride * 2 < ((int64_t)1 << 31),
-                 "one (batch, head) slice of q spans more than 2 GiB: not addressable by the gfx950 kernels");
+                 "one (batch / sequence, head) slice of q spans more than 2 GiB: not addressable by the gfx950 kernels");
         FA_CHECK(rows_k * p.k_row_stride * 2 < lim && rows_k * p.v_row_stride * 2 < lim,
-                 "one (batch, head) slice of k/v spans more than 4 GiB: not addressable by the gfx950 kernels");
+                 "one (batch / sequence, head) slice of k/v spans more than 4 GiB: not addressable by the gfx950 kernels");
     }
     return FA_OK;
 }

@@ -252,15 +252,15 @@ def _dense_forward(q, k, v, dropout_p, softmax_scale, causal, window_size, softc
     return res, lse, dmask, (q_, k_, v_, out_), rng, softmax_scale
 
 
-# Small dense dK/dV launches (batch x kv-heads x key blocks < the CUs' slots) split their query rows over several workgroups
-# (include/fa_mi355.h: FA_FLAG_NO_DKV_SPLIT).  False: one workgroup per key block, bit-identical across batch sizes.
-DKV_SPLIT = True
-
-
 def _dense_backward(dout, q_, k_, v_, out_, lse, alibi_slopes, dropout_p, softmax_scale, causal,
-                    window_size, softcap, rng, dq_, dk_, dv_, keep_window=False):
+                    window_size, softcap, rng, dq_, dk_, dv_, keep_window=False, deterministic=False):
     """One fa_bwd call; dq_/dk_/dv_ are caller-allocated [B, S, H, dpad] views (written in place).  dq_ = None, or
-    dk_ = dv_ = None, skips that gradient's kernel (autograd's needs_input_grad)."""
+    dk_ = dv_ = None, skips that gradient's kernel (autograd's needs_input_grad).
+
+    `deterministic`: every backward form is atomic-free and run-to-run repeatable; what the flag adds is BATCH INVARIANCE -
+    small dK/dV launches (batch x kv-heads x key blocks < the CUs' slots) otherwise split their query rows over several
+    workgroups and sum fp32 partials, so the last bit of dK / dV depends on batch x heads and the CU count.  True sets
+    FA_FLAG_NO_DKV_SPLIT (include/fa_mi355.h): one workgroup per key block, the same bits at every batch size."""
     B, M, H_Q, dpad = q_.shape
     N, H_K = k_.shape[1], k_.shape[2]
     dout_ = _prep(dout, dpad)
@@ -283,15 +283,15 @@ def _dense_backward(dout, q_, k_, v_, out_, lse, alibi_slopes, dropout_p, softma
     p.seqlen_q, p.seqlen_k = M, N
     if keep_window:
         p.flags = _lib.FA_FLAG_KEEP_WINDOW
-    if not DKV_SPLIT:
+    if deterministic:
         p.flags |= _lib.FA_FLAG_NO_DKV_SPLIT
     _set_head_dim(p, dpad)
     _alibi(p, alibi_slopes, B, H_Q, q_.device)
     _philox(p, dropout_p, B, H_Q, q_.device, rng=rng)
-    ws = _workspace(_lib.lib.fa_bwd_workspace_bytes(ctypes.byref(p)), q_.device)
-    if ws is not None:
-        p.workspace, p.workspace_bytes = _ptr(ws), ws.numel()
-    with _on_device(q_.device):
+    with _on_device(q_.device):                          # (the query reads the CURRENT device's CU count: same device as the launch)
+        ws = _workspace(_lib.lib.fa_bwd_workspace_bytes(ctypes.byref(p)), q_.device)
+        if ws is not None:
+            p.workspace, p.workspace_bytes = _ptr(ws), ws.numel()
         _lib.call("fa_bwd", p, _stream(q_.device))
     return softmax_d
 
@@ -333,7 +333,7 @@ class FlashAttnFunc(torch.autograd.Function):
         dq_ = new(q_) if need_q else None
         dk_, dv_ = (new(k_), new(v_)) if need_kv else (None, None)
         _dense_backward(dout, q_, k_, v_, out_, lse, alibi_slopes, ctx.dropout_p, ctx.softmax_scale,
-                        ctx.causal, ctx.window_size, ctx.softcap, ctx.rng, dq_, dk_, dv_)
+                        ctx.causal, ctx.window_size, ctx.softcap, ctx.rng, dq_, dk_, dv_, deterministic=ctx.deterministic)
         cut = lambda t, need: t[..., :d] if (t is not None and need) else None
         return (cut(dq_, need_q), cut(dk_, ctx.needs_input_grad[1]), cut(dv_, ctx.needs_input_grad[2])) + (None,) * 10
 
@@ -365,7 +365,7 @@ class FlashAttnQKVPackedFunc(torch.autograd.Function):
         dqkv = torch.empty((B, S, 3, H, dpad), dtype=q_.dtype, device=q_.device)
         _dense_backward(dout, q_, k_, v_, out_, lse, alibi_slopes, ctx.dropout_p, ctx.softmax_scale,
                         ctx.causal, ctx.window_size, ctx.softcap, ctx.rng,
-                        dqkv[:, :, 0], dqkv[:, :, 1], dqkv[:, :, 2])
+                        dqkv[:, :, 0], dqkv[:, :, 1], dqkv[:, :, 2], deterministic=ctx.deterministic)
         return (dqkv[..., :d],) + (None,) * 9
 
 
@@ -396,17 +396,20 @@ class FlashAttnKVPackedFunc(torch.autograd.Function):
         dq_ = _prep(dq_, dpad)
         dkv = torch.empty((B, Sk, 2, Hk, dpad), dtype=q_.dtype, device=q_.device)
         _dense_backward(dout, q_, k_, v_, out_, lse, alibi_slopes, ctx.dropout_p, ctx.softmax_scale,
-                        ctx.causal, ctx.window_size, ctx.softcap, ctx.rng, dq_, dkv[:, :, 0], dkv[:, :, 1])
+                        ctx.causal, ctx.window_size, ctx.softcap, ctx.rng, dq_, dkv[:, :, 0], dkv[:, :, 1],
+                        deterministic=ctx.deterministic)
         return (dq_[..., :d], dkv[..., :d]) + (None,) * 9
 
 
 def _warn_deterministic(deterministic):
     if deterministic:
-        # the reference warns and clears the flag (flash_attn_interface.py:129-131); our backward is
-        # atomic-free, i.e. always deterministic, so the request is honoured either way.
+        # the reference warns and clears the flag (flash_attn_interface.py:129-131); our backward is atomic-free, i.e. always
+        # run-to-run deterministic - the flag is kept and additionally makes the gradients batch-invariant (no split dK/dV
+        # launches: `_dense_backward`).
         warnings.warn("Forward is always deterministic. Backward on gfx950 is atomic-free and "
-                      "deterministic as well.", RuntimeWarning)
-    return False
+                      "deterministic as well; deterministic=True also disables the split dK/dV launches "
+                      "(batch-invariant gradients).", RuntimeWarning)
+    return bool(deterministic)
 
 
 def flash_attn_func(q, k, v, dropout_p: float = 0.0, softmax_scale: float = None,
@@ -543,7 +546,7 @@ def _varlen_forward(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqle
 
 def _varlen_backward(dout, q_, k_, v_, out_, lse, cu_seqlens_q, cu_seqlens_k, alibi_slopes,
                      max_seqlen_q, max_seqlen_k, dropout_p, softmax_scale, causal, window_size,
-                     softcap, rng, dq_, dk_, dv_):
+                     softcap, rng, dq_, dk_, dv_, deterministic=False):
     T_Q, H_Q, dpad = q_.shape
     H_K = k_.shape[1]
     B = cu_seqlens_q.numel() - 1
@@ -568,14 +571,14 @@ def _varlen_backward(dout, q_, k_, v_, out_, lse, cu_seqlens_q, cu_seqlens_k, al
     _set_head_dim(p, dpad)
     p.cu_seqlens_q, p.cu_seqlens_k = _ptr(cu_seqlens_q), _ptr(cu_seqlens_k)
     p.total_q, p.total_k = T_Q, k_.shape[0]
-    if not DKV_SPLIT:
+    if deterministic:
         p.flags |= _lib.FA_FLAG_NO_DKV_SPLIT
     _alibi(p, alibi_slopes, B, H_Q, q_.device)
     _philox(p, dropout_p, B, H_Q, q_.device, rng=rng)
-    ws = _workspace(_lib.lib.fa_bwd_workspace_bytes(ctypes.byref(p)), q_.device)
-    if ws is not None:
-        p.workspace, p.workspace_bytes = _ptr(ws), ws.numel()
     with _on_device(q_.device):
+        ws = _workspace(_lib.lib.fa_bwd_workspace_bytes(ctypes.byref(p)), q_.device)
+        if ws is not None:
+            p.workspace, p.workspace_bytes = _ptr(ws), ws.numel()
         _lib.call("fa_varlen_bwd", p, _stream(q_.device))
     return softmax_d
 
@@ -618,7 +621,7 @@ class FlashAttnVarlenFunc(torch.autograd.Function):
         dk_, dv_ = (new(k_), new(v_)) if need_kv else (None, None)
         _varlen_backward(dout, q_, k_, v_, out_, lse, cu_seqlens_q, cu_seqlens_k, alibi_slopes,
                          ctx.max_seqlen_q, ctx.max_seqlen_k, ctx.dropout_p, ctx.softmax_scale,
-                         ctx.causal, ctx.window_size, ctx.softcap, ctx.rng, dq_, dk_, dv_)
+                         ctx.causal, ctx.window_size, ctx.softcap, ctx.rng, dq_, dk_, dv_, deterministic=ctx.deterministic)
         cut = lambda t, need: t[..., :d] if (t is not None and need) else None
         return (cut(dq_, need_q), cut(dk_, ctx.needs_input_grad[1]), cut(dv_, ctx.needs_input_grad[2])) + (None,) * 14
 

@@ -78,7 +78,7 @@ def bwd(dout: Tensor, q: Tensor, k: Tensor, v: Tensor, out: Tensor, softmax_lse:
     softmax_d = _fi._dense_backward(dout, q_, k_, v_, out_, softmax_lse, alibi_slopes, p_dropout,
                                     softmax_scale, is_causal, (window_size_left, window_size_right),
                                     softcap, _rng_tuple(rng_state) if p_dropout > 0.0 else (0, 0),
-                                    dq_, dk_, dv_)
+                                    dq_, dk_, dv_, deterministic=deterministic)
     if dpad != d:
         dq_, dk_, dv_ = (t[..., :d].contiguous() for t in (dq_, dk_, dv_))
     return dq_, dk_, dv_, softmax_d
@@ -156,7 +156,7 @@ def varlen_bwd(dout: Tensor, q: Tensor, k: Tensor, v: Tensor, out: Tensor, softm
                                      max_seqlen_q, max_seqlen_k, p_dropout, softmax_scale, is_causal,
                                      (window_size_left, window_size_right), softcap,
                                      _rng_tuple(rng_state) if p_dropout > 0.0 else (0, 0),
-                                     dq_, dk_, dv_)
+                                     dq_, dk_, dv_, deterministic=deterministic)
     if dpad != d:
         dq_, dk_, dv_ = (t[..., :d].contiguous() for t in (dq_, dk_, dv_))
     return dq_, dk_, dv_, softmax_d
@@ -259,7 +259,7 @@ def bwd_out(dout: Tensor, q: Tensor, k: Tensor, v: Tensor, out: Tensor, softmax_
     softmax_d = _fi._dense_backward(dout, q_, k_, v_, out_, softmax_lse, alibi_slopes, p_dropout,
                                     softmax_scale, is_causal, (window_size_left, window_size_right),
                                     softcap, _rng_tuple(rng_state) if p_dropout > 0.0 else (0, 0),
-                                    dq_, dk_, dv_)
+                                    dq_, dk_, dv_, deterministic=deterministic)
     if not direct:
         dq.copy_(dq_[..., :d]); dk.copy_(dk_[..., :d]); dv.copy_(dv_[..., :d])
     return softmax_d

@@ -37,10 +37,10 @@ def load_ref_oracle():
 
 
 def gen_dense(ref_fwd, ref_bwd):
-    # the five 1-tile shapes of test.py:116-120 (D=M=N) up to 128, x causal in {F,T},
+    # the five 1-tile shapes of test.py:116-120 (D=M=N = 16 .. 256), x causal in {F,T},
     # plus two ragged-size cases exercising the same oracle functions.
     shapes = [(1, 1, 16, 16, 16), (1, 1, 32, 32, 32), (1, 1, 64, 64, 64),
-              (1, 1, 128, 128, 128), (1, 2, 96, 96, 64), (2, 1, 80, 80, 128)]
+              (1, 1, 128, 128, 128), (1, 1, 256, 256, 256), (1, 2, 96, 96, 64), (2, 1, 80, 80, 128)]
     for (B, H, M, N, D) in shapes:
         for causal in (False, True):
             torch.manual_seed(421)

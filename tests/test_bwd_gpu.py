@@ -1,6 +1,7 @@
 """GPU parity: dense backward (autograd through the Python API -> fa_bwd) vs the oracle and
 the reference-generated golden gradients."""
 import glob
+import warnings
 import os
 
 import numpy as np
@@ -342,10 +343,11 @@ def test_small_dkdv_launches_split_their_query_rows(case, monkeypatch):
     do = rand16((B, Sq, Hq, D), dt, 524)
     grads = {}
     for on in (True, False):
-        monkeypatch.setattr(fi, "DKV_SPLIT", on)
-        out = _fa().flash_attn_func(q, k, v, causal=causal, window_size=window)
-        grads[on] = torch.autograd.grad(out, (q, k, v), do)
-        again = torch.autograd.grad(_fa().flash_attn_func(q, k, v, causal=causal, window_size=window), (q, k, v), do)
+        run = lambda: _fa().flash_attn_func(q, k, v, causal=causal, window_size=window, deterministic=not on)   # the public switch
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", RuntimeWarning)
+            grads[on] = torch.autograd.grad(run(), (q, k, v), do)
+            again = torch.autograd.grad(run(), (q, k, v), do)
         for a_, b_ in zip(grads[on], again):
             assert torch.equal(a_, b_)                       # both forms are deterministic
     assert torch.equal(grads[True][0], grads[False][0])      # dQ does not know about it
@@ -355,6 +357,26 @@ def test_small_dkdv_launches_split_their_query_rows(case, monkeypatch):
     for on in (True, False):
         assert_close(t(grads[on][1]), g[1], dt, f"dk split={on}", mult=2.0)
         assert_close(t(grads[on][2]), g[2], dt, f"dv split={on}", mult=2.0)
+
+
+def test_deterministic_means_batch_invariant_gradients():
+    """`deterministic=True` sets FA_FLAG_NO_DKV_SPLIT: a sample's dK / dV have the same BITS alone and inside a larger batch
+    (the split launches sum fp32 partials whose number follows batch x kv-heads and the CU count)."""
+    B, S, Hq, Hk, D = 4, 1024, 8, 2, 128
+    q = rand16((B, S, Hq, D), "bf16", 901).requires_grad_(True)
+    k = rand16((B, S, Hk, D), "bf16", 902).requires_grad_(True)
+    v = rand16((B, S, Hk, D), "bf16", 903).requires_grad_(True)
+    do = rand16((B, S, Hq, D), "bf16", 904)
+
+    def grads(n):
+        qq, kk, vv = (t[:n].detach().clone().requires_grad_(True) for t in (q, k, v))
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", RuntimeWarning)
+            out = _fa().flash_attn_func(qq, kk, vv, causal=True, deterministic=True)
+        return torch.autograd.grad(out, (qq, kk, vv), do[:n])
+    one, four = grads(1), grads(4)
+    for a_, b_ in zip(one, four):
+        assert torch.equal(a_[0], b_[0])
 
 
 def test_a_full_round_of_dkdv_workgroups_is_not_split():

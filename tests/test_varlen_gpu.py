@@ -1,4 +1,5 @@
 """GPU parity: packed variable-length forward/backward (and paged K/V) vs the oracle."""
+import warnings
 import numpy as np
 import pytest
 import torch
@@ -495,14 +496,15 @@ def test_small_packed_dkdv_launches_split_their_query_rows(case, monkeypatch):
     grads, ws = {}, {}
     real = fi._workspace
     for on in (True, False):
-        monkeypatch.setattr(fi, "DKV_SPLIT", on)
         seen = []
         monkeypatch.setattr(fi, "_workspace", lambda n, dev: (seen.append(n), real(n, dev))[1])
-        out = _fa().flash_attn_varlen_func(q, k, v, cu_q, cu_k, mq, mk, causal=causal, window_size=window)
-        grads[on] = torch.autograd.grad(out, (q, k, v), do)
-        ws[on] = max(seen)
-        again = torch.autograd.grad(_fa().flash_attn_varlen_func(q, k, v, cu_q, cu_k, mq, mk, causal=causal, window_size=window),
-                                    (q, k, v), do)
+        run = lambda: _fa().flash_attn_varlen_func(q, k, v, cu_q, cu_k, mq, mk, causal=causal, window_size=window,
+                                                   deterministic=not on)          # the public switch (FA_FLAG_NO_DKV_SPLIT)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", RuntimeWarning)
+            grads[on] = torch.autograd.grad(run(), (q, k, v), do)
+            ws[on] = max(seen)
+            again = torch.autograd.grad(run(), (q, k, v), do)
         for a_, b_ in zip(grads[on], again):
             assert torch.equal(a_[:Tk] if a_.shape[0] == Tk + pad else a_, b_[:Tk] if b_.shape[0] == Tk + pad else b_)
     assert ws[True] > ws[False]                              # the split form ran: it asked for the partial slabs
@@ -514,3 +516,40 @@ def test_small_packed_dkdv_launches_split_their_query_rows(case, monkeypatch):
     for on in (True, False):
         assert_close(f64(grads[on][1][:Tk]), g[1], dt, f"dk split={on}", mult=2.0)
         assert_close(f64(grads[on][2][:Tk]), g[2], dt, f"dv split={on}", mult=2.0)
+
+
+def test_packed_batch_past_2gib_of_q():
+    """A packed batch of 303 104 tokens at H 32 / D 128 (37 x 8192: 2.48 GB of q, its last sequence starts 2.4 GB into the
+    tensor) - ordinary with sequence packing; the reference offsets with size_t (include/template.h:199-217).  Until round 6
+    fa_api.hip bounded the WHOLE packed tensor by 2 GiB although every kernel rebases its descriptors at the sequence's first
+    row.  Checked: the packed call == the dense call on the same memory viewed as (37, 8192, H, D) (forward, LSE and all three
+    gradients), and one head of the LAST sequence against the fp64 oracle."""
+    nseq, S, H, D, dt = 37, 8192, 32, 128, "bf16"
+    T = nseq * S
+    assert T * H * D * 2 > (1 << 31)
+    gen = torch.Generator(device="cuda").manual_seed(77)
+    mk = lambda: torch.randn((T, H, D), generator=gen, device="cuda", dtype=torch.bfloat16)
+    q, k, v, do = mk().requires_grad_(True), mk().requires_grad_(True), mk().requires_grad_(True), mk()
+    cu = _cu([S] * nseq)
+    out, lse, _ = _fa().flash_attn_varlen_func(q, k, v, cu, cu, S, S, causal=True, return_attn_probs=True)
+    dq, dk, dv = torch.autograd.grad(out, (q, k, v), do)
+    assert all(torch.isfinite(t).all() for t in (out, dq, dk, dv))
+
+    d4 = lambda t: t.detach().view(nseq, S, H, D)
+    qd, kd, vd = (d4(t).requires_grad_(True) for t in (q, k, v))
+    out_d, lse_d, _ = _fa().flash_attn_func(qd, kd, vd, causal=True, return_attn_probs=True)
+    gd = torch.autograd.grad(out_d, (qd, kd, vd), d4(do))
+    assert torch.equal(d4(out), out_d)                       # same kernel bodies, same tiles: the same bits
+    assert torch.equal(lse.view(H, nseq, S).transpose(0, 1), lse_d)
+    for name, a_, b_ in zip(("dq", "dk", "dv"), (dq, dk, dv), gd):
+        assert_close(f64(d4(a_)[-2:]), f64(b_[-2:]), dt, name + " packed vs dense", mult=0.25)
+
+    s0, h = T - S, 31                                        # last sequence (byte offset 2.4 GB), last head
+    t = lambda x: f64(x[s0:, h])[None, None]
+    o_ref, lse_ref, _ = oracle.attn_fwd(t(q), t(k), t(v), D ** -0.5, causal=True)
+    assert_close(t(out), o_ref, dt, "o last sequence")
+    assert_lse_close(f64(lse[h, s0:])[None, None], lse_ref, "lse last sequence")
+    # (dK / dV of one head need the other heads' queries only under GQA: H_q == H_k here, so one head is self-contained)
+    g = oracle.attn_bwd(t(do), t(q), t(k), t(v), o_ref, lse_ref.astype(np.float64), D ** -0.5, causal=True)
+    for name, got, ref in zip(("dq", "dk", "dv"), (dq, dk, dv), g):
+        assert_close(t(got), ref, dt, name + " last sequence", mult=2.0)

@@ -49,9 +49,8 @@ SHAPES = [
     ("Gemma-2    B2 S4096 H16/8 D256 causal", 2, 4096, 4096, 16, 8, 256, True, torch.bfloat16),
 ]
 sel = [int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 and sys.argv[1] != "all" else range(len(SHAPES))
-if len(sys.argv) > 2 and sys.argv[2] == "nosplit":           # A/B: one workgroup per key block (FA_FLAG_NO_DKV_SPLIT)
-    from flash_attn_mi355 import flash_attn_interface as fi
-    fi.DKV_SPLIT = False
+NOSPLIT = len(sys.argv) > 2 and sys.argv[2] == "nosplit"     # A/B: one workgroup per key block (deterministic=True: FA_FLAG_NO_DKV_SPLIT)
+if NOSPLIT:
     print("(FA_FLAG_NO_DKV_SPLIT)")
 for i in sel:
     name, B, Sq, Sk, Hq, Hk, D, causal, dt = SHAPES[i]
@@ -60,7 +59,7 @@ for i in sel:
     k = torch.randn(B, Sk, Hk, D, device="cuda", dtype=dt, requires_grad=True)
     v = torch.randn(B, Sk, Hk, D, device="cuda", dtype=dt, requires_grad=True)
     do = torch.randn_like(q)
-    f = lambda a, b, c: fa.flash_attn_func(a, b, c, causal=causal)
+    f = lambda a, b, c: fa.flash_attn_func(a, b, c, causal=causal, deterministic=NOSPLIT)
     with torch.no_grad():
         tf = t_ms(lambda: f(q, k, v))
     r = {nm: t_ms(bwd_call(f, q, k, v, do, nm), n=8) for nm in ("dkdv", "dq", "all")}

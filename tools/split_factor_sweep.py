@@ -6,8 +6,7 @@ sys.path.insert(0, os.path.join(ROOT, "flash-attention-v100_amd")); sys.path.ins
 import torch, flash_attn as fa
 from flash_attn_mi355 import flash_attn_interface as fi
 from _bwdsel import bwd_call
-if len(sys.argv) > 1 and sys.argv[1] == "nosplit":
-    fi.DKV_SPLIT = False
+NOSPLIT = len(sys.argv) > 1 and sys.argv[1] == "nosplit"     # deterministic=True: FA_FLAG_NO_DKV_SPLIT
 
 def b2b(f, n=20):
     for _ in range(5): f()
@@ -18,7 +17,7 @@ def b2b(f, n=20):
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / n * 1e3
 
-tag = os.path.basename(os.environ.get("FA_MI355_LIB", "product")) + (" nosplit" if not fi.DKV_SPLIT else "")
+tag = os.path.basename(os.environ.get("FA_MI355_LIB", "product")) + (" nosplit" if NOSPLIT else "")
 SH = [(1, 4096, 32, 8, 128, True), (3, 4096, 8, 8, 128, True), (3, 4096, 32, 8, 128, True), (5, 4096, 32, 8, 128, True), (1, 2048, 32, 8, 128, True),
       (6, 2048, 8, 8, 128, True), (2, 8192, 16, 16, 128, False), (12, 1024, 16, 16, 128, False), (1, 4096, 16, 8, 256, True), (3, 4096, 16, 4, 64, True),
       (12, 2048, 16, 16, 64, True), (4, 1024, 16, 16, 64, False)]
@@ -28,6 +27,6 @@ for (B, S, H, Hk, D, causal) in SH:
     k = torch.randn(B, S, Hk, D, device="cuda", dtype=torch.bfloat16, requires_grad=True)
     v = torch.randn(B, S, Hk, D, device="cuda", dtype=torch.bfloat16, requires_grad=True)
     do = torch.randn_like(q)
-    f = lambda a, b, c: fa.flash_attn_func(a, b, c, causal=causal)
+    f = lambda a, b, c: fa.flash_attn_func(a, b, c, causal=causal, deterministic=NOSPLIT)
     out.append(f"{b2b(bwd_call(f, q, k, v, do, 'all')):7.1f}")
 print(f"{tag:28s} " + " ".join(out), flush=True)

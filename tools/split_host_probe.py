@@ -32,9 +32,8 @@ for (B, Sq, Sk, H, Hk, D, causal, dt) in ((8, 4096, 77, 8, 8, 40, False, torch.f
     k = torch.randn(B, Sk, Hk, D, device="cuda", dtype=dt, requires_grad=True)
     v = torch.randn(B, Sk, Hk, D, device="cuda", dtype=dt, requires_grad=True)
     do = torch.randn_like(q)
-    f = lambda a, b, c: fa.flash_attn_func(a, b, c, causal=causal)
     for on in (True, False):
-        fi.DKV_SPLIT = on
+        f = lambda a, b, c, on=on: fa.flash_attn_func(a, b, c, causal=causal, deterministic=not on)     # deterministic=True: FA_FLAG_NO_DKV_SPLIT
         for nm in ("dkdv", "dq", "all"):
             c = bwd_call(f, q, k, v, do, nm)
             print(f"B{B} Sq{Sq} Sk{Sk} H{H}/{Hk} D{D} split={on} {nm:5s}: issue loop {host_us(c):7.1f} us/call, back-to-back {dev_us(c):7.1f} us/call", flush=True)

@@ -33,10 +33,9 @@ for name, lens, H, Hk, D, win in CASES:
     k = torch.randn(T, Hk, D, device="cuda", dtype=torch.bfloat16, requires_grad=True)
     v = torch.randn(T, Hk, D, device="cuda", dtype=torch.bfloat16, requires_grad=True)
     do = torch.randn_like(q)
-    f = lambda a, b, c: fa.flash_attn_varlen_func(a, b, c, cu, cu, max(lens), max(lens), causal=True, window_size=win)
     r = {}
     for on in (False, True, False, True):
-        fi.DKV_SPLIT = on
+        f = lambda a, b, c, on=on: fa.flash_attn_varlen_func(a, b, c, cu, cu, max(lens), max(lens), causal=True, window_size=win, deterministic=not on)
         r.setdefault(on, []).append((b2b(bwd_call(f, q, k, v, do, "dkdv")), b2b(bwd_call(f, q, k, v, do, "all"))))
     fmt = lambda xs: " / ".join(f"{a:6.1f}" for a in xs)
     print(f"{name:42s} key blocks x kv-heads {(T // 128 + len(lens)) * Hk:5d} | dK/dV(+pre) off {fmt([x[0] for x in r[False]])}  on {fmt([x[0] for x in r[True]])} us"
