@@ -422,6 +422,66 @@ def config5(flash_attn, dev, world, rank, iters=3, warm=2):
     return ms, flops, Bs, Hs
 
 
+def init_dist(local_rank, dry_run=False):
+    """The data path has NO collective (heads x batch shard): the process group only carries the timing barrier
+    and the MAX over ranks.  RCCL ("nccl") first; if its init or first barrier fails, the same two operations run over gloo on
+    the CPU - an RCCL problem on the node must not cost the scaling measurement.  -> (torch.distributed, backend name)"""
+    import datetime
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    want = os.environ.get("FA_BENCH_DIST_BACKEND", "gloo" if dry_run else "nccl")
+    if want == "nccl":
+        try:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(seconds=120))
+            dist.barrier()
+            torch.cuda.synchronize()
+            return dist, "nccl"
+        except Exception as e:                       # noqa: BLE001
+            print(f"bench.py: nccl (RCCL) process group failed ({type(e).__name__}: {str(e)[:200]}); falling back to gloo",
+                  file=sys.stderr, flush=True)
+            try:
+                dist.destroy_process_group()
+            except Exception:                        # noqa: BLE001
+                pass
+            # (every rank takes the same branch: an init failure is collective; the fallback group meets on the next port)
+            os.environ["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 1)
+    dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=300))
+    return dist, "gloo"
+
+
+def max_over_ranks(dist, backend, seconds, dev):
+    if dist is None:
+        return seconds
+    t = torch.tensor([seconds], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def dry_run(args, rank, world, dist, backend):
+    """--dry-run: the N > 1 control path without a GPU - rendezvous, barrier on both sides of K "steps", MAX over ranks, ONE JSON
+    line from rank 0 with the contract's keys (tests/test_bench_contract.py runs it with two gloo ranks)."""
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.001 * (1 + rank))               # rank 1 is slower: the MAX must pick it up
+    barrier()
+    elapsed = max_over_ranks(dist, backend, time.perf_counter() - t0, None)
+    if rank == 0:
+        ff = fwd_flops(CFG)
+        print(json.dumps({"metric": "attention TFLOPS fwd+bwd (seqlen 4096, hd128, causal)", "value": world * 3.5 * ff / (elapsed / args.steps) / 1e12, "unit": "TFLOP/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+                          "data": "dry run: no GPU work, sleeps instead of steps", "dist_backend": backend,
+                          "config": {"workload": "dense fwd+bwd bf16 causal B8 H16 S4096 D128 (BASELINE configs[1])", "dry_run": True}}), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -429,19 +489,20 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU work: exercise the launch / rendezvous / barrier / MAX-over-ranks / JSON path only (CPU test of N > 1)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
+    dist_backend = None
     if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(0)
+        dist, dist_backend = init_dist(local_rank, args.dry_run)
+    if args.dry_run:
+        return dry_run(args, rank, world, dist, dist_backend)
+    torch.cuda.set_device(local_rank if world > 1 else 0)
     dev = torch.device("cuda", local_rank if world > 1 else 0)
 
     import flash_attn
@@ -473,10 +534,7 @@ def main():
         step()
     barrier()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = max_over_ranks(dist, dist_backend, elapsed, dev)
 
     ff = fwd_flops(c)
     step_flops = 3.5 * ff
@@ -532,10 +590,7 @@ def main():
         torch.cuda.empty_cache()
         ms5, fl5, Bs, Hs = config5(flash_attn, dev, world, rank)
         barrier()
-        t5 = torch.tensor([ms5], device=dev, dtype=torch.float64)
-        if dist is not None:
-            dist.all_reduce(t5, op=dist.ReduceOp.MAX)
-        ms5max = float(t5.item())
+        ms5max = max_over_ranks(dist, dist_backend, ms5, dev)
         total5 = 4.0 * 64 * 32 * 8192 * 8192 * 128 / 2
         strong = {"workload": "dense fwd bf16 causal + ALiBi B64 H32 S8192 D128, heads sharded over the ranks (BASELINE configs[4])",
                   "n_gpus": world, "batch_per_gpu": Bs, "heads_per_gpu": Hs, "ms": round(ms5max, 4),
@@ -616,6 +671,8 @@ def main():
             "fwd_tflops": kernels["fwd"]["achieved"], "fwd_frac_of_mfma_peak": kernels["fwd"]["frac"],
             "roofline": roofline, "kernels": kernels,
         }
+        if world > 1:
+            out["dist_backend"] = dist_backend      # barrier + MAX only (no data-path collective): "nccl" = RCCL, "gloo" = the CPU fallback
         if strong is not None:
             out["strong_scaling_config5"] = strong
         if not args.no_other_configs:

@@ -106,7 +106,7 @@ def build(force=False, verbose=False, defines=(), out=None):
     for src in SOURCES:
         obj = os.path.join(bdir, src.replace(".hip", ".o"))
         objs.append(obj)
-        extra = ["-Rpass-analysis=kernel-resource-usage"] if src in ASM_SOURCES else []
+        extra = ["-Rpass-analysis=kernel-resource-usage"]         # every kernel's registers / spills / scratch -> kernel_resources.json
         cmd = [hipcc] + FLAGS + extra + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
@@ -116,9 +116,9 @@ def build(force=False, verbose=False, defines=(), out=None):
         out, _ = pr.communicate()
         if pr.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{out.decode(errors='replace')}")
-        if src in ASM_SOURCES:
-            resources.update(_asm_kernel_resources(out.decode(errors="replace")))
-    _check_asm_kernels(resources)
+        resources.update(_asm_kernel_resources(out.decode(errors="replace")))
+    _check_asm_kernels(resources)                                # (hand-scheduled bodies: no spill, no scratch; the compiler kernels'
+                                                                 #  spill budget is tests/test_build_resources.py + csrc/spill_budget.json)
     import json
     with open(RESOURCES, "w") as f:
         json.dump(resources, f, indent=1, sort_keys=True)

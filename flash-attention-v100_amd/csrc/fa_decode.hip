@@ -1591,9 +1591,9 @@ size_t decode_split_workspace_bytes(const fa_params& p) {
 
 // two waves per SIMD for the MFMA decode kernel?  (FA_DEC_NW = 4 / 8 forces it: A/B in tools/decode_splits_sweep.py)
 static bool decode_eight_waves(const fa_params& p) {
-    const char* e = getenv("FA_DEC_NW");
-    if (e && e[0] == '8') return true;
-    if (e && e[0] == '4') return false;
+    static const int forced = [] { const char* e = getenv("FA_DEC_NW"); return e ? (int)e[0] : 0; }();   // (read once, not per call)
+    if (forced == '8') return true;
+    if (forced == '4') return false;
     // head dims up to 128: the SIMD's second wave fills the first one's waits (LDS round trips, MFMA chains, loads) - 7-24 %
     // faster on every shape measured (profiles/r03_decode_features.txt (5)); D = 256 keeps its 128 accumulator registers
     // and four waves

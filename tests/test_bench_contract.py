@@ -71,3 +71,54 @@ def test_bench_json_line_contract():
     assert 0.95 <= t["sum_over_step"] <= 1.03, t                # vs the wall-clock mean of the timed steps (outliers, host tail)
     for name in ("fwd", "bwd_dq", "bwd_all"):
         assert d["kernels"][name]["ms_min"] <= d["kernels"][name]["ms"]
+
+
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_two_rank_dry_run_of_the_multi_gpu_path():
+    """N > 1 without a GPU: the driver's launch line (torch.distributed.run, one rank per GPU) with --dry-run - rendezvous on
+    127.0.0.1, barrier on both sides of the K steps, MAX over ranks (rank 1 sleeps twice as long: the reported time must be
+    its time), ONE JSON line from rank 0 with the contract's keys and the backend that carried the barrier."""
+    env = dict(os.environ)
+    env.pop("RANK", None); env.pop("WORLD_SIZE", None)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+                          os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "2", "--dry-run"],
+                         capture_output=True, text=True, cwd=ROOT, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    r = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config"):
+        assert key in r, key
+    assert r["n_gpus"] == 2 and r["steps"] == 20 and r["dist_backend"] == "gloo"
+    assert r["ms_per_step"] >= 2.0                  # rank 1's 2 ms per "step", not rank 0's 1 ms: the MAX over ranks
+    assert "workload" in r["config"]
+
+
+def test_nccl_failure_falls_back_to_gloo(monkeypatch):
+    """bench.init_dist: an RCCL init problem must not cost the scaling run - barrier and MAX move to gloo (here: no GPU at all,
+    so the nccl branch fails in-process; world size 1 keeps the test single-process)."""
+    m = _bench_module()
+    import torch.distributed as dist
+    if dist.is_initialized():
+        dist.destroy_process_group()
+    monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
+    monkeypatch.setenv("MASTER_PORT", str(_free_port()))
+    monkeypatch.setenv("RANK", "0"); monkeypatch.setenv("WORLD_SIZE", "1")
+    monkeypatch.delenv("FA_BENCH_DIST_BACKEND", raising=False)
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("needs a box without a GPU (the nccl init succeeds here)")
+    d, backend = m.init_dist(0)
+    try:
+        assert backend == "gloo"
+        assert m.max_over_ranks(d, backend, 1.25, None) == 1.25
+    finally:
+        d.destroy_process_group()
