@@ -132,3 +132,30 @@ def test_kernels_of_the_baseline_configs_do_not_spill():
                 seen[w] += 1
                 assert res[n].get("spill", 0) <= allowed and res[n].get("scratch", 0) <= 4 * allowed + 4 * (allowed > 0), (dm, res[n])
     assert all(seen.values()), seen
+
+
+def test_transposed_lds_reads_are_waited_for_before_use():
+    """fa_common.h issues ds_read_b64_tr_b16 / _tr_b8 as inline asm with hand-counted `s_waitcnt lgkmcnt(n)` (hipcc would put a
+    vmcnt(0) in front of the builtin form); the compiler does not know those asm outputs are in flight.  tools/isa_lds_check.py
+    replays the disassembly of every compiler-scheduled kernel with the in-order LDS queue: no instruction may name a
+    transposing read's destination before the wait that covers it (a coalescer copy or a hoisted use would read stale data
+    silently).  The hand-scheduled *_asm_kernel bodies are not replayed linearly (branches into unrolled copies, called
+    routines): their generator's own hazard checker emits and counts every wait (test_hazard_checker_... above)."""
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import build
+    import isa_lds_check as chk
+    build.build()
+    bdir = os.path.join(build.CSRC, "build")
+    objs = [os.path.join(bdir, s.replace(".hip", ".o")) for s in build.SOURCES if s not in build.ASM_SOURCES]
+    with tempfile.TemporaryDirectory() as wd:
+        report, bad = chk.check_objects(objs, wd)
+    assert sum(nt for _, nt in report.values()) > 10000          # the reads are there: forward, backward, decode
+    assert not bad, bad[:5]
+    # the checker does flag the failure it is written for: a copy of the destination in front of the wait
+    code = ["ds_read_b64_tr_b16 v[10:11], v5", "ds_read_b64_tr_b16 v[12:13], v5 offset:512", "v_mov_b32_e32 v20, v11",
+            "s_waitcnt lgkmcnt(0)", "v_mfma_f32_32x32x16_bf16 a[0:15], v[10:13], v[30:33], a[0:15]"]
+    assert len(chk.check_function("synthetic", code)[1]) == 1
+    ok = ["ds_read_b64_tr_b16 v[10:11], v5", "ds_read_b64_tr_b16 v[12:13], v5 offset:512", "ds_read_b128 v[40:43], v6",
+          "s_load_dword s4, s[0:1], 0x0", "s_waitcnt lgkmcnt(1)", "v_mfma_f32_32x32x16_bf16 a[0:15], v[10:13], v[30:33], a[0:15]"]
+    assert chk.check_function("synthetic", ok)[1] == []
