@@ -1930,7 +1930,9 @@ static int bwd_dkv_split_for(const KArgs& a, bool asm_kernel) {
     const bool drop = p.p_dropout > 0.f;
     const bool lin_alibi = p.alibi_slopes && p.softcap <= 0.f && (p.is_causal || p.window_right == 0);
     const bool cap_only = p.softcap > 0.f && !p.alibi_slopes;
-    const int pair = ((p.is_causal || p.window_right >= 0) && p.window_left < 0) ? 1 : 0;     // (fa_api.hip: make_args)
+    // the predicate of fa_api.hip: make_args (block_m = 128) - the kernels pair key blocks only when a.pair_qblocks is set: a
+    // causal call with seqlen_q <= 128 over long keys is NOT paired (the model would otherwise see half its workgroups)
+    const int pair = ((p.is_causal || p.window_right >= 0) && p.window_left < 0 && (p.seqlen_q + 127) / 128 >= 2) ? 1 : 0;
     if (asm_kernel) return p.alibi_slopes ? 1 : dkv_split_factor(p, pair, 1, 32, 8);     // (the ALiBi bodies have no partial epilogue)
     if (a.ds_ws) return 1;
     if (p.head_dim > 128)                                  // two waves per key block (fa_bwd_d256.hip): one workgroup per CU

@@ -171,7 +171,12 @@ const char* fa_build_info(void);           /* arch, compiler, kernel variants */
 size_t fa_fwd_workspace_bytes(const fa_params* p);
 /* fa_bwd_workspace_bytes: the row-statistics planes of the hand-scheduled D = 128 dK/dV kernel (2 x rows x heads x 4 bytes) and, for
  * dK/dV launches smaller than the GPU (see FA_FLAG_NO_DKV_SPLIT), fp32 partial dK / dV slabs behind them.  A smaller or NULL workspace
- * is legal: the kernels that need no workspace run (same results up to the order of fp32 additions). */
+ * is legal: the kernels that need no workspace run (same results up to the order of fp32 additions).
+ * One query serves fa_bwd AND fa_varlen_bwd: pass the struct EXACTLY as it goes into the op - cu_seqlens_q / cu_seqlens_k select the
+ * packed sizing and split decision, and fa_bwd itself ignores them (a dense caller that recycles a struct must clear the varlen
+ * fields before the query, or the sizes answer the varlen op; the `workspace_bytes` guard of the ops keeps a mismatch safe - the
+ * split is then dropped or the slabs go unused - but not fast).  The split decision reads the CU count of the CURRENT device:
+ * query on the device the op will be launched on. */
 size_t fa_bwd_workspace_bytes(const fa_params* p);
 size_t fa_fwd_kvcache_workspace_bytes(const fa_params* p);
 
