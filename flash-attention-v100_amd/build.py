@@ -13,7 +13,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 OUT_DIR = os.path.join(HERE, "flash_attn_mi355")
 LIB = os.path.join(OUT_DIR, "libfa_mi355.so")
-SOURCES = ["fa_api.hip", "fa_fwd.hip", "fa_fwd_asm.hip", "fa_bwd.hip", "fa_bwd_d256.hip", "fa_bwd_asm.hip", "fa_bwd_dq_asm.hip", "fa_kvcache.hip", "fa_decode.hip", "fa_rows.hip"]
+SOURCES = ["fa_api.hip", "fa_fwd.hip", "fa_fwd_asm.hip", "fa_bwd.hip", "fa_bwd_d256.hip", "fa_bwd_asm.hip", "fa_bwd_dq_asm.hip", "fa_bwd_dq_ds.hip", "fa_kvcache.hip", "fa_decode.hip", "fa_rows.hip"]
 GENERATED = [("gen_fwd_asm.py", "fa_fwd_asm_gen.h", []),
              ("gen_bwd_dkdv_asm.py", "fa_bwd_asm_gen.h", []),
              ("gen_bwd_dq_asm.py", "fa_bwd_dq_asm_gen.h", [])]  # (generator, header, arguments): hand-scheduled asm bodies

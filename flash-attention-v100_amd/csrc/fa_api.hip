@@ -65,7 +65,7 @@ static int check_common(const fa_params& p, bool need_out) {
     FA_CHECK(p.q && (no_keys || (p.k && p.v)), "q, k, v must not be NULL");
     FA_CHECK(!need_out || (p.o && p.lse), "o and lse must not be NULL");
     FA_CHECK(p.dtype == FA_FP16 || p.dtype == FA_BF16, "q must be fp16 or bf16");
-    FA_CHECK((p.flags & ~(FA_FLAG_KEEP_WINDOW | FA_FLAG_NO_DKV_SPLIT)) == 0, "fa_params::flags has unknown bits set (zero-initialise the struct)");
+    FA_CHECK((p.flags & ~(FA_FLAG_KEEP_WINDOW | FA_FLAG_NO_DKV_SPLIT | FA_FLAG_DS_HANDOFF)) == 0, "fa_params::flags has unknown bits set (zero-initialise the struct)");
     FA_CHECK(p.batch > 0, "batch size must be positive");
     FA_CHECK(p.head_dim <= 256, "head dimension must be <= 256");
     FA_CHECK(p.head_dim % 8 == 0, "head dimension must be multiple of 8");

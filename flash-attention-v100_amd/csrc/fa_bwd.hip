@@ -1785,6 +1785,9 @@ __global__ void __launch_bounds__(BWD_THREADS, 2) fa_bwd_dq_from_ds_kernel(const
 // the dQ kernel drops from 0.81 to 0.53 ms, but writing the tiles costs the one-wave-per-SIMD dK/dV
 // kernel +0.29 ms (1.55 -> 1.84 ms; store issue is fully exposed there) - a wash that costs 4.3 GB.
 int launch_bwd_dkdv_split(const KArgs& a, int grid, hipStream_t stream);
+bool bwd_ds2_applicable(const fa_params& p);             // fa_bwd_dq_ds.hip: dS hand-off between the generated dK/dV kernel and a one-GEMM dQ kernel
+size_t bwd_ds2_bytes(const fa_params& p);
+int launch_bwd_dq_ds(const KArgs& a, hipStream_t stream);
 bool bwd_asm_applicable(const KArgs& a);
 size_t bwd_asm_workspace_bytes(const fa_params& p);
 int launch_bwd_dkdv_asm(const KArgs& a, hipStream_t stream);
@@ -1941,13 +1944,20 @@ static int bwd_dkv_split_for(const KArgs& a, bool asm_kernel) {
     return p.head_dim <= 64 ? dkv_split_factor(p, pair, FA_DKV2_OCC64, 64, 4) : dkv_split_factor(p, pair, 2, 32, 8);
 }
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+// dS hand-off (fa_bwd_dq_ds.hip): where both generated kernels would run, the launch fills the chip (no split) and the caller asked
+// for all three gradients
+static bool bwd_takes_ds2(const KArgs& a, bool asm_kernel, int split) {
+    return asm_kernel && split <= 1 && bwd_ds2_applicable(a.p);
+}
 size_t bwd_workspace_bytes(const fa_params& p) {
     const size_t ds = bwd_ds_workspace_bytes(p);
     if (ds > 0) return ds;
     const KArgs a = bwd_probe_args(p);
     const bool asm_kernel = bwd_asm_applicable(a);
     const size_t stats = asm_kernel ? bwd_asm_workspace_bytes(p) : 0;
-    const size_t part = dkv_split_bytes(p, bwd_dkv_split_for(a, asm_kernel));
+    const int split = bwd_dkv_split_for(a, asm_kernel);
+    if (bwd_takes_ds2(a, asm_kernel, split)) return align256(stats) + bwd_ds2_bytes(p);
+    const size_t part = dkv_split_bytes(p, split);
     return part ? align256(stats) + part : stats;
 }
 #ifdef FA_TIMERS
@@ -2087,6 +2097,8 @@ static int launch_bwd_td(const KArgs& a, hipStream_t stream) {
             FA_SET_LDS_ONCE(kern, smem);
             if (grid > 0) hipLaunchKernelGGL(kern, dim3(grid), dim3(BWD_THREADS), smem, stream, a);
         }
+    } else if ((g_bwd_phase_mask & 4) && D == 128 && a.ds2_ws) {
+        launch_bwd_dq_ds(a, stream);                      // one GEMM over the handed-off dS tiles (fa_bwd_dq_ds.hip)
     } else if ((g_bwd_phase_mask & 4) && D == 128 && bwd_dq_asm_applicable(a)) {
         launch_bwd_dq_asm(a, stream);                     // hand-scheduled body (fa_bwd_dq_asm.hip)
     } else if (g_bwd_phase_mask & 4) {
@@ -2150,11 +2162,22 @@ int launch_bwd(const KArgs& a_in, hipStream_t stream) {
             if (a.p.cu_seqlens_q) a.stats_ws = nullptr;
         }
     }
+    // dS hand-off: preprocess -> generated dK/dV kernel (+ tile stores) -> one-GEMM dQ kernel
+    a.ds2_ws = nullptr;
+    if (a.stats_ws && !a.ds_ws && bwd_takes_ds2(a, true, bwd_dkv_split_for(a, true))) {
+        const size_t off = align256(bwd_asm_workspace_bytes(a.p));
+        if (a.p.workspace_bytes >= off + bwd_ds2_bytes(a.p)) {
+            a.ds2_ws = reinterpret_cast<char*>(a.p.workspace) + off;
+            a.ds2_nqb = (a.p.seqlen_q + 31) / 32;
+            a.ds2_nkb = 4 * ((a.p.seqlen_k + 127) / 128);
+            a.fuse_pre = 0;                               // the dK/dV kernel runs first: statistics from the preprocess kernel
+        }
+    }
     // a dense dK/dV launch smaller than the chip: query tiles split over several workgroups + a reduction (dkv_split_factor)
     a.dkv_split = 0;
     a.dkv_part = nullptr;
     const bool packed = a.p.cu_seqlens_q || a.p.cu_seqlens_k;
-    if (a.p.dk && !a.ds_ws && (!packed || (a.flat_blocks && a.p.cu_seqlens_q && a.p.cu_seqlens_k))) {
+    if (a.p.dk && !a.ds_ws && !a.ds2_ws && (!packed || (a.flat_blocks && a.p.cu_seqlens_q && a.p.cu_seqlens_k))) {
         const bool asm_kernel = a.p.head_dim == 128 && a.stats_ws != nullptr;
         const int split = bwd_dkv_split_for(a, asm_kernel);
         const size_t off = align256(bwd_asm_applicable(a) ? bwd_asm_workspace_bytes(a.p) : 0);      // as bwd_workspace_bytes lays it out

@@ -488,6 +488,9 @@ struct KArgs {
     // backward: dS hand-off from the dK/dV kernel to the dQ kernel (NULL: dQ recomputes S and dP)
     void* ds_ws;                   // [B, Hq, ds_nqb, ds_nkb][2 KiB]: one 32-query x 32-key dS tile each
     int ds_nqb, ds_nkb;            // ceil(seqlen_q / 32), ceil(seqlen_k / 32)
+    // dS hand-off between the GENERATED dK/dV kernel and fa_bwd_dq_ds_kernel (fa_bwd_dq_ds.hip): [B, Hq, ds2_nkb, ds2_nqb][2 KiB]
+    void* ds2_ws;
+    int ds2_nqb, ds2_nkb;          // ceil(seqlen_q / 32), 4 * ceil(seqlen_k / 128)
     // backward, asm dK/dV kernel (fa_bwd_asm.hip): row statistics written by the preprocess kernel, or NULL
     float* stats_ws;               // [2][B][Hq][Sq]: plane 0 = LSE log2(e) (+inf where LSE = -inf), plane 1 = -D
     int skip_short_q;              // varlen forward of a mixed batch: sequences with 1 .. skip_short_q query rows are served by the

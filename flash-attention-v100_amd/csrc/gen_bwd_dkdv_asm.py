@@ -63,12 +63,21 @@ S_N0 = 73                       # q0 of the stage being masked
 S_SUB, S_RET = 74, 76
 S_MASKFN = (78, 80)
 S_DIT = 82                      # DMA stream: stage index it + 3
+# dS hand-off bodies (DKV(ds=True): the packed dS tile of every stage goes to a workspace, a one-GEMM dQ kernel reads it back -
+# fa_bwd_dq_ds.hip): descriptor over the kv-head's group of q-heads, [head][32-key block][32-row tile][2 KiB]
+S_DSRS = 84                     # in: s84..s87 buffer descriptor of the dS tiles (base: first q-head of the group)
+S_DSWRAP = 88                   # in: what the tile offset advances by at a head wrap: head bytes - (mt1 - mt0 - 1) * 2048
+S_DSN = 89                      # owned: tile offset of stage `it` (head + 32-row tile; the wave's key block rides in the lane offset)
+S_DSO = 90                      # owned: ... of stage it - 1: the stage whose tile this iteration stores
+S_DSX = 91                      # owned: S_DSO, or out of range for the virtual stages
 S_LAST = 83
+S_LAST_DS = 91
 
 # ------------------------------------------------------------------ VGPRs
 V_CBS = 16                      # in: v16..v19 = swizzled column byte of the lane's 16-byte DMA chunk for rows 4p + (lane >> 4), p = 0..3
 V_KRB, V_VRB = 42, 43           # in (uniform): bytes per K / V row
 V_DKRB, V_DVRB, V_KW0 = 208, 209, 210   # in (uniform): bytes per dK / dV row, first key of the wave
+V_DSVO = 211                    # in (dS hand-off bodies): 16 lane + byte offset of the wave's 32-key block in a head's tiles
 V_ROW = 20                      # in: 8 row-read addresses (swzt image, tile-relative)
 V_TR = 28                       # in: 8 transposed-read addresses [h][d]
 V_STB = 36                      # in: statistics read base (16 g)
@@ -104,9 +113,11 @@ NFR = 8
 
 
 class DKV(Gen):
-    def __init__(self, dtype, alibi=False):
+    def __init__(self, dtype, alibi=False, ds=False):
         Gen.__init__(self, dtype)
         self.alibi_kv = alibi
+        self.ds = ds
+        assert not (alibi and ds)
 
     def reset_dkv(self):
         self.now = 0
@@ -232,6 +243,21 @@ class DKV(Gen):
               Ins(f"buffer_load_dword v{V_DMAST}, {sr(S_STRS, 4)}, s{sst} offen lds", "raw"), Ins(f"L_ns{u}_%=:", "raw")]
         return g, st
 
+    def ds_stores(self, par, fast):
+        """dS hand-off: the packed dS of stage it - 1 (B operands of this iteration's dK MFMAs, registers of the other parity) ->
+        its 2-KiB tile: piece t = the lanes' four registers 4 t .. 4 t + 3, i.e. lane (key l31, g) leaves rows
+        16 t + 4 g + (0..3) and 16 t + 8 + 4 g + (0..3) of its key as 16 contiguous bytes; two 1-KiB stores per wave.
+        Virtual stages (it - 1 outside [0, n_iter)) store out of range (dropped by the descriptor's range check); the fast
+        copies only run real stages (the host keeps FLO >= 1 for these bodies)."""
+        so = S_DSO if fast else S_DSX
+        if self.cfg_ds.get("ds_fixed"):             # timing experiment (wrong results): every stage lands on the head's first tile - no HBM stream
+            so = "0"
+            return [Ins(f"buffer_store_dwordx4 {vr(V_DS[par] + 4 * t, 4)}, v{V_DSVO}, {sr(S_DSRS, 4)}, 0 offen" + (f" offset:{1024 * t}" if t else ""),
+                        "vmem", rl("v", V_DS[par] + 4 * t, 4) + [f"v{V_DSVO}"], []) for t in range(2)]
+        extra = (" " + self.cfg_ds["ds_bits"].replace("+", " ")) if self.cfg_ds.get("ds_bits") else ""
+        return [Ins(f"buffer_store_dwordx4 {vr(V_DS[par] + 4 * t, 4)}, v{V_DSVO}, {sr(S_DSRS, 4)}, s{so} offen" + (f" offset:{1024 * t}" if t else "") + extra,
+                    "vmem", rl("v", V_DS[par] + 4 * t, 4) + [f"v{V_DSVO}"], []) for t in range(2)]
+
     def slots(self, c):
         """copy c (0..5): it = c - 1 (mod 6) at loop entry; stage s lives in ring slot (s + 1) % 6 and in the register
         buffers of parity s & 1 -> (slot of stage it-1, of stage it+1, of the DMA target it+3, parity of it, of it+-1)"""
@@ -294,8 +320,15 @@ class DKV(Gen):
         A(f"s_cselect_b32 s{t + 3}, s{S_DQS}, s{S_OOB}")
         A(f"s_cselect_b32 s{t + 4}, s{S_DDOS}, s{S_OOB}")
         A(f"s_cselect_b32 s{t + 5}, s{S_DSTS}, s{S_OOB}")
+        if self.ds:                                                   # stage it - 1 real?  (one unsigned compare: it - 1 <u n_iter)
+            A(f"s_sub_u32 s{t}, s{S_IT}, 1")
+            A(f"s_cmp_lt_u32 s{t}, s{S_NITER}")
+            A(f"s_cselect_b32 s{S_DSX}, s{S_DSO}, s{S_OOB}")
+
+    cfg_ds = {}
 
     def gen_streams(self, c, cfg, fast):
+        self.cfg_ds = cfg
         sl_prev, sl_next, sl_dma, par_cur, par_oth = self.slots(c)
         # ---- streams
         sdp = self.sdp_stream(sl_next, par_oth)
@@ -317,6 +350,12 @@ class DKV(Gen):
         st_at = cfg.get("st_at", 26)
         d_at = cfg.get("d_at", [1, 3, 5, 7])
         l_at = cfg.get("l_at", [19, 23, 27, 30])
+        # (the two stores go out FIRST: the iteration's closing vmcnt(4) counts its four younger LOADS - loads return in order, so
+        #  "at most 4 outstanding" proves the previous iteration's pieces have landed whatever the stores do (stores and loads
+        #  complete out of order with respect to each other: a count that included them would prove nothing) - but it also
+        #  waits for the stores themselves, which therefore get the whole iteration to be acknowledged)
+        ds_at = cfg.get("ds_at", [0, 1]) if self.ds else []
+        ds_st = self.ds_stores(par_oth, fast) if self.ds else []
         M = len(mf_items)
         for k, (kind, (rd, mf)) in enumerate(mf_items):
             if issued < M:
@@ -340,6 +379,8 @@ class DKV(Gen):
                 self.emit(d_reads[d_at.index(k)])
             if k in l_at:
                 self.emit(l_reads[l_at.index(k)])
+            if k in ds_at:
+                self.emit(ds_st[ds_at.index(k)])
             take = -(-(nv - vi) // (M - k))
             for _ in range(take):
                 if vi < nv:
@@ -368,6 +409,11 @@ class DKV(Gen):
         o += [f"s_add_u32 s{S_VMT}, s{S_VMT}, 1",
               f"s_cmp_ge_i32 s{S_VMT}, s{S_MT1}",
               f"s_cselect_b32 s{S_VMT}, s{S_MT0}, s{S_VMT}"]
+        if self.ds:                         # (scc still holds the wrap: next tile of the head, or tile mt0 of the next head)
+            o += [f"s_mov_b32 s{S_DSO}, s{S_DSN}",
+                  f"s_cselect_b32 s{t}, s{S_DSWRAP}, 2048",
+                  f"s_add_u32 s{S_DSN}, s{S_DSN}, s{t}"]
+        self.n_valu_adv = len(o)
         o += [f"s_add_u32 s{S_DIT}, s{S_DIT}, 1",
               f"s_add_u32 s{S_DQS}, s{S_DQS}, s{S_QROW32}",
               f"s_add_u32 s{S_DDOS}, s{S_DDOS}, s{S_DOROW32}",
@@ -482,7 +528,7 @@ class DKV(Gen):
 
         def dma_advance():
             u = self.uid()
-            return [x.replace("{u}", str(u)) for x in self.salu_advance()[3:]]      # (the DMA stream only)
+            return [x.replace("{u}", str(u)) for x in self.salu_advance()[self.n_valu_adv:]]      # (the DMA stream only)
 
         # ---- stages 0, 1 -> slots 1, 2 (stage 2 is the first iteration's DMA)
         for slot in (1, 2):
@@ -522,6 +568,9 @@ class DKV(Gen):
         A(f"s_mov_b32 s{S_IT}, -1")
         A(f"s_mov_b32 s{S_VMT}, s{S_MT0}")
         A(f"s_sub_u32 s{S_VMT}, s{S_VMT}, 1")                      # stage -1 (virtual): advanced to mt0 before stage 0
+        if self.ds:                                                # tile offsets of the stages -1 (never stored) and -2
+            A(f"s_lshl_b32 s{S_DSN}, s{S_VMT}, 11")
+            A(f"s_mov_b32 s{S_DSO}, s{S_OOB}")
         A("s_waitcnt vmcnt(0)")
         A(f"s_lshl_b32 s{t + 5}, s{S_W1024}, 3")
         A(f"s_add_u32 s{t + 4}, s{t + 5}, {VST}")
@@ -566,7 +615,7 @@ class DKV(Gen):
             for x in self.salu_advance():
                 A(x.replace("{u}", str(u)))
             if "vmwait" not in self.ko:
-                A("s_waitcnt vmcnt(4)")      # (the wave that fetched the statistics, last, also waits for its first tile piece)
+                A(f"s_waitcnt vmcnt({cfg.get('ds_vmcnt', 4) if self.ds else 4})")      # (the wave that fetched the statistics, last, also waits for its first tile piece)
             A(f"s_add_u32 s{S_IT}, s{S_IT}, 1")
             A(f"s_cmp_le_i32 s{S_IT}, s{S_NITER}")
             if c < NRING - 1:
@@ -590,8 +639,11 @@ class DKV(Gen):
                 A(f"s_add_u32 s{S_DQS}, s{S_DQS}, s{S_QROW32}")
                 A(f"s_add_u32 s{S_DDOS}, s{S_DDOS}, s{S_DOROW32}")
                 A(f"s_add_u32 s{S_DSTS}, s{S_DSTS}, 128")
+                if self.ds:
+                    A(f"s_mov_b32 s{S_DSO}, s{S_DSN}")
+                    A(f"s_add_u32 s{S_DSN}, s{S_DSN}, 2048")
                 if "vmwait" not in self.ko:
-                    A("s_waitcnt vmcnt(4)")
+                    A(f"s_waitcnt vmcnt({cfg.get('ds_vmcnt', 4) if self.ds else 4})")
                 A(f"s_add_u32 s{S_IT}, s{S_IT}, 1")
                 A(f"s_cmp_lt_i32 s{S_IT}, s{S_FEND}")
                 A(f"s_cbranch_scc1 L_f{(c + 1) % NRING}_%=")
@@ -699,12 +751,14 @@ class DKV(Gen):
         return L, report
 
 
-def clobbers(alibi=False):
+def clobbers(alibi=False, ds=False):
     c = ["memory", "vcc", "scc", "m0"]
-    keep = (V_DKRB, V_DVRB, V_KW0) + (tuple(range(V_AA, V_SVL + 1)) if alibi else ())
+    keep = (V_DKRB, V_DVRB, V_KW0) + (tuple(range(V_AA, V_SVL + 1)) if alibi else ()) + ((V_DSVO,) if ds else ())
     c += [f"v{i}" for i in range(44, 256) if i not in keep]
     c += [f"a{i}" for i in range(256)]
     c += [f"s{i}" for i in range(S_IT, S_LAST + 1)]
+    if ds:
+        c += [f"s{i}" for i in range(S_DSN, S_LAST_DS + 1)]
     return c
 
 
@@ -721,10 +775,10 @@ def main():
     print("#pragma once")
     print(f"#define FA_BWD_ASM_LDS_BYTES {LDS_TOTAL}")
     print(f"#define FA_BWD_ASM_STATS_OFF {STATS}")
-    for alibi in (False, True):
-        tag = "ALIBI_" if alibi else ""
+    for (alibi, ds) in ((False, False), (True, False), (False, True)):
+        tag = "ALIBI_" if alibi else ("DS_" if ds else "")
         for dt in ("bf16", "f16"):
-            g = DKV(dt, alibi=alibi)
+            g = DKV(dt, alibi=alibi, ds=ds)
             g.ko = ko
             body, report = g.gen_body(cfg)
             print(f"#define FA_BWD_DKDV_ASM_{tag}BODY_{dt.upper()} \\")
@@ -733,7 +787,7 @@ def main():
             print('    ""')
             for k, (st, n) in report.items():
                 print(f"// {dt} {tag}copy {k}: {n} lines, nop states {st['nop_states']}, lgkmcnt waits {st['lgkm_waits']}")
-        cl = ", ".join(f'"{c}"' for c in clobbers(alibi))
+        cl = ", ".join(f'"{c}"' for c in clobbers(alibi, ds))
         print(f"#define FA_BWD_DKDV_ASM_{tag}CLOBBERS {cl}")
 
 

@@ -15,6 +15,7 @@ There is no CPU fallback: tensors must live on an AMD GPU and the HIP library mu
 """
 import collections
 import ctypes
+import os
 import traceback
 import warnings
 from typing import Optional, Tuple, Union
@@ -252,6 +253,11 @@ def _dense_forward(q, k, v, dropout_p, softmax_scale, causal, window_size, softc
     return res, lse, dmask, (q_, k_, v_, out_), rng, softmax_scale
 
 
+# Opt-in experiment (include/fa_mi355.h: FA_FLAG_DS_HANDOFF; break-even on BASELINE config 2, profiles/r06_ds_handoff.txt): the dense
+# D = 128 backward hands dS from the dK/dV kernel to a one-GEMM dQ kernel instead of recomputing S and dP.  FA_BWD_DS=1 at import.
+DS_HANDOFF = os.environ.get("FA_BWD_DS", "0") == "1"
+
+
 def _dense_backward(dout, q_, k_, v_, out_, lse, alibi_slopes, dropout_p, softmax_scale, causal,
                     window_size, softcap, rng, dq_, dk_, dv_, keep_window=False, deterministic=False):
     """One fa_bwd call; dq_/dk_/dv_ are caller-allocated [B, S, H, dpad] views (written in place).  dq_ = None, or
@@ -285,6 +291,8 @@ def _dense_backward(dout, q_, k_, v_, out_, lse, alibi_slopes, dropout_p, softma
         p.flags = _lib.FA_FLAG_KEEP_WINDOW
     if deterministic:
         p.flags |= _lib.FA_FLAG_NO_DKV_SPLIT
+    if DS_HANDOFF:
+        p.flags |= _lib.FA_FLAG_DS_HANDOFF
     _set_head_dim(p, dpad)
     _alibi(p, alibi_slopes, B, H_Q, q_.device)
     _philox(p, dropout_p, B, H_Q, q_.device, rng=rng)

@@ -42,6 +42,11 @@ extern "C" {
  * 16-bit partial dK / dV in fp32 (deterministic; needs the workspace fa_bwd_workspace_bytes() reports).  dK / dV then differ in
  * the last bit from the one-workgroup-per-key-block result.  FA_FLAG_NO_DKV_SPLIT keeps one workgroup per key block. */
 #define FA_FLAG_NO_DKV_SPLIT 2
+/* fa_bwd, opt-in, measured at break-even (profiles/r06_ds_handoff.txt): where the dense D = 128 backward would run its two generated
+ * kernels and all three gradients are requested, the dK/dV kernel hands its 16-bit dS tiles to a one-GEMM dQ kernel through the
+ * workspace (2 bytes per (query, key) pair and head: fa_bwd_workspace_bytes() reports it) instead of dQ recomputing S and dP.
+ * Same results up to the order of fp32 additions.  Ignored where it does not apply. */
+#define FA_FLAG_DS_HANDOFF 4
 
 typedef enum fa_dtype {
     FA_FP16 = 0,      /* IEEE half */

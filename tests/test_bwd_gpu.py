@@ -211,8 +211,8 @@ def test_unneeded_gradients_are_skipped_not_changed(S, D, H, Hk, causal, dt):
     # frozen Q: dq = NULL, the preprocess kernel provides D
     k1, v1 = k.detach().clone().requires_grad_(True), v.detach().clone().requires_grad_(True)
     flash_attn.flash_attn_func(q.detach(), k1, v1, causal=causal).backward(do)
-    assert_close(f64(k1.grad), f64(dk), dt, "dk (dk, dv only)", mult=0.25)
-    assert_close(f64(v1.grad), f64(dv), dt, "dv (dk, dv only)", mult=0.25)
+    assert_close(f64(k1.grad), f64(dk), dt, "dk (dk, dv only)", mult=0.5)
+    assert_close(f64(v1.grad), f64(dv), dt, "dv (dk, dv only)", mult=0.5)
     # only v requires grad: dk is computed with it (one kernel) and dropped
     v2 = v.detach().clone().requires_grad_(True)
     flash_attn.flash_attn_func(q.detach(), k.detach(), v2, causal=causal).backward(do)
@@ -253,8 +253,8 @@ def test_backward_without_workspace_matches(monkeypatch):
     monkeypatch.setattr(fi, "_workspace", lambda nbytes, device: None)
     got = torch.autograd.grad(o, (q, k, v), do)
     assert torch.equal(got[0], ref[0])                                   # same dQ kernel, same bits
-    assert_close(f64(got[1]), f64(ref[1]), "bf16", "dk (no workspace)", mult=0.25)
-    assert_close(f64(got[2]), f64(ref[2]), "bf16", "dv (no workspace)", mult=0.25)
+    assert_close(f64(got[1]), f64(ref[1]), "bf16", "dk (no workspace)", mult=0.5)
+    assert_close(f64(got[2]), f64(ref[2]), "bf16", "dv (no workspace)", mult=0.5)
 
 
 @pytest.mark.parametrize("dt,scale", [("fp16", 2048.0), ("fp16", 1.0 / 64.0), ("bf16", 1048576.0)])
@@ -406,3 +406,52 @@ def test_units_that_do_not_fill_a_round_of_xcds(B, Hq, Hk, D, dt, causal):
     assert_close(t(dq), g[0], dt, "dq", mult=2.0)
     assert_close(t(dk), g[1], dt, "dk", mult=2.0)
     assert_close(t(dv), g[2], dt, "dv", mult=2.0)
+
+
+# dS hand-off (opt-in: include/fa_mi355.h FA_FLAG_DS_HANDOFF, fa_bwd_dq_ds.hip): the generated dK/dV kernel stores its packed dS
+# tiles, a one-GEMM dQ kernel reads them back.  Launches that fill the chip only (smaller ones split their dK/dV pass instead).
+DS_CASES = [
+    # B, Hq, Hk, Sq, Sk, dtype, causal, window
+    (4, 16, 16, 1024, 1024, "bf16", True, (-1, -1)),
+    (2, 16, 16, 2048, 2048, "fp16", False, (-1, -1)),
+    (8, 8, 8, 1000, 1000, "bf16", True, (-1, -1)),           # ragged: partial last row tile and key block
+    (4, 16, 4, 1536, 1536, "bf16", True, (-1, -1)),          # GQA: the tile offsets wrap from head to head
+    (8, 8, 8, 700, 1300, "fp16", True, (-1, -1)),            # Sq < Sk (bottom-right aligned)
+    (8, 8, 8, 1300, 700, "bf16", True, (-1, -1)),            # Sq > Sk: rows without keys
+    (4, 16, 16, 1024, 1024, "bf16", False, (200, 0)),        # sliding window: key blocks start late
+    (4, 16, 16, 1024, 1024, "fp16", False, (100, 50)),       # two-sided window
+]
+
+
+@pytest.mark.parametrize("case", DS_CASES, ids=lambda c: "-".join(map(str, c)))
+def test_ds_handoff_backward_vs_oracle(case, monkeypatch):
+    from flash_attn_mi355 import flash_attn_interface as fi
+    B, Hq, Hk, Sq, Sk, dt, causal, window = case
+    D = 128
+    q = rand16((B, Sq, Hq, D), dt, 811).requires_grad_(True)
+    k = rand16((B, Sk, Hk, D), dt, 812).requires_grad_(True)
+    v = rand16((B, Sk, Hk, D), dt, 813).requires_grad_(True)
+    do = rand16((B, Sq, Hq, D), dt, 814)
+    real = fi._workspace
+    grads, ws = {}, {}
+    for on in (False, True):
+        monkeypatch.setattr(fi, "DS_HANDOFF", on)
+        seen = []
+        monkeypatch.setattr(fi, "_workspace", lambda n, dev: (seen.append(n), real(n, dev))[1])
+        out = _fa().flash_attn_func(q, k, v, causal=causal, window_size=window)
+        grads[on] = torch.autograd.grad(out, (q, k, v), do)
+        ws[on] = max(seen)
+        again = torch.autograd.grad(_fa().flash_attn_func(q, k, v, causal=causal, window_size=window), (q, k, v), do)
+        for a_, b_ in zip(grads[on], again):
+            assert torch.equal(a_, b_)                       # atomic-free either way
+    assert ws[True] >= ws[False] + B * Hq * ((Sq + 31) // 32) * 4 * ((Sk + 127) // 128) * 2048      # the hand-off path ran
+    sel = slice(0, 2)                                        # oracle on two batch entries (fp64 on the CPU)
+    t = lambda x: f64(x[sel]).transpose(0, 2, 1, 3)
+    o_ref, lse_ref, _ = oracle.attn_fwd(t(q), t(k), t(v), D ** -0.5, causal=causal, window=window)
+    g = oracle.attn_bwd(t(do), t(q), t(k), t(v), o_ref, lse_ref.astype(np.float64), D ** -0.5, causal=causal, window=window)
+    for on in (False, True):
+        for i, name in enumerate(("dq", "dk", "dv")):
+            assert_close(t(grads[on][i]), g[i], dt, f"{name} handoff={on}", mult=2.0)
+    # the two paths against each other: same products, another summation order for dQ (and D from another kernel)
+    for i, name in enumerate(("dq", "dk", "dv")):
+        assert_close(f64(grads[True][i]), f64(grads[False][i]), dt, f"{name} handoff vs recompute", mult=0.5)

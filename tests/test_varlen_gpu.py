@@ -542,7 +542,7 @@ def test_packed_batch_past_2gib_of_q():
     assert torch.equal(d4(out), out_d)                       # same kernel bodies, same tiles: the same bits
     assert torch.equal(lse.view(H, nseq, S).transpose(0, 1), lse_d)
     for name, a_, b_ in zip(("dq", "dk", "dv"), (dq, dk, dv), gd):
-        assert_close(f64(d4(a_)[-2:]), f64(b_[-2:]), dt, name + " packed vs dense", mult=0.25)
+        assert_close(f64(d4(a_)[-2:]), f64(b_[-2:]), dt, name + " packed vs dense", mult=0.5)
 
     s0, h = T - S, 31                                        # last sequence (byte offset 2.4 GB), last head
     t = lambda x: f64(x[s0:, h])[None, None]

@@ -247,3 +247,33 @@ def test_kvcache_plan_table_is_lru():
         assert ("g", 0) in fi._KV_PLANS and ("g", 1) not in fi._KV_PLANS and len(fi._KV_PLANS) == fi._KV_PLANS_MAX
     finally:
         fi._KV_PLANS.clear(); fi._KV_PLANS.update(saved)
+
+
+def test_backward_ds_handoff_workspace(lib):
+    """FA_FLAG_DS_HANDOFF (opt-in): where the dense D = 128 backward runs its two generated kernels, fills the chip (no split
+    launch) and all three gradients are requested, the workspace grows by the dS tiles - [B][Hq][4 ceil(Sk / 128)][ceil(Sq / 32)]
+    tiles of 2 KiB behind the statistics planes (fa_bwd_dq_ds.hip); anywhere else the flag changes nothing."""
+    q = lib.lib.fa_bwd_workspace_bytes
+    al = lambda x: (x + 255) & ~255
+    p = _dense(lib, 8, 4096, 16, 16, 128)
+    base = q(ctypes.byref(p))
+    p.flags = lib.FA_FLAG_DS_HANDOFF
+    assert q(ctypes.byref(p)) == base                        # (no gradient pointers yet: dq / dk / dv all have to be asked for)
+    p.dq = p.dk = p.dv = 4096                                # (any non-NULL value: the query only tests the pointers)
+    assert q(ctypes.byref(p)) == al(2 * 8 * 16 * 4096 * 4) + 8 * 16 * 128 * 128 * 2048
+    p.dq = 0
+    assert q(ctypes.byref(p)) == base
+    p = _dense(lib, 2, 1000, 8, 8, 128)                      # ragged: 32 row tiles, 4 x 8 key blocks
+    p.dq = p.dk = p.dv = 4096
+    p.flags = lib.FA_FLAG_DS_HANDOFF | lib.FA_FLAG_NO_DKV_SPLIT
+    assert q(ctypes.byref(p)) == al(2 * 2 * 8 * 1000 * 4) + 2 * 8 * 32 * 32 * 2048
+    for change in ("head64", "dropout", "softcap", "split"):
+        p = _dense(lib, 8, 4096, 16, 16, 64 if change == "head64" else 128) if change != "split" else _dense(lib, 1, 4096, 32, 8, 128)
+        p.dq = p.dk = p.dv = 4096
+        if change == "dropout":
+            p.p_dropout = 0.1
+        if change == "softcap":
+            p.softcap = 30.0
+        want = q(ctypes.byref(p))
+        p.flags = lib.FA_FLAG_DS_HANDOFF
+        assert q(ctypes.byref(p)) == want, change            # other kernels / a split launch: the flag is ignored

@@ -7,8 +7,12 @@ import torch
 DT = {"fp16": torch.float16, "bf16": torch.bfloat16}
 # normalised max error |got-ref|_max / |ref|_max and relative Frobenius error.  The io
 # rounding floor alone is 2^-11 (fp16) / 2^-8 (bf16) relative per element.
-TOL_MAXREL = {"fp16": 2e-3, "bf16": 1.6e-2}
-TOL_FRO = {"fp16": 1e-3, "bf16": 6e-3}
+# Calibrated in round 6 against what the kernels ACHIEVE over the whole GPU suite (FA_TOL_LOG=<file> logs every assertion:
+# 828 of them; worst bf16 max-rel 6.5e-3 / Frobenius 3.8e-3, fp16 8.3e-4 / 8.0e-4): with the `mult` the tests pass (1 forward,
+# 1.5 - 2 gradients, 3 dropout) a gate sits at about twice the worst case of its dtype - a 1 % systematic error in a
+# bf16-only variant no longer passes (round 5: 1.6e-2 x 2, five times what the kernels do).
+TOL_MAXREL = {"fp16": 1.0e-3, "bf16": 7e-3}
+TOL_FRO = {"fp16": 6e-4, "bf16": 4e-3}
 
 
 def rand16(shape, dtype, seed, scale=1.0, device="cuda"):
