@@ -13,10 +13,11 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 OUT_DIR = os.path.join(HERE, "flash_attn_mi355")
 LIB = os.path.join(OUT_DIR, "libfa_mi355.so")
-SOURCES = ["fa_api.hip", "fa_fwd.hip", "fa_fwd_asm.hip", "fa_bwd.hip", "fa_bwd_d256.hip", "fa_bwd_asm.hip", "fa_bwd_dq_asm.hip", "fa_bwd_dq_ds.hip", "fa_kvcache.hip", "fa_decode.hip", "fa_rows.hip"]
+SOURCES = ["fa_api.hip", "fa_fwd.hip", "fa_fwd_d256.hip", "fa_fwd_asm.hip", "fa_bwd.hip", "fa_bwd_d256.hip", "fa_bwd_asm.hip", "fa_bwd_dq_asm.hip", "fa_bwd_dq_ds.hip", "fa_kvcache.hip", "fa_decode.hip", "fa_rows.hip"]
 GENERATED = [("gen_fwd_asm.py", "fa_fwd_asm_gen.h", []),
              ("gen_bwd_dkdv_asm.py", "fa_bwd_asm_gen.h", []),
              ("gen_bwd_dq_asm.py", "fa_bwd_dq_asm_gen.h", [])]  # (generator, header, arguments): hand-scheduled asm bodies
+EXTRA_FLAGS = {"fa_fwd_d256.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}      # per-source compiler switches (see the file's header)
 ASM_SOURCES = ("fa_fwd_asm.hip", "fa_bwd_asm.hip", "fa_bwd_dq_asm.hip")   # kernels whose body is one hand-scheduled asm statement
 RESOURCES = os.path.join(OUT_DIR, "kernel_resources.json")              # their register / scratch use, checked at build time
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"),
@@ -36,6 +37,7 @@ def _digest(paths):
         h.update(p.encode())
         h.update(open(p, "rb").read())
     h.update(" ".join(FLAGS).encode())
+    h.update(repr(sorted(EXTRA_FLAGS.items())).encode())
     return h.hexdigest()
 
 
@@ -107,7 +109,7 @@ def build(force=False, verbose=False, defines=(), out=None):
         obj = os.path.join(bdir, src.replace(".hip", ".o"))
         objs.append(obj)
         extra = ["-Rpass-analysis=kernel-resource-usage"]         # every kernel's registers / spills / scratch -> kernel_resources.json
-        cmd = [hipcc] + FLAGS + extra + ["-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + extra + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
@@ -157,7 +159,7 @@ def _build_variant(defines, out, verbose):
     for src in SOURCES:
         obj = os.path.join(bdir, src.replace(".hip", ".o"))
         objs.append(obj)
-        cmd = [hipcc] + FLAGS + [d if d.startswith("-") else "-D" + d for d in defines] + ["-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + [d if d.startswith("-") else "-D" + d for d in defines] + ["-c", os.path.join(CSRC, src), "-o", obj]
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
     for src, pr in procs:
         o, _ = pr.communicate()

@@ -851,6 +851,16 @@ static int launch_fwd_td(const KArgs& a, bool paged, hipStream_t stream) {
     return 0;
 }
 
+// The head-dim-256 instantiations live in their own translation unit (fa_fwd_d256.hip = this file under FA_FWD_TU_D256, built with
+// -mllvm -amdgpu-mfma-vgpr-form): at one wave per SIMD hipcc otherwise selects every MFMA in accumulator form, S lands in AGPRs, the
+// softmax's operands bounce through v_accvgpr_read and the kernel spills 38 - 156 registers of 512 (round-5 review: "one wave per
+// SIMD with 512 registers should not spill"); with VGPR-form MFMAs none does (tests/test_build_resources.py, csrc/spill_budget.json).
+int launch_fwd_d256(const KArgs& a, bool paged, hipStream_t stream);
+#ifdef FA_FWD_TU_D256
+int launch_fwd_d256(const KArgs& a, bool paged, hipStream_t stream) {
+    return a.p.dtype == FA_BF16 ? launch_fwd_td<bf16_tag, 256>(a, paged, stream) : launch_fwd_td<fp16_tag, 256>(a, paged, stream);
+}
+#else
 bool fwd_asm_applicable(const KArgs& a);
 int launch_fwd_asm(const KArgs& a, hipStream_t stream);
 
@@ -869,9 +879,10 @@ int launch_fwd(const KArgs& a0, hipStream_t stream) {
     switch (a.p.head_dim) {
         case 64:  return bf ? launch_fwd_td<bf16_tag, 64>(a, paged, stream) : launch_fwd_td<fp16_tag, 64>(a, paged, stream);
         case 128: return bf ? launch_fwd_td<bf16_tag, 128>(a, paged, stream) : launch_fwd_td<fp16_tag, 128>(a, paged, stream);
-        case 256: return bf ? launch_fwd_td<bf16_tag, 256>(a, paged, stream) : launch_fwd_td<fp16_tag, 256>(a, paged, stream);
+        case 256: return launch_fwd_d256(a, paged, stream);
         default:  return -2;
     }
 }
+#endif   // FA_FWD_TU_D256
 
 }  // namespace fa

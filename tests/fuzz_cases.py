@@ -19,7 +19,14 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "flash-attention-v100_amd"))
 
 import oracle                                                     # noqa: E402
-from util import DT, TOL_FRO, TOL_MAXREL, f64, rand16             # noqa: E402
+from util import DT, f64, rand16                                  # noqa: E402
+
+# The differential fuzz draws TINY shapes as well (two rows, one head, one visible key): there a gradient element can be a single
+# 16-bit rounding of a sum that cancels, and "max error / max reference" over a handful of elements is not the statistic the
+# calibrated gates of tests/util.py (about 2 x the worst case of the fixed GPU suite) were measured on.  The fuzz keeps the
+# wider round-1..5 constants; its job is to find wrong masks, offsets and races over thousands of shapes, not last-bit drift.
+TOL_MAXREL = {"fp16": 2e-3, "bf16": 1.6e-2}
+TOL_FRO = {"fp16": 1e-3, "bf16": 6e-3}
 
 EDGES = (1, 2, 31, 32, 33, 63, 64, 65, 96, 127, 128, 129, 191, 192, 193, 255, 256, 257, 320, 383, 384, 385, 511, 512,
          513, 640, 767, 768, 769)

@@ -415,7 +415,7 @@ DS_CASES = [
     (4, 16, 16, 1024, 1024, "bf16", True, (-1, -1)),
     (2, 16, 16, 2048, 2048, "fp16", False, (-1, -1)),
     (8, 8, 8, 1000, 1000, "bf16", True, (-1, -1)),           # ragged: partial last row tile and key block
-    (4, 16, 4, 1536, 1536, "bf16", True, (-1, -1)),          # GQA: the tile offsets wrap from head to head
+    (8, 32, 8, 1536, 1536, "bf16", True, (-1, -1)),          # GQA: the tile offsets wrap from head to head (64 units x 6 pairs fill the chip)
     (8, 8, 8, 700, 1300, "fp16", True, (-1, -1)),            # Sq < Sk (bottom-right aligned)
     (8, 8, 8, 1300, 700, "bf16", True, (-1, -1)),            # Sq > Sk: rows without keys
     (4, 16, 16, 1024, 1024, "bf16", False, (200, 0)),        # sliding window: key blocks start late
