@@ -12,7 +12,8 @@ function linearly with the in-order LDS return queue:
     return out of order, but they are NOT in the queue: the counter is (outstanding LDS + outstanding SMEM), so "counter <= n"
     bounds the outstanding LDS instructions by n whether the scalar loads have returned or not (pending ones only make the
     wait stricter) - which is also why the hand-placed counts never include them;
-  * any other instruction that names a register of an outstanding transposing read's destination is a violation.
+  * any other instruction that names a register of an outstanding transposing read's destination is a violation;
+  * the replay is linear (fall-through paths): the queue is dropped at s_endpgm / s_branch / s_setpc.
 
   python tools/isa_lds_check.py            -> per-object summary, exit code 1 on a violation
 Used by tests/test_build_resources.py::test_transposed_lds_reads_are_waited_for_before_use.
@@ -81,8 +82,8 @@ def check_function(name, code):
                 n = int(m.group(1))
                 queue = queue[len(queue) - n:] if 0 < n < len(queue) else ([] if n == 0 else queue)
             continue
-        if op == "s_endpgm":
-            queue = []
+        if op in ("s_endpgm", "s_branch", "s_setpc_b64"):   # what follows an unconditional jump is not reached from here (the replay is
+            queue = []                                       # linear: it covers fall-through paths, i.e. the straight-line tile loops)
             continue
         touched = regs_of(ins)
         for kind, dst, text in queue:
