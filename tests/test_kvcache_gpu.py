@@ -4,7 +4,7 @@ import pytest
 import torch
 
 import oracle
-from util import DT, assert_close, assert_lse_close, f64, rand16
+from util import LSE_ATOL_FP8, DT, assert_close, assert_lse_close, f64, rand16
 
 pytestmark = pytest.mark.gpu
 
@@ -69,7 +69,7 @@ def test_kvcache_vs_oracle(case):
     assert np.abs(f64(kc) - kc_ref).max() <= tol * max(1.0, np.abs(kc_ref).max())
     assert np.array_equal(f64(vc), vc_ref)
     assert_close(f64(out), o_ref, dt, "out", mult=2.0 if rd else 1.0)
-    assert_lse_close(f64(lse), lse_ref, "lse", atol=2e-2 if rd else 2e-3)
+    assert_lse_close(f64(lse), lse_ref, "lse")
 
 
 @pytest.mark.parametrize("page", [64, 256, 16, 32, 80])
@@ -96,7 +96,7 @@ def test_kvcache_paged_with_rotary(page):
     assert np.abs(f64(kc) - kc_ref).max() <= 2.0 ** -10 * max(1.0, np.abs(kc_ref).max())
     assert np.array_equal(f64(vc), vc_ref)
     assert_close(f64(out), o_ref, dt, "out", mult=2.0)
-    assert_lse_close(f64(lse), lse_ref, "lse", atol=2e-2)
+    assert_lse_close(f64(lse), lse_ref, "lse")
 
 
 def test_kvcache_argument_errors():
@@ -177,7 +177,7 @@ def test_decode_fp8_kv_cache(Hk):
     assert (got_k != kc_ref).mean() < 1e-3
     assert np.array_equal(got_v, vc_ref)
     assert_close(f64(out), o_ref, dt, "out", mult=1.5)
-    assert_lse_close(f64(lse), lse_ref, "lse", atol=3e-2)
+    assert_lse_close(f64(lse), lse_ref, "lse", atol=LSE_ATOL_FP8)
 
 
 @pytest.mark.parametrize("Tq,Hq,Hk,D,paged,causal,window,rot", [
@@ -219,7 +219,7 @@ def test_fp8_cache_multi_token_queries(Tq, Hq, Hk, D, paged, causal, window, rot
                                         causal=causal, window=window, rotary_interleaved=False, io_dtype=dt,
                                         k_descale=kd, v_descale=vd)
     assert_close(f64(out), o_ref, dt, "out", mult=1.5)
-    assert_lse_close(f64(lse), lse_ref, "lse", atol=3e-2)
+    assert_lse_close(f64(lse), lse_ref, "lse", atol=LSE_ATOL_FP8)
     if rot:
         return                     # (a second call would need the rotated q again: only the append call carries the tables)
     # and the explicit split-KV path gives the same rows
@@ -298,7 +298,7 @@ def test_fp8_cache_with_alibi_or_softcap(Tq, softcap, alibi):
                                         alibi_slopes=None if slopes is None else f64(slopes), io_dtype=dt,
                                         k_descale=kd, v_descale=vd)
     assert_close(f64(out), o_ref, dt, "out", mult=1.5)
-    assert_lse_close(f64(lse), lse_ref, "lse", atol=3e-2)
+    assert_lse_close(f64(lse), lse_ref, "lse", atol=LSE_ATOL_FP8)
 
 
 @pytest.mark.parametrize("B,Tq,Hq,Hk,D,dt,kv8,paged,softcap,alibi,nsplit", [
@@ -348,7 +348,7 @@ def test_decode_with_softcap_or_alibi(B, Tq, Hq, Hk, D, dt, kv8, paged, softcap,
                                         block_table=None if bt is None else bt.numpy(), causal=causal, softcap=softcap,
                                         alibi_slopes=None if slopes is None else f64(slopes), io_dtype=dt, **okw)
     assert_close(f64(out), o_ref, dt, "out", mult=1.5 if kv8 else 1.0)
-    assert_lse_close(f64(lse), lse_ref, "lse", **(dict(atol=3e-2) if kv8 else {}))
+    assert_lse_close(f64(lse), lse_ref, "lse", **(dict(atol=LSE_ATOL_FP8) if kv8 else {}))
 
 
 @pytest.mark.parametrize("B,Tq,Hq,Hk,D,dt,paged,rot,softcap,nsplit", [
@@ -397,7 +397,7 @@ def test_decode_head_dims_256_and_narrow(B, Tq, Hq, Hk, D, dt, paged, rot, softc
     assert np.array_equal(f64(vc), vc_ref)
     assert out.shape == q.shape
     assert_close(f64(out), o_ref, dt, "out", mult=2.0 if rot else 1.0)
-    assert_lse_close(f64(lse), lse_ref, "lse", **(dict(atol=2e-2) if rot else {}))
+    assert_lse_close(f64(lse), lse_ref, "lse")
 
 
 @pytest.mark.parametrize("nw", ["4", "8"])
@@ -452,11 +452,11 @@ def test_full_size_config4_decode_paged_rotary_fp8():
                                             causal=True, rotary_interleaved=False, io_dtype=dt,
                                             k_descale=kd, v_descale=vd)
         assert_close(f64(out[b:b + 1]), o_ref, dt, f"out[{b}]", mult=1.5)
-        # gate 3e-2 = 15 x the 16-bit gate: the APPENDED key reaches the scores as an e4m3 code (2^-4 relative on one of
-        # 8193 logits) while the oracle attends to the 16-bit row; what the kernels actually achieve is printed (pytest -s)
-        # and recorded in profiles/r04_fp8_decode.txt
-        achieved = assert_lse_close(f64(lse[b:b + 1]), lse_ref, f"lse[{b}]", atol=3e-2)
-        print(f"config-4 fp8 decode, batch entry {b}: max |LSE - oracle| = {achieved:.3e} (gate 3e-2)")
+        # the 16-bit gate (2e-3): the oracle quantises the appended row to e4m3 as the op does, so what is left is an occasional
+        # neighbouring fp8 code of one appended element (RoPE in 16-bit vs fp64 arithmetic) on one of 8193 logits - the kernels achieve
+        # 1e-6 .. 2e-6 here (printed with pytest -s; round 5 carried a 3e-2 gate from before the oracle quantised the append)
+        achieved = assert_lse_close(f64(lse[b:b + 1]), lse_ref, f"lse[{b}]")
+        print(f"config-4 fp8 decode, batch entry {b}: max |LSE - oracle| = {achieved:.3e} (gate 2e-3)")
         # the appended row: logical position L -> page L // 256, row L % 256 of this entry's table
         phys = int(bt[b, L // page])
         got_k = kc[phys, L % page].float().double().cpu().numpy()
@@ -490,7 +490,7 @@ def test_kvcache_paged_chunk_prefill_general_path(lp_kind):
                                         causal=True, io_dtype=dt)
     assert np.array_equal(f64(kc), kc_ref) and np.array_equal(f64(vc), vc_ref)
     assert_close(f64(out), o_ref, dt, "out", mult=1.5)
-    assert_lse_close(f64(lse), lse_ref, "lse", atol=2e-2)
+    assert_lse_close(f64(lse), lse_ref, "lse")
 
 
 @pytest.mark.parametrize("B,Tq,Hq,Hk,page,lens,dt,contig", [
@@ -542,7 +542,7 @@ def test_kvcache_chunked_prefill_on_the_hand_scheduled_forward(B, Tq, Hq, Hk, pa
                                         cache_seqlens=seqlens.numpy(), block_table=None if bt is None else bt.numpy(),
                                         causal=True, io_dtype=dt)
     assert_close(f64(out), o_ref, dt, "out", mult=1.5)
-    assert_lse_close(f64(lse), lse_ref, "lse", atol=2e-3)
+    assert_lse_close(f64(lse), lse_ref, "lse")
 
 
 def test_kvcache_edge_cases():
@@ -684,7 +684,7 @@ def test_fp8_decode_keeps_the_mass_of_many_small_probabilities(Hq, Hk, dt):
                                         cache_seqlens=lens.numpy(), block_table=bt.numpy(), causal=True, io_dtype=dt,
                                         k_descale=kd, v_descale=vd)
     assert_close(f64(out), o_ref, dt, "out", mult=1.5)
-    assert_lse_close(f64(lse), lse_ref, "lse", atol=2e-3)
+    assert_lse_close(f64(lse), lse_ref, "lse", atol=2e-3)            # (fp8 cache, many small probabilities: achieved 9.4e-4)
     s0 = (f64(q)[0, 0, 0] @ (kc.float().double().cpu().numpy()[bt[0].long().numpy()].reshape(-1, Hk, D)[:, 0].T * kd)) * D ** -0.5
     p0 = np.exp(s0 - s0.max())
     # (the construction does what it says: in the first head's row the ~2e-4 probabilities hold almost half of the mass)

@@ -46,12 +46,22 @@ def assert_close(got, ref, dtype, name, mult=1.0):
     return mr, fro
 
 
-def assert_lse_close(got, ref, name, atol=2e-3):
+# LSE gates, calibrated like the element gates (FA_TOL_LOG over the forward / varlen / kv-cache / parity files): every 16-bit path lands
+# within 1e-5 of the fp64 oracle (worst: 9.8e-6, dense forward; most 1e-6 = one or two fp32 ulps of values around 5), fp8 caches within
+# 3.9e-3 (the scores themselves carry e4m3 operands).  Round 5 gated at 2e-3 / 2e-2 / 3e-2.
+LSE_ATOL = 5e-5
+LSE_ATOL_FP8 = 8e-3
+
+
+def assert_lse_close(got, ref, name, atol=LSE_ATOL):
     got = np.asarray(got, dtype=np.float64)
     ref = np.asarray(ref, dtype=np.float64)
     inf_ref = np.isneginf(ref)
     assert (np.isneginf(got) == inf_ref).all(), f"{name}: -inf pattern differs"
     d = np.abs(got[~inf_ref] - ref[~inf_ref])
+    if d.size and os.environ.get("FA_TOL_LOG"):
+        with open(os.environ["FA_TOL_LOG"], "a") as f:
+            f.write(f"lse\t{atol}\t{d.max():.4e}\t0\t{os.environ.get('PYTEST_CURRENT_TEST', '')}\t{name}\n")
     if d.size:
         assert d.max() <= atol, f"{name}: LSE max abs diff {d.max():.3e}"
     return d.max() if d.size else 0.0
