@@ -27,7 +27,10 @@
 namespace fa {
 
 constexpr int DQS_BM = 256;                      // query rows per workgroup (64 per wave)
-constexpr int DQS_NST = 6;                       // ring stages: five 32-key stages (80 KiB of dS per CU) in flight
+#ifndef DQS_NST_V
+#define DQS_NST_V 6
+#endif
+constexpr int DQS_NST = DQS_NST_V;                       // ring stages: five 32-key stages (80 KiB of dS per CU) in flight
 constexpr int DQS_KT = 32 * 256;                 // K rows of one 32-key stage (shared by the four waves)
 constexpr int DQS_STAGE = DQS_KT + 4 * 2 * 2048; // + two dS tiles per wave
 constexpr int DQS_LDS = DQS_NST * DQS_STAGE;     // 144 KiB
@@ -157,11 +160,13 @@ __global__ void __launch_bounds__(256, 1) fa_bwd_dq_ds_kernel(const KArgs a) {
         };
         auto mfmas = [&](Frag& f, int) {                     // twelve younger reads (the next group) may be in flight
             asm volatile("s_waitcnt lgkmcnt(12)" : "+v"(f.b[0]), "+v"(f.b[1]), "+v"(f.a[0]), "+v"(f.a[1]), "+v"(f.a[2]), "+v"(f.a[3]));
+#ifndef DQS_KO_MFMA                                      // (timing experiment: -DDQS_KO_MFMA streams the tiles without the products)
 #pragma unroll
             for (int d = 0; d < 4; ++d) {
                 acc[0][d] = E::mfma(f.a[d], f.b[0], acc[0][d]);
                 acc[1][d] = E::mfma(f.a[d], f.b[1], acc[1][d]);
             }
+#endif
         };
         __builtin_amdgcn_s_barrier();                                     // the previous pass is done with the ring
 #pragma unroll
