@@ -335,6 +335,7 @@ def _split_bytes(B, Hq, Hk, Sq, Sk, D, dt, causal, window, flags):
 def test_small_dkdv_launches_split_their_query_rows(case, monkeypatch):
     from flash_attn_mi355 import _lib, flash_attn_interface as fi
     B, Hq, Hk, Sq, Sk, D, dt, causal, window = case
+    monkeypatch.setattr(fi, "DS_HANDOFF", False)             # (an FA_BWD_DS=1 environment would hand the UNSPLIT call's dS over: another dQ kernel)
     # the split is on for this shape: it asks for partial slabs on top of the unsplit call's workspace
     assert _split_bytes(*case, 0) > _split_bytes(*case, _lib.FA_FLAG_NO_DKV_SPLIT)
     q = rand16((B, Sq, Hq, D), dt, 521).requires_grad_(True)
