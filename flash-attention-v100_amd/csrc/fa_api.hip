@@ -15,6 +15,7 @@
 
 namespace fa {
 int launch_fwd(const KArgs& a, hipStream_t stream);
+size_t fwd_split_workspace_bytes(const KArgs& a);        // fa_fwd_asm.hip: forward key split of one-wave causal launches
 int launch_gather_rows(const void* src, const int64_t* idx, void* dst, int64_t n_idx, int64_t row_bytes,
                        int64_t src_stride, int64_t n_src_rows, hipStream_t stream);
 int launch_scatter_rows(const void* src, const int64_t* idx, void* dst, int64_t n_idx, int64_t n_dst_rows,
@@ -65,7 +66,7 @@ static int check_common(const fa_params& p, bool need_out) {
     FA_CHECK(p.q && (no_keys || (p.k && p.v)), "q, k, v must not be NULL");
     FA_CHECK(!need_out || (p.o && p.lse), "o and lse must not be NULL");
     FA_CHECK(p.dtype == FA_FP16 || p.dtype == FA_BF16, "q must be fp16 or bf16");
-    FA_CHECK((p.flags & ~(FA_FLAG_KEEP_WINDOW | FA_FLAG_NO_DKV_SPLIT | FA_FLAG_DS_HANDOFF)) == 0, "fa_params::flags has unknown bits set (zero-initialise the struct)");
+    FA_CHECK((p.flags & ~(FA_FLAG_KEEP_WINDOW | FA_FLAG_NO_DKV_SPLIT | FA_FLAG_DS_HANDOFF | FA_FLAG_FWD_KEY_SPLIT)) == 0, "fa_params::flags has unknown bits set (zero-initialise the struct)");
     FA_CHECK(p.batch > 0, "batch size must be positive");
     FA_CHECK(p.head_dim <= 256, "head dimension must be <= 256");
     FA_CHECK(p.head_dim % 8 == 0, "head dimension must be multiple of 8");
@@ -206,6 +207,13 @@ size_t fa_fwd_workspace_bytes(const fa_params* p) {
     if (!p) return 0;
     if (varlen_decode_route(*p, d)) return fa::decode_workspace_bytes(d);
     if (varlen_mixed_route(*p, d)) return fa::decode_workspace_bytes(d);
+    if (!p->cu_seqlens_q && !p->cu_seqlens_k && !p->block_table && p->seqlen_q > 0 && p->seqlen_k > 0 && p->kv_dtype == p->dtype) {
+        // fa_fwd: partial outputs of a key-split one-wave causal launch (the struct as fa_fwd will see it)
+        fa_params q = *p;
+        q.seqused_k = nullptr;
+        normalize(q, false);
+        return fa::fwd_split_workspace_bytes(make_args(q, 128));
+    }
     return 0;
 }
 size_t fa_bwd_workspace_bytes(const fa_params* pp) {

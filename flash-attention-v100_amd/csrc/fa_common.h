@@ -468,6 +468,7 @@ static inline bool asm_256row_blocks_pay(int seqlen_q, bool paired) {
 }
 
 // Host-side launch args: the ABI struct plus derived values.
+constexpr int FA_FS_MAX_ITEMS = 64, FA_FS_MAX_BLOCKS = 32;
 struct KArgs {
     fa_params p;
     int n_qblocks;         // q-blocks per (batch, head) in the GRID (halved when pairing)
@@ -488,6 +489,14 @@ struct KArgs {
     // backward: dS hand-off from the dK/dV kernel to the dQ kernel (NULL: dQ recomputes S and dP)
     void* ds_ws;                   // [B, Hq, ds_nqb, ds_nkb][2 KiB]: one 32-query x 32-key dS tile each
     int ds_nqb, ds_nkb;            // ceil(seqlen_q / 32), ceil(seqlen_k / 32)
+    // forward key split of one-wave causal launches (fa_fwd_asm.hip: launch_asm_t): fs_items > 0: the work list per (batch, head) is
+    // fs_items entries (heaviest first) of (256-row block, key-tile range, part); blocks from fs_qb0 on are split into fs_parts[qb]
+    // parts whose fp32 partial O / LSE land in fs_o / fs_lse ([part][B][Hq][rows from fs_qb0 * 256][128] / [..][rows])
+    int fs_items, fs_qb0, fs_max_parts;
+    uint8_t fs_qb[FA_FS_MAX_ITEMS], fs_part[FA_FS_MAX_ITEMS], fs_parts[FA_FS_MAX_BLOCKS];
+    uint16_t fs_t0[FA_FS_MAX_ITEMS], fs_t1[FA_FS_MAX_ITEMS];
+    float* fs_o;
+    float* fs_lse;
     // dS hand-off between the GENERATED dK/dV kernel and fa_bwd_dq_ds_kernel (fa_bwd_dq_ds.hip): [B, Hq, ds2_nkb, ds2_nqb][2 KiB]
     void* ds2_ws;
     int ds2_nqb, ds2_nkb;          // ceil(seqlen_q / 32), 4 * ceil(seqlen_k / 128)

@@ -97,6 +97,10 @@ S_KB, S_VB = 87, 89      # in: words 0, 1 of the K / V descriptor of this kv-hea
 S_BT = 92                # in: s[92:93] this sequence's block-table row (an aligned pair)
 S_PSH, S_PMASK = 91, 94  # in: log2(tiles per page), tiles per page - 1
 S_KPAGE, S_VPAGE = 95, 96   # in: bytes between pages
+S_P32 = 87               # in (plain D = 128 bodies only - the paged bodies use s87..s97): != 0: this launch item is ONE PART of a 256-row block
+                         # whose key range is split over several workgroups (fa_fwd_asm.hip: forward key split of one-wave causal launches);
+                         # the epilogue then leaves the part's normalised O in fp32 (the O descriptor / row bytes describe rows of 128
+                         # floats in the workspace) and its own LSE - fwd_split_merge_kernel combines the parts
 S_SEQK = 97              # in: keys of this sequence (rows past it read as zeros: V rows of a page's unused tail may hold anything)
 S_BLKK, S_BLKV, S_BLKN = 98, 99, 100     # owned: page of the K tile fetched this iteration (j + 4), of the V tile (j + 3), of the next K tile (in flight)
 
@@ -1110,6 +1114,10 @@ class Gen:
         A("s_nop 4")
         A(f"v_add_u32 v{E + 6}, s{t + 2}, v{E + 6}")               # global row
         A(f"v_mad_u32_u24 v{goff}, v{E + 6}, s{t + 1}, v{E + 7}")  # byte offset of the lane's chunk
+        split_ep = (HD == 128) and not self.alibi and not self.paged
+        if split_ep:
+            A(f"s_cmp_eq_u32 s{S_P32}, 0")
+            A("s_cbranch_scc0 L_ep32_%=")
         A(f"s_lshl_b32 s{t + 1}, s{t + 1}, {2 if EP_ROWS == 4 else 3}")   # EP_ROWS rows further
         A("s_nop 7")
         for qb in range(2):
@@ -1152,6 +1160,47 @@ class Gen:
                 A(f"s_add_u32 s{t + 3}, s{t + 3}, s{t + 1}")
             A("s_nop 1")
         # (no wait for the stores: their data left the registers at issue, and nothing below reads what they write)
+        if split_ep:
+            # ---- epilogue of a PART of a key-split block: normalised O in fp32, 16 bytes per lane straight from the accumulators
+            # (lane = query row l31 of the 32-row block, registers = d: 32 d + 8 r4 + 4 g + (0..3) are four consecutive floats of the
+            # row), the part's LSE like a whole block's.  32-byte runs per row and instruction: ~2 % of a pass, and the rows are
+            # read back from L2 by the merge kernel.
+            A("s_branch L_epend_%=")
+            A("L_ep32_%=:")
+            A(f"v_add_u32 v{E + 6}, s{t + 2}, v{E + 4}")                # global row of the lane's accumulator column (q-block 0)
+            A(f"v_lshlrev_b32 v{E + 7}, 4, v{E + 5}")                   # 16 g
+            A("s_nop 1")
+            A(f"v_mad_u32_u24 v{goff}, v{E + 6}, s{t + 1}, v{E + 7}")   # row * row bytes + 16 g
+            A(f"s_lshl_b32 s{t + 3}, s{t + 1}, 5")                      # q-block 1: 32 rows further
+            A("s_nop 7")
+            for qb in range(2):
+                l, mrun = f"v{V_L[qb]}", f"v{V_MRUN[qb]}"
+                ta, lt, inv, lse, zero = f"v{T}", f"v{T + 1}", f"v{T + 2}", f"v{T + 3}", f"v{T + 4}"
+                A(f"v_add_f32 {l}, {l}, v{V_L2[qb]}")
+                A(f"v_mov_b32 {ta}, {l}")
+                A("s_nop 1")
+                A(f"v_permlane32_swap_b32 {ta}, {l}")
+                A(f"v_add_f32 {lt}, {ta}, {l}")
+                A(f"v_rcp_f32 {inv}, {lt}")
+                A(f"v_log_f32 {lse}, {lt}")
+                A(f"v_mov_b32 {zero}, 0")
+                A(f"v_cmp_lt_f32 vcc, 0, {lt}")
+                A(f"v_cndmask_b32 {inv}, {zero}, {inv}, vcc")
+                A(f"v_add_f32 {lse}, {lse}, {mrun}")
+                A(f"v_mul_f32 {lse}, 0x3f317218, {lse}")
+                A(f"buffer_store_dword {lse}, v{V_LSEOFF[qb]}, {sr(S_LRS, 4)}, 0 offen")
+                so = "0" if qb == 0 else f"s{t + 3}"
+                for d in range(DB):
+                    for r4 in range(4):
+                        base = A_O[qb] + 16 * d + 4 * r4
+                        tt = T + 8 + 4 * (r4 & 1)                      # (v60..v67 as in the 16-bit epilogue: v70 / v71 hold q-block 1's second row sum)
+                        for e in range(4):
+                            A(f"v_accvgpr_read_b32 v{tt + e}, a{base + e}")
+                        for e in range(4):
+                            A(f"v_mul_f32 v{tt + e}, v{tt + e}, {inv}")
+                        A("s_nop 0")
+                        A(f"buffer_store_dwordx4 {vr(tt, 4)}, v{goff}, {sr(S_ORS, 4)}, {so} offen offset:{128 * d + 32 * r4}")
+            A("L_epend_%=:")
         if timers:
             A("s_waitcnt vmcnt(0)")
             stamp(3)

@@ -13,6 +13,7 @@ FA_ABI_VERSION = 3
 FA_FLAG_KEEP_WINDOW = 1
 FA_FLAG_NO_DKV_SPLIT = 2
 FA_FLAG_DS_HANDOFF = 4
+FA_FLAG_FWD_KEY_SPLIT = 8
 
 _i64, _i32, _f32, _u64 = ctypes.c_int64, ctypes.c_int32, ctypes.c_float, ctypes.c_uint64
 _ptr = ctypes.c_void_p

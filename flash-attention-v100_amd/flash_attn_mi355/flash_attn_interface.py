@@ -203,6 +203,11 @@ def _base_params(q, dtype, scale, causal, window_size, softcap):
 # ======================================================================================
 # DENSE ATTENTION (B, M, H, D)
 # ======================================================================================
+# Opt-in experiment (include/fa_mi355.h: FA_FLAG_FWD_KEY_SPLIT; a net loss at the shapes it was built for, profiles/r06_fwd_split.txt):
+# causal launches of at most one wave of 256-row blocks split the key range of their heavy blocks.  FA_FWD_SPLIT=1 at import.
+FWD_SPLIT = os.environ.get("FA_FWD_SPLIT", "0") == "1"
+
+
 def _dense_forward(q, k, v, dropout_p, softmax_scale, causal, window_size, softcap, alibi_slopes,
                    return_softmax, out=None, keep_window=False):
     """One fa_fwd call on [B, S, H, D] views (any strides with a contiguous last dim).  keep_window (sharding.py only):
@@ -235,6 +240,8 @@ def _dense_forward(q, k, v, dropout_p, softmax_scale, causal, window_size, softc
     p.seqlen_q, p.seqlen_k = M, N
     if keep_window:
         p.flags = _lib.FA_FLAG_KEEP_WINDOW
+    if FWD_SPLIT:
+        p.flags |= _lib.FA_FLAG_FWD_KEY_SPLIT
     _set_head_dim(p, dpad)
     _alibi(p, alibi_slopes, B, H_Q, q.device)
     rng = _philox(p, dropout_p, B, H_Q, q.device)
@@ -244,6 +251,10 @@ def _dense_forward(q, k, v, dropout_p, softmax_scale, causal, window_size, softc
         p.dmask = _ptr(dmask)
     if q_.numel() > 0:                                   # (an empty query block is a no-op)
         with _on_device(q.device):
+            # (non-zero only with the opt-in key split of one-wave causal launches, include/fa_mi355.h: FA_FLAG_FWD_KEY_SPLIT)
+            ws = _workspace(_lib.lib.fa_fwd_workspace_bytes(ctypes.byref(p)), q.device) if (FWD_SPLIT and N > 0) else None
+            if ws is not None:
+                p.workspace, p.workspace_bytes = _ptr(ws), ws.numel()
             _lib.call("fa_fwd", p, _stream(q.device))
     if out is not None and out_ is not out:              # caller-allocated out the kernel could not write directly
         out.copy_(out_[..., :head_size_og])

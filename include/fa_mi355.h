@@ -47,6 +47,12 @@ extern "C" {
  * workspace (2 bytes per (query, key) pair and head: fa_bwd_workspace_bytes() reports it) instead of dQ recomputing S and dP.
  * Same results up to the order of fp32 additions.  Ignored where it does not apply. */
 #define FA_FLAG_DS_HANDOFF 4
+/* fa_fwd, opt-in, measured a net loss at the shapes it was built for (profiles/r06_fwd_split.txt).  A causal-like dense D = 128 launch
+ * whose 256-row query blocks all get a compute unit at once (batch x heads x ceil(Sq / 256) <= the CU count: micro-batch-1 training,
+ * batch-1 prefill, a tensor-parallel shard) runs as long as its heaviest block; with this flag and the workspace
+ * fa_fwd_workspace_bytes() reports, the heavy blocks' key ranges are cut into 2 - 4 parts whose fp32 partial outputs a merge kernel
+ * combines (deterministic; out / LSE equal the unsplit result up to the order of fp32 additions).  Ignored where it does not apply. */
+#define FA_FLAG_FWD_KEY_SPLIT 8
 
 typedef enum fa_dtype {
     FA_FP16 = 0,      /* IEEE half */
@@ -169,7 +175,7 @@ const char* fa_last_error(void);
 const char* fa_build_info(void);           /* arch, compiler, kernel variants */
 
 
-/* Workspace queries (bytes; 0 = none needed).  fa_fwd_workspace_bytes covers fa_fwd (always 0) and fa_varlen_fwd: non-zero
+/* Workspace queries (bytes; 0 = none needed).  fa_fwd_workspace_bytes covers fa_fwd (non-zero only with FA_FLAG_FWD_KEY_SPLIT on one-wave causal launches) and fa_varlen_fwd: non-zero
  * when the call is a decode step issued through the varlen op (every sequence brings the same <= 32 query tokens, paged
  * K / V) or a mixed batch whose sequences are mostly short (decode sequences next to a prefill chunk) - with the workspace
  * the split-KV decode kernels serve the short sequences, without it the general kernel serves everything (same results). */

@@ -187,3 +187,47 @@ def test_degenerate_shapes():
     assert torch.isfinite(o).all() and torch.isfinite(lse).all()
     # row 0 of causal attention is v[0]
     assert torch.allclose(o[0, 0].float(), q[0, 0].float(), atol=1e-3)
+
+
+# Forward key split of one-wave causal launches (opt-in: include/fa_mi355.h FA_FLAG_FWD_KEY_SPLIT, fa_fwd_asm.hip): the heavy 256-row
+# blocks of a launch whose blocks all get a CU at once leave fp32 partials per key range, a merge kernel combines them.
+FS_CASES = [
+    # B, Hq, Hk, Sq, Sk, dtype
+    (1, 32, 32, 2048, 2048, "bf16"),
+    (1, 32, 8, 2048, 2048, "fp16"),          # GQA
+    (1, 32, 32, 1900, 1900, "bf16"),         # ragged last block
+    (1, 16, 16, 2048, 3000, "bf16"),         # Sq < Sk: every block sees the 952 extra keys
+    (2, 8, 8, 4096, 4096, "fp16"),
+]
+
+
+@pytest.mark.parametrize("case", FS_CASES, ids=lambda c: "-".join(map(str, c)))
+def test_forward_key_split_vs_oracle(case, monkeypatch):
+    from flash_attn_mi355 import flash_attn_interface as fi
+    B, Hq, Hk, Sq, Sk, dt = case
+    D = 128
+    q, k, v = rand16((B, Sq, Hq, D), dt, 31), rand16((B, Sk, Hk, D), dt, 32), rand16((B, Sk, Hk, D), dt, 33)
+    real = fi._workspace
+    res = {}
+    for on in (False, True):
+        monkeypatch.setattr(fi, "FWD_SPLIT", on)
+        seen = []
+        monkeypatch.setattr(fi, "_workspace", lambda n, dev: (seen.append(n), real(n, dev))[1])
+        out, lse, _ = _fa().flash_attn_func(q, k, v, causal=True, return_attn_probs=True)
+        again, lse2, _ = _fa().flash_attn_func(q, k, v, causal=True, return_attn_probs=True)
+        assert torch.equal(out, again) and torch.equal(lse, lse2)           # deterministic either way
+        res[on] = (out, lse, max(seen) if seen else 0)
+    assert res[True][2] > 0 and res[False][2] == 0                           # the split path ran (it asked for its partial buffers)
+    assert_close(f64(res[True][0]), f64(res[False][0]), dt, "split vs unsplit")      # (one 16-bit ulp where the fp32 sums round differently)
+    assert_lse_close(f64(res[True][1]), f64(res[False][1]), "lse split vs unsplit")
+    hs = slice(0, Hq, max(1, Hq // 4))                                       # oracle on every fourth head
+    t = lambda x: f64(x).transpose(0, 2, 1, 3)
+    hk = slice(0, Hk, max(1, Hk // 4)) if Hq == Hk else None
+    if hk is not None:
+        o_ref, lse_ref, _ = oracle.attn_fwd(t(q)[:, hs], t(k)[:, hk], t(v)[:, hk], D ** -0.5, causal=True)
+        assert_close(t(res[True][0])[:, hs], o_ref, dt, "out (split)")
+        assert_lse_close(f64(res[True][1])[:, hs], lse_ref, "lse (split)")
+    else:
+        o_ref, lse_ref, _ = oracle.attn_fwd(t(q), t(k), t(v), D ** -0.5, causal=True)
+        assert_close(t(res[True][0]), o_ref, dt, "out (split)")
+        assert_lse_close(f64(res[True][1]), lse_ref, "lse (split)")

@@ -277,3 +277,23 @@ def test_backward_ds_handoff_workspace(lib):
         want = q(ctypes.byref(p))
         p.flags = lib.FA_FLAG_DS_HANDOFF
         assert q(ctypes.byref(p)) == want, change            # other kernels / a split launch: the flag is ignored
+
+
+def test_forward_key_split_workspace(lib):
+    """FA_FLAG_FWD_KEY_SPLIT (opt-in): a causal dense D = 128 launch of at most one wave of 256-row blocks (B x Hq x ceil(Sq / 256)
+    <= 256 CUs without a GPU) asks for fp32 partial outputs + LSEs of its split blocks; everything else asks for nothing."""
+    q = lib.lib.fa_fwd_workspace_bytes
+    p = _dense(lib, 1, 2048, 32, 32, 128)
+    assert q(ctypes.byref(p)) == 0                             # opt-in
+    p.flags = lib.FA_FLAG_FWD_KEY_SPLIT
+    # tiles per block 4 .. 32, 18 per CU if the work could be cut at will -> parts of <= 13 tiles: blocks 3 .. 7 split (2, 2, 2, 3, 3)
+    rows_split = 2048 - 3 * 256
+    assert q(ctypes.byref(p)) == 3 * 1 * 32 * rows_split * (128 + 1) * 4
+    p.is_causal = 0
+    assert q(ctypes.byref(p)) == 0                             # no causal imbalance
+    p = _dense(lib, 8, 4096, 16, 16, 128)                      # BASELINE config 2: 2048 blocks, the paired queue balances them
+    p.flags = lib.FA_FLAG_FWD_KEY_SPLIT
+    assert q(ctypes.byref(p)) == 0
+    p = _dense(lib, 1, 2048, 32, 32, 64)                       # other head dims: compiler kernels
+    p.flags = lib.FA_FLAG_FWD_KEY_SPLIT
+    assert q(ctypes.byref(p)) == 0
