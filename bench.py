@@ -24,8 +24,13 @@ Besides the contract fields the JSON line carries
                     2.5 PF peak assumes 2.4 GHz.  `traffic` is NOT measured in this run: it is the HBM byte count of
                     the committed rocprofv3 PMC passes (`traffic_source` names the file);
   kernels         - the same for every kernel of the step (fwd, bwd dK/dV, bwd dQ): median and min over individually
-                    evented launches, taken right behind the timed steps; `timing.sum_over_step` compares their sum
+                    evented launches, taken right IN FRONT of the timed steps; `timing.sum_over_step` compares their sum
                     with ms_per_step (tests/test_bench_contract.py fails a recorded line where they differ by > 3 %);
+  cold_start      - the same W + K steps timed straight behind the input set-up, on an idle socket: an MI355X needs ~15 steps
+                    (35-40 ms of work) to reach its sustained clock state and loses it again after 5 ms of idling
+                    (profiles/r06_step_ramp.txt), so a 45 ms region behind 13 ms of warm-up times the ramp - 2-3 % below the
+                    rate every later step runs at.  `value` is the same region timed again behind the per-kernel legs
+                    (0.3 s of the same launches), i.e. in the state a training loop runs in; rounds 1-5 reported the cold figure;
   other_configs   - BASELINE configs 3, 4 (fp8 and fp16 KV) and the config-5 shard, measured in the same run (rank 0);
   strong_scaling_config5 - BASELINE configs[4]: dense fwd bf16 causal + ALiBi, B64 H32 S8192 D128 with the 32 heads
                     sharded over the N ranks (flash_attn_mi355.sharding.shard_units / shard_alibi): total TFLOP/s at
@@ -526,48 +531,66 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    elapsed = max_over_ranks(dist, dist_backend, elapsed, dev)
+    def timed_region():
+        """the contract: W untimed warm-up steps, then EXACTLY K steps between barrier + synchronize on both sides, MAX over ranks"""
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        return max_over_ranks(dist, dist_backend, time.perf_counter() - t0, dev)
 
     ff = fwd_flops(c)
     step_flops = 3.5 * ff
+
+    # ---- (1) the K steps from a COLD socket: straight behind the input set-up, the first warm-up step loads the code objects
+    #      (~150 ms of host time with the GPU idle) and W = 5 steps are 13 ms.  An idle MI355X socket needs ~15 steps (35-40 ms
+    #      of work) to reach its sustained clock state - and an idle gap of 5 ms is enough to lose it again (tools/step_profile.py,
+    #      profiles/r06_step_ramp.txt: 2.99, 2.72, 2.55, 2.45, 2.40 ... 2.19 ms) - so this region times the RAMP.  Reported as
+    #      `cold_start`; it is what rounds 1-5 reported as `value`.
+    cold_elapsed = timed_region()
+
+    # ---- (2) per-kernel durations (HIP events on the launch stream) on EVERY rank - only rank 0 reports them, but every socket has
+    #      to stay busy: ~0.3 s of back-to-back launches, the same kernels as the steps, which also brings the socket to the state
+    #      a training loop runs in --------------------------------------------------------------------------------------------
+    kern, kmin, kmean = {}, {}, {}
+    it = 30
+    with torch.no_grad():
+        st = med_min(event_times_ms(lambda: flash_attn.flash_attn_func(q, k, v, causal=c["causal"]), it, warm=3))
+        kern["fwd"], kmin["fwd"], kmean["fwd"] = st[0], st[1], st.mean
+    # which backward kernels run follows from the gradients the op has to produce (autograd's needs_input_grad ->
+    # fa_bwd with dq == NULL or dk == dv == NULL): q alone = the dQ kernel, k and v = preprocess + dK/dV kernel,
+    # all three = dQ kernel + dK/dV kernel (the step's backward)
+    qd, kd, vd = q.detach(), k.detach(), v.detach()
+    graphs = {"bwd_all": (flash_attn.flash_attn_func(q, k, v, causal=c["causal"]), (q, k, v)),
+              "bwd_dq": (flash_attn.flash_attn_func(q, kd, vd, causal=c["causal"]), (q,)),
+              "bwd_dkdv_pre": (flash_attn.flash_attn_func(qd, k, v, causal=c["causal"]), (k, v))}
+    for name, (o, ins) in graphs.items():
+        st = med_min(event_times_ms(lambda: torch.autograd.grad(o, ins, do, retain_graph=True), it, warm=3))
+        kern[name], kmin[name], kmean[name] = st[0], st[1], st.mean
+    del graphs, o
+
+    def fb():
+        oo = flash_attn.flash_attn_func(q, k, v, causal=c["causal"])
+        oo.backward(do)
+        q.grad = k.grad = v.grad = None
+    st = med_min(event_times_ms(fb, it, warm=3))
+    kern["step"], kmin["step"], kmean["step"] = st[0], st[1], st.mean
+
+    # ---- (3) `value`: the contract's timed region again, now on a socket in its sustained state - W warm-up steps, barrier +
+    #      synchronize, EXACTLY K steps, barrier + synchronize, MAX over ranks.  With N > 1 a rendezvous first, so that the ranks
+    #      enter their warm-up steps together and the bracketing barrier finds them aligned (a rank waiting 5 ms in a barrier would
+    #      start its timed steps on a socket that has dropped its clocks).
+    if dist is not None:
+        dist.barrier()
+    elapsed = timed_region()
     ms_per_step = elapsed / args.steps * 1e3
     value = world * step_flops / (elapsed / args.steps) / 1e12
+    cold_ms = cold_elapsed / args.steps * 1e3
 
-    # ---- per-kernel durations (rank 0; HIP events on the launch stream), right behind the timed steps and BEFORE the
-    #      28 ms config-5 launches, so that they are taken in the power / clock state the steps ran in ------------------
-    kern, kmin, kmean = {}, {}, {}
     if rank == 0:
-        it = 30
-        with torch.no_grad():
-            st = med_min(event_times_ms(lambda: flash_attn.flash_attn_func(q, k, v, causal=c["causal"]), it, warm=3))
-            kern["fwd"], kmin["fwd"], kmean["fwd"] = st[0], st[1], st.mean
-        # which backward kernels run follows from the gradients the op has to produce (autograd's needs_input_grad ->
-        # fa_bwd with dq == NULL or dk == dv == NULL): q alone = the dQ kernel, k and v = preprocess + dK/dV kernel,
-        # all three = dQ kernel + dK/dV kernel (the step's backward)
-        qd, kd, vd = q.detach(), k.detach(), v.detach()
-        graphs = {"bwd_all": (flash_attn.flash_attn_func(q, k, v, causal=c["causal"]), (q, k, v)),
-                  "bwd_dq": (flash_attn.flash_attn_func(q, kd, vd, causal=c["causal"]), (q,)),
-                  "bwd_dkdv_pre": (flash_attn.flash_attn_func(qd, k, v, causal=c["causal"]), (k, v))}
-        for name, (o, ins) in graphs.items():
-            st = med_min(event_times_ms(lambda: torch.autograd.grad(o, ins, do, retain_graph=True), it, warm=3))
-            kern[name], kmin[name], kmean[name] = st[0], st[1], st.mean
-        del graphs, o
-
-        def fb():
-            oo = flash_attn.flash_attn_func(q, k, v, causal=c["causal"])
-            oo.backward(do)
-            q.grad = k.grad = v.grad = None
-        st = med_min(event_times_ms(fb, it, warm=3))
-        kern["step"], kmin["step"], kmean["step"] = st[0], st[1], st.mean
-
         # ---- the step sustained for ~2 s with power / clock sampled (this is also what a coarse GPU-busy sampler gets to
         #      see: the K timed steps above are 45 ms), then the bare-MFMA ceiling of this socket in the same state -------
         smi = _Smi(local_rank if world > 1 else 0)
@@ -636,7 +659,8 @@ def main():
                              "sum_over_step": round(sum_k / ms_per_step, 4),
                              "note": "sum_over_step_evented = (median fwd + median bwd) / median evented step: the same statistic on "
                                      "both sides; sum_over_step divides by ms_per_step, the wall-clock MEAN of the K timed steps "
-                                     "(includes the slow outlier launches a median drops and the host-side tail)"}
+                                     "(includes the slow outlier launches a median drops and the host-side tail); the evented "
+                                     "launches run right in front of the timed region"}
         dom = max(("fwd", "bwd_dkdv", "bwd_dq"), key=lambda n: dur[n])
         fwd_kernel = "fa_fwd_kernel" if os.environ.get("FA_FWD_ASM") == "0" else "fa_fwd_asm_kernel"
         dkdv_kernel = "fa_bwd_dkdv2_kernel" if os.environ.get("FA_BWD_ASM") == "0" else "fa_bwd_dkdv_asm_kernel"
@@ -653,7 +677,7 @@ def main():
             roofline["fwd_frac_of_ceiling"] = round(kernels["fwd"]["achieved_mean"] / ceiling["tflops"], 4)
         roofline["sustained_step"] = {"ms": round(sus_ms, 4), "steps": sus_n, "tflops": round(step_flops / (sus_ms * 1e-3) / 1e12, 1),
                                       "watts": sus_state["watts"], "mhz": sus_state["mhz"], "power_source": sus_state["source"],
-                                      "note": "the step back to back for ~2 s after the timed region, socket power and shader clock sampled every 50 ms"}
+                                      "note": "the step back to back for ~2 s right behind the timed region, socket power and shader clock sampled every 50 ms"}
         tr = measured_traffic(roofline["kernel"])
         if tr:
             roofline["traffic"] = tr[0]
@@ -670,6 +694,10 @@ def main():
             "frac_of_mfma_peak": round(value / world / PEAK_BF16_TFLOPS, 4),
             "fwd_tflops": kernels["fwd"]["achieved"], "fwd_frac_of_mfma_peak": kernels["fwd"]["frac"],
             "roofline": roofline, "kernels": kernels,
+            "cold_start": {"ms_per_step": round(cold_ms, 4), "value": round(world * step_flops / (cold_ms * 1e-3) / 1e12, 2),
+                           "note": "the same W warm-up + K timed steps straight behind the input set-up, on an idle socket (clock ramp: "
+                                   "profiles/r06_step_ramp.txt); `value` is the region timed again behind the per-kernel legs - every "
+                                   "rank runs them -, the state every step of a training loop after the first 40 ms runs in"},
         }
         if world > 1:
             out["dist_backend"] = dist_backend      # barrier + MAX only (no data-path collective): "nccl" = RCCL, "gloo" = the CPU fallback
