@@ -92,6 +92,16 @@ def med_min(ts):
     return r
 
 
+def settle(fn, ms=60.0):
+    """Back-to-back calls of `fn` for >= `ms` of GPU time, no synchronize at the end: an MI355X that has idled for 5 ms (input
+    set-up on the host, a synchronize with host work behind it) runs its next ~35 ms of launches on a clock ramp, up to 35 % slow
+    (profiles/r06_step_ramp.txt).  Every leg below measures behind one of these - the state a serving or training loop runs in."""
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record(); fn(); b.record(); b.synchronize()
+    for _ in range(min(4000, int(ms / max(a.elapsed_time(b), 1e-3)) + 1)):
+        fn()
+
+
 def event_time_ms(fn, iters, warm=1):
     """Median duration of `fn` over `iters` individually-evented calls."""
     return med_min(event_times_ms(fn, iters, warm))[0]
@@ -332,15 +342,19 @@ def config3(flash_attn, dev):
         return a.elapsed_time(b) / n
 
     with torch.no_grad():
+        settle(fwd)
         t_f = event_time_ms(fwd, 10, warm=3)
         t_fs = sustained_ms(fwd)
+    settle(fb)
     t_fb = event_time_ms(fb, 10, warm=3)
     t_fbs = sustained_ms(fb, 20)
     return {"workload": "varlen fp16 B64 mixed seqlens (max 2048) H32 D64 window (512,0)", "total_tokens": T,
             "fwd_ms": round(t_f, 4), "fwd_tflops": round(flops / t_f / 1e9, 1),
             "fwd_frac_of_mfma_peak": round(flops / t_f / 1e9 / PEAK_BF16_TFLOPS, 4),
             "fwd_bwd_ms": round(t_fb, 4), "fwd_bwd_tflops": round(3.5 * flops / t_fb / 1e9, 1),
-            "timing": "fwd_ms / fwd_bwd_ms: medians of 10 individually evented calls; *_sustained_*: 40 (20) back-to-back calls between two events",
+            "timing": "fwd_ms / fwd_bwd_ms: medians of 10 individually evented calls; *_sustained_*: 40 (20) back-to-back calls between two events; "
+                      "each pair behind 60 ms of the same calls (settle(): rounds 1-5 measured on the clock ramp of a socket that had idled "
+                      "through the input set-up, profiles/r06_step_ramp.txt)",
             "fwd_sustained_ms": round(t_fs, 4), "fwd_sustained_tflops": round(flops / t_fs / 1e9, 1),
             "fwd_bwd_sustained_ms": round(t_fbs, 4), "fwd_bwd_sustained_tflops": round(3.5 * flops / t_fbs / 1e9, 1)}
 
@@ -369,6 +383,7 @@ def config4(flash_attn, dev, kv_dtype, Hk=32):
     fn = lambda: flash_attn.flash_attn_with_kvcache(q, kc, vc, k=kn, v=vn, rotary_cos=cos, rotary_sin=sin,
                                                     cache_seqlens=seqlens, block_table=bt, causal=True,
                                                     rotary_interleaved=False, **kw)
+    settle(fn)
     ms = event_time_ms(fn, 10, warm=3)
     nbytes = 2.0 * B * (L + 1) * Hk * D * kc.element_size()
     return {"workload": f"decode B128 H32{'' if Hk == 32 else '/%d' % Hk} D128 cache 8192 paged(256)+rotary, KV {'fp8-e4m3' if kc.element_size() == 1 else 'fp16'}",
@@ -395,6 +410,7 @@ def serving_steps(flash_attn, dev):
             fn = lambda: flash_attn.flash_attn_varlen_func(qv, kc, vc, cu_q, cu_k, Tq, ctx, causal=True, block_table=bt, seqused_k=lens)
         else:
             fn = lambda: flash_attn.flash_attn_with_kvcache(q, kc, vc, cache_seqlens=lens, block_table=bt, causal=kw.get("softcap", 0.0) == 0.0, **kw)
+        settle(fn, 40.0)
         ts = event_times_ms(fn, 20, warm=12)
         out[name] = round(sorted(ts)[len(ts) // 2] * 1e3, 1)
     run("decode_B1_us", 1, 1, 32, 8, 128, 8192)
@@ -405,7 +421,7 @@ def serving_steps(flash_attn, dev):
     run("decode_B8_softcap_us", 8, 1, 32, 8, 128, 8192, softcap=50.0)
     run("decode_B8_D256_us", 8, 1, 16, 8, 256, 8192)
     run("decode_B8_via_varlen_op_us", 8, 1, 32, 8, 128, 8192, varlen=True)
-    out["workload"] = "decode step latency, H 32/8 (D256: 16/8), paged(256) bf16 cache, context 8192 unless named; medians of 20 evented calls"
+    out["workload"] = "decode step latency, H 32/8 (D256: 16/8), paged(256) bf16 cache, context 8192 unless named; medians of 20 evented calls behind 40 ms of the same calls"
     return out
 
 
@@ -422,6 +438,7 @@ def config5(flash_attn, dev, world, rank, iters=3, warm=2):
     q, k, v = mk(), mk(), mk()
     fn = lambda: flash_attn.flash_attn_func(q, k, v, causal=True, alibi_slopes=sl)
     with torch.no_grad():
+        settle(fn)
         ms = event_time_ms(fn, iters, warm=warm)
     flops = 4.0 * Bs * Hs * S * S * D / 2
     return ms, flops, Bs, Hs
