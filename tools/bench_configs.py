@@ -21,8 +21,12 @@ import flash_attn  # noqa: E402
 PEAK_TF, PEAK_GBS = 2500.0, 8000.0
 
 
-def timeit(fn, iters=10, warm=10):
-    for _ in range(warm):
+def timeit(fn, iters=10, warm=10, settle_ms=60.0):
+    """mean of `iters` back-to-back calls between two events, behind `warm` calls AND >= settle_ms of the same calls: an idle MI355X
+    runs its next ~35 ms of launches on a clock ramp (profiles/r06_step_ramp.txt) - 10 warm-up calls of a 0.5 ms kernel end inside it"""
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record(); fn(); e.record(); e.synchronize()
+    for _ in range(max(warm, min(4000, int(settle_ms / max(s.elapsed_time(e), 1e-3)) + 1))):
         fn()
     torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
