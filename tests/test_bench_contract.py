@@ -68,7 +68,12 @@ def test_bench_json_line_contract():
     t = d["kernels"]["timing"]
     assert abs(t["sum_of_kernels_ms"] - (d["kernels"]["fwd"]["ms"] + d["kernels"]["bwd_all"]["ms"])) < 1e-3
     assert 0.97 <= t["sum_over_step_evented"] <= 1.03, t        # same statistic on both sides: the kernels compose the step
-    assert 0.95 <= t["sum_over_step"] <= 1.03, t                # vs the wall-clock mean of the timed steps (outliers, host tail)
+    assert 0.97 <= t["sum_over_step"] <= 1.03, t                # vs the wall-clock mean of the timed steps: the region runs on a socket
+    #                                                              in its sustained state (0.974 when it timed the clock ramp)
+    # the same W + K region timed from an idle socket rides along; the sustained figure is not slower than the ramp
+    cs = d["cold_start"]
+    assert cs["ms_per_step"] > 0 and abs(cs["value"] - 1924.16e9 / (cs["ms_per_step"] * 1e-3) / 1e12) / cs["value"] < 1e-2
+    assert d["ms_per_step"] <= 1.02 * cs["ms_per_step"], (d["ms_per_step"], cs)
     for name in ("fwd", "bwd_dq", "bwd_all"):
         assert d["kernels"][name]["ms_min"] <= d["kernels"][name]["ms"]
 
