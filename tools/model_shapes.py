@@ -4,7 +4,10 @@ import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "flash-attention-v100_amd"))
 import torch, flash_attn as fa
 def t_ms(f, n=10):
-    for _ in range(3): f()
+    # >= 60 ms of the same calls first: an idle socket runs its next ~35 ms of launches on a clock ramp (profiles/r06_step_ramp.txt)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record(); f(); b.record(); b.synchronize()
+    for _ in range(max(3, min(4000, int(60.0 / max(a.elapsed_time(b), 1e-3)) + 1))): f()
     torch.cuda.synchronize()
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
     for s, e in evs:
