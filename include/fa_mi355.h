@@ -42,7 +42,7 @@ extern "C" {
  * 16-bit partial dK / dV in fp32 (deterministic; needs the workspace fa_bwd_workspace_bytes() reports).  dK / dV then differ in
  * the last bit from the one-workgroup-per-key-block result.  FA_FLAG_NO_DKV_SPLIT keeps one workgroup per key block. */
 #define FA_FLAG_NO_DKV_SPLIT 2
-/* fa_bwd, opt-in, measured at break-even (profiles/r06_ds_handoff.txt): where the dense D = 128 backward would run its two generated
+/* fa_bwd, opt-in, measured at break-even over short runs and 5 % slower sustained (profiles/r06_ds_handoff.txt): where the dense D = 128 backward would run its two generated
  * kernels and all three gradients are requested, the dK/dV kernel hands its 16-bit dS tiles to a one-GEMM dQ kernel through the
  * workspace (2 bytes per (query, key) pair and head: fa_bwd_workspace_bytes() reports it) instead of dQ recomputing S and dP.
  * Same results up to the order of fp32 additions.  Ignored where it does not apply. */
