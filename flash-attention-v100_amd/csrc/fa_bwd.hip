@@ -1176,10 +1176,15 @@ __global__ void __launch_bounds__(BWD_THREADS, D <= 64 ? FA_DKV2_OCC64 : 2) fa_b
     }
 
     if (my_key < sg.seqlen_k) {
+        // (the output addresses are formed HERE: left visible, hipcc computes the two 64-bit lane pointers in front of the stage loop
+        //  and, at three workgroups per CU - 168 registers -, parks them in scratch across it; the lane's key index passes through an
+        //  opaque asm so that nothing below can be hoisted)
+        int my_key_e = my_key, g_e = g;
+        asm volatile("" : "+v"(my_key_e), "+v"(g_e));
         const int64_t dkb = p.cu_seqlens_k ? 0 : (int64_t)b * p.dk_batch_stride;
         const int64_t dvb = p.cu_seqlens_k ? 0 : (int64_t)b * p.dv_batch_stride;
-        uint16_t* dkp = reinterpret_cast<uint16_t*>(p.dk) + dkb + (sg.k_row0 + my_key) * p.dk_row_stride + (int64_t)hk * p.dk_head_stride;
-        uint16_t* dvp = reinterpret_cast<uint16_t*>(p.dv) + dvb + (sg.k_row0 + my_key) * p.dv_row_stride + (int64_t)hk * p.dv_head_stride;
+        uint16_t* dkp = reinterpret_cast<uint16_t*>(p.dk) + dkb + (sg.k_row0 + my_key_e) * p.dk_row_stride + (int64_t)hk * p.dk_head_stride;
+        uint16_t* dvp = reinterpret_cast<uint16_t*>(p.dv) + dvb + (sg.k_row0 + my_key_e) * p.dv_row_stride + (int64_t)hk * p.dv_head_stride;
         if (PART) {
             // partial dK / dV of this split, fp32 [dK | dV][split][B][Sk][Hk][D]: the accumulators as they are (dK scaled, dV
             // with the dropout factor) - dkv_reduce_kernel adds the splits and rounds once
@@ -1193,11 +1198,11 @@ __global__ void __launch_bounds__(BWD_THREADS, D <= 64 ? FA_DKV2_OCC64 : 2) fa_b
             for (int d = 0; d < DBLKS; ++d)
 #pragma unroll
                 for (int rq = 0; rq < 4; ++rq) {
-                    if (d * 32 + 8 * rq + 4 * g < dv) {
+                    if (d * 32 + 8 * rq + 4 * g_e < dv) {
                         const f32x4 k4 = {dk_acc[d][4 * rq + 0] * sc, dk_acc[d][4 * rq + 1] * sc, dk_acc[d][4 * rq + 2] * sc, dk_acc[d][4 * rq + 3] * sc};
                         const f32x4 v4 = {dv_acc[d][4 * rq + 0] * rp, dv_acc[d][4 * rq + 1] * rp, dv_acc[d][4 * rq + 2] * rp, dv_acc[d][4 * rq + 3] * rp};
-                        *reinterpret_cast<f32x4*>(pk + d * 32 + 8 * rq + 4 * g) = k4;
-                        *reinterpret_cast<f32x4*>(pv + d * 32 + 8 * rq + 4 * g) = v4;
+                        *reinterpret_cast<f32x4*>(pk + d * 32 + 8 * rq + 4 * g_e) = k4;
+                        *reinterpret_cast<f32x4*>(pv + d * 32 + 8 * rq + 4 * g_e) = v4;
                     }
                 }
         } else {
@@ -1212,9 +1217,9 @@ __global__ void __launch_bounds__(BWD_THREADS, D <= 64 ? FA_DKV2_OCC64 : 2) fa_b
                 const float rp = DROPOUT ? a.rp_dropout : 1.0f;
                 v2[0] = E::pack2(dv_acc[d][4 * rq + 0] * rp, dv_acc[d][4 * rq + 1] * rp);
                 v2[1] = E::pack2(dv_acc[d][4 * rq + 2] * rp, dv_acc[d][4 * rq + 3] * rp);
-                if (d * 32 + 8 * rq + 4 * g < dv) {
-                    *reinterpret_cast<u32x2*>(dkp + d * 32 + 8 * rq + 4 * g) = k2;
-                    *reinterpret_cast<u32x2*>(dvp + d * 32 + 8 * rq + 4 * g) = v2;
+                if (d * 32 + 8 * rq + 4 * g_e < dv) {
+                    *reinterpret_cast<u32x2*>(dkp + d * 32 + 8 * rq + 4 * g_e) = k2;
+                    *reinterpret_cast<u32x2*>(dvp + d * 32 + 8 * rq + 4 * g_e) = v2;
                 }
             }
         }

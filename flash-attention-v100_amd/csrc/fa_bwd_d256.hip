@@ -354,23 +354,26 @@ __global__ void __launch_bounds__(SPLIT_THREADS, 1) fa_bwd_dkdv_split_kernel(con
 
     if (my_key < sg.seqlen_k) {
         // the P wave stores dV, the dS wave dK * softmax_scale
+        // (addresses from opaque copies of the lane's key and half: nothing below is hoisted over the stage loop and parked in scratch)
+        int key_e = my_key, g_e = g;
+        asm volatile("" : "+v"(key_e), "+v"(g_e));
         const int64_t ob = p.cu_seqlens_k ? 0 : (int64_t)b * (role == 0 ? p.dv_batch_stride : p.dk_batch_stride);
         uint16_t* op = reinterpret_cast<uint16_t*>(role == 0 ? p.dv : p.dk) + ob +
-                       (sg.k_row0 + my_key) * (role == 0 ? p.dv_row_stride : p.dk_row_stride) +
+                       (sg.k_row0 + key_e) * (role == 0 ? p.dv_row_stride : p.dk_row_stride) +
                        (int64_t)hk * (role == 0 ? p.dv_head_stride : p.dk_head_stride);
         const float sc = role == 0 ? 1.0f : p.softmax_scale;
         if (PART) {
             // fp32 partial of this split, [dK | dV][split][B][Sk][Hk][D]: dkv_reduce_kernel adds the splits and rounds once
             const int64_t row = (int64_t)p.nheads_k * D;
             const int64_t slab = (p.cu_seqlens_k ? (int64_t)p.total_k : (int64_t)p.batch * p.seqlen_k) * row;
-            const int64_t krow = p.cu_seqlens_k ? sg.k_row0 + my_key : (int64_t)b * p.seqlen_k + my_key;
+            const int64_t krow = p.cu_seqlens_k ? sg.k_row0 + key_e : (int64_t)b * p.seqlen_k + key_e;
             float* pp = reinterpret_cast<float*>(a.dkv_part) + ((role == 0 ? nsplit : 0) + split) * slab + krow * row + (int64_t)hk * D;
 #pragma unroll
             for (int d = 0; d < DBLKS; ++d)
 #pragma unroll
                 for (int rq = 0; rq < 4; ++rq) {
                     const f32x4 o4 = {acc[d][4 * rq + 0] * sc, acc[d][4 * rq + 1] * sc, acc[d][4 * rq + 2] * sc, acc[d][4 * rq + 3] * sc};
-                    if (d * 32 + 8 * rq + 4 * g < dv) *reinterpret_cast<f32x4*>(pp + d * 32 + 8 * rq + 4 * g) = o4;
+                    if (d * 32 + 8 * rq + 4 * g_e < dv) *reinterpret_cast<f32x4*>(pp + d * 32 + 8 * rq + 4 * g_e) = o4;
                 }
         } else
 #pragma unroll
@@ -380,7 +383,7 @@ __global__ void __launch_bounds__(SPLIT_THREADS, 1) fa_bwd_dkdv_split_kernel(con
                 u32x2 o2;
                 o2[0] = E::pack2(acc[d][4 * rq + 0] * sc, acc[d][4 * rq + 1] * sc);
                 o2[1] = E::pack2(acc[d][4 * rq + 2] * sc, acc[d][4 * rq + 3] * sc);
-                if (d * 32 + 8 * rq + 4 * g < dv) *reinterpret_cast<u32x2*>(op + d * 32 + 8 * rq + 4 * g) = o2;
+                if (d * 32 + 8 * rq + 4 * g_e < dv) *reinterpret_cast<u32x2*>(op + d * 32 + 8 * rq + 4 * g_e) = o2;
             }
     }
     }   // pass

@@ -768,8 +768,14 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : FA_FWD_OCC)) fa_fw
     const float l_tot = xhalf_sum(l_run);
     const float inv = l_tot > 0.f ? (DROPOUT ? a.rp_dropout : (KV8 ? p.v_descale : 1.0f)) / l_tot : 0.f;
     if (my_row < seqlen_q) {
+        // (the store addresses are formed HERE from opaque copies of the lane's row and half: left visible, hipcc computes the 64-bit lane
+        //  pointers in front of the tile loop and parks them in scratch / AGPRs across it - csrc/spill_budget.json)
+        int row_e = my_row, g_e = g;
+#ifndef FA_FWD_TU_D256                                  // (head dim 256: one wave per SIMD, nothing is parked in scratch there; the copies cost it 4 AGPR moves)
+        asm volatile("" : "+v"(row_e), "+v"(g_e));
+#endif
         uint16_t* op = reinterpret_cast<uint16_t*>(p.o) + (p.cu_seqlens_q ? 0 : (int64_t)w.b * p.o_batch_stride)
-                       + (q_row0 + my_row) * p.o_row_stride + (int64_t)w.h * p.o_head_stride;
+                       + (q_row0 + row_e) * p.o_row_stride + (int64_t)w.h * p.o_head_stride;
 #pragma unroll
         for (int d = 0; d < DBLKS; ++d)
 #pragma unroll
@@ -777,11 +783,11 @@ __global__ void __launch_bounds__(FWD_THREADS, (D > 128 ? 1 : FA_FWD_OCC)) fa_fw
                 u32x2 o2;
                 o2[0] = E::pack2(oacc[d][4 * rq + 0] * inv, oacc[d][4 * rq + 1] * inv);
                 o2[1] = E::pack2(oacc[d][4 * rq + 2] * inv, oacc[d][4 * rq + 3] * inv);
-                if (d * 32 + 8 * rq + 4 * g < dv) *reinterpret_cast<u32x2*>(op + d * 32 + 8 * rq + 4 * g) = o2;
+                if (d * 32 + 8 * rq + 4 * g_e < dv) *reinterpret_cast<u32x2*>(op + d * 32 + 8 * rq + 4 * g_e) = o2;
             }
-        if (g == 0) {
+        if (g_e == 0) {
             const float lse = l_tot > 0.f ? (m_run + fast_log2(l_tot)) * kLn2 : -INFINITY;
-            p.lse[(int64_t)w.b * p.lse_batch_stride + (int64_t)w.h * p.lse_head_stride + q_row0 + my_row] = lse;
+            p.lse[(int64_t)w.b * p.lse_batch_stride + (int64_t)w.h * p.lse_head_stride + q_row0 + row_e] = lse;
         }
     }
     // ---- next pass: fresh accumulators ----
