@@ -285,19 +285,20 @@ __global__ void __launch_bounds__(64 * NW, 1) fa_decode_kernel(const DecArgs da)
     constexpr int NS = (KV8 && NW == 8 && D <= 64) ? FA_DEC_NS8W8 : ((D > 128 || NW == 8) ? FA_DEC_NS256 : (KV8 ? FA_DEC_NS8 : FA_DEC_NS16));
     constexpr int STAGES = DecSmem<D, NW>::STAGES;
     u32x4 kS[NS][CH], vS[NS][CH];
-    // loop-invariant per-lane byte offsets inside a tile (row * row_stride + 16-byte column)
-    uint32_t k_voff[CH], v_voff[CH];
+    // loop-invariant per-lane byte offset inside a tile (row * row_stride + 16-byte column) of the lane's FIRST chunk; chunk i lies
+    // i * RPS rows further down (64 lanes cover 64 / CPR whole rows per load step), which is a UNIFORM distance: it goes into the
+    // scalar base of load i.  (As sixteen per-lane offsets - round 1's form - the 16-bit eight-wave kernel parked three of them in
+    // scratch and reloaded them INSIDE the tile loop, each reload followed by an `s_waitcnt vmcnt(0)` that drained the K / V loads
+    // issued before it: profiles/r06_decode.txt section 3.)
+    static_assert(64 % CPR == 0, "a load step covers whole rows");
     bool cok[CH];                                           // NARROW: is this lane's chunk inside the row?
     const int vchunks = vcols * EB / 16;
+    const int cc0 = lane % CPR;
 #pragma unroll
-    for (int i = 0; i < CH; ++i) {
-        const int cidx = lane + 64 * i;
-        const int row = cidx / CPR, cc = cidx % CPR;
-        cok[i] = !NARROW || cc < vchunks;
-        const int ccl = cok[i] ? cc : 0;                    // (a chunk past the row reads chunk 0 and is zeroed)
-        k_voff[i] = (uint32_t)(row * p.k_row_stride * EB + ccl * 16);
-        v_voff[i] = (uint32_t)(row * p.v_row_stride * EB + ccl * 16);
-    }
+    for (int i = 0; i < CH; ++i) cok[i] = !NARROW || cc0 < vchunks;
+    const int ccl0 = cok[0] ? cc0 : 0;                      // (a chunk past the row reads chunk 0 and is zeroed)
+    const uint32_t k_voff0 = (uint32_t)((lane / CPR) * p.k_row_stride * EB + ccl0 * 16);
+    const uint32_t v_voff0 = (uint32_t)((lane / CPR) * p.v_row_stride * EB + ccl0 * 16);
     const u32x4 zero4 = {0, 0, 0, 0};
     // a 16-row half of a tile lies inside one page when the left pad and the page size are multiples of 16
     // (pages of 16 tokens - vLLM's default block - hold half a 32-key tile: the tile's two 16-row halves take their own
@@ -337,10 +338,11 @@ __global__ void __launch_bounds__(64 * NW, 1) fa_decode_kernel(const DecArgs da)
         const uint8_t* vb2 = PAGED && BN > 16 ? vbase + vo2 * EB : vb;
         // (the empty asm keeps the zero-extension of the 32-bit lane offset next to the load: hoisted out of the loop as a
         //  64-bit pair it cost a v_lshl_add_u64 per load and 16 registers; here the load takes SGPR base + 32-bit VGPR offset)
+        const int64_t kstep = (int64_t)(64 / CPR) * p.k_row_stride * EB, vstep = (int64_t)(64 / CPR) * p.v_row_stride * EB;
 #pragma unroll
-        for (int i = 0; i < CH; ++i) { uint32_t o = k_voff[i]; FA_DEC_PIN(o); kreg[i] = *reinterpret_cast<const u32x4*>((i * RPS >= 16 ? kb2 : kb) + o); }
+        for (int i = 0; i < CH; ++i) { uint32_t o = k_voff0; FA_DEC_PIN(o); kreg[i] = *reinterpret_cast<const u32x4*>((i * RPS >= 16 ? kb2 : kb) + i * kstep + o); }
 #pragma unroll
-        for (int i = 0; i < CH; ++i) { uint32_t o = v_voff[i]; FA_DEC_PIN(o); vreg[i] = *reinterpret_cast<const u32x4*>((i * RPS >= 16 ? vb2 : vb) + o); }
+        for (int i = 0; i < CH; ++i) { uint32_t o = v_voff0; FA_DEC_PIN(o); vreg[i] = *reinterpret_cast<const u32x4*>((i * RPS >= 16 ? vb2 : vb) + i * vstep + o); }
     };
     (void)cok; (void)zero4;
     auto load_tile = [&](int tile, u32x4 (&kreg)[CH], u32x4 (&vreg)[CH]) {
