@@ -6,8 +6,12 @@ sys.path.insert(0, os.path.join(ROOT, "flash-attention-v100_amd"))
 import flash_attn
 from flash_attn_mi355 import flash_attn_interface as fi
 warnings.simplefilter("ignore")
-def b2b(fn, n=50):
-    for _ in range(10): fn()
+def b2b(fn, n=500):
+    # >= 60 ms of the same calls first (an idle socket runs its next ~35 ms of launches on a clock ramp, profiles/r06_step_ramp.txt: the
+    # first version of this tool timed 50 launches behind 10 - ~4 ms in all - and measured the split variant FIRST, i.e. colder)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record(); fn(); b.record(); b.synchronize()
+    for _ in range(min(4000, int(60.0 / max(a.elapsed_time(b), 1e-3)) + 1)): fn()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
     for _ in range(n): fn()
