@@ -426,6 +426,8 @@ DS_CASES = [
 
 @pytest.mark.parametrize("case", DS_CASES, ids=lambda c: "-".join(map(str, c)))
 def test_ds_handoff_backward_vs_oracle(case, monkeypatch):
+    if os.environ.get("FA_BWD_ASM") == "0" or os.environ.get("FA_BWD_DQ_ASM") == "0":
+        pytest.skip("the hand-off lives in the generated dK/dV kernel: an A/B run on the compiler-scheduled kernels has nothing to test here")
     from flash_attn_mi355 import flash_attn_interface as fi
     B, Hq, Hk, Sq, Sk, dt, causal, window = case
     D = 128
